@@ -1,0 +1,226 @@
+/*
+ * nafgpu.h -- C-ABI of libnafgpu, the MI355X-native NAF decode path.
+ *
+ * This is the drop-in boundary for the hot path of althonos/nafcodec v0.3.1
+ * (/root/reference): everything below the crate's public `Decoder` iterator --
+ * container parse, per-section Zstandard decompression, 4-bit -> IUPAC unpack,
+ * mask application, record slicing -- runs behind these entry points, on the GPU.
+ * The reference has no FFI seam inside the path; the seam is its
+ * public L3 API, so each entry point names the reference item it replaces.
+ * A Rust / C++ / Python shim re-creates `Decoder`/`DecoderBuilder`/`Record` on
+ * top (INTEGRATION.md shows the Rust one; include/nafcodec.hpp and
+ * nafcodec_amd/ are the C++ and Python ones).
+ *
+ * Conventions: plain pointers and sizes only; no HIP or torch types.  Every
+ * function returns NAFGPU_OK (0) or a negative nafgpu_status unless stated.
+ * A decoder may move between threads but calls on one decoder must be
+ * serialised by the caller (mirrors `Send + !Sync`, nafcodec/src/lib.rs:24-28).
+ * Nothing here aborts or throws across the boundary.
+ */
+#ifndef NAFGPU_H
+#define NAFGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NAFGPU_ABI_VERSION 1
+
+/* ---- status / error kinds ------------------------------------------------
+ * Mirrors nafcodec::Error (nafcodec/src/error.rs:4-11) plus the std::io kinds
+ * the decode path raises (decoder/mod.rs:180-185, 430-435; reader.rs:108-109). */
+typedef enum {
+    NAFGPU_OK = 0,
+    NAFGPU_END = 1,              /* Iterator::next -> None (decoder/mod.rs:447-449) */
+    NAFGPU_E_IO = -1,            /* Error::Io; see nafgpu_error.io_kind */
+    NAFGPU_E_NOM = -2,           /* Error::Nom; see nafgpu_error.nom_code */
+    NAFGPU_E_UTF8 = -3,          /* Error::Utf8 */
+    NAFGPU_E_PANIC = -4,         /* the reference panics / never returns on this input */
+    NAFGPU_E_DEVICE = -5,        /* HIP runtime failure, no usable GPU, out of device memory */
+    NAFGPU_E_INVALID_ARG = -6
+} nafgpu_status;
+
+typedef enum {                   /* std::io::ErrorKind values used on the path */
+    NAFGPU_IO_NONE = 0,
+    NAFGPU_IO_UNEXPECTED_EOF = 1,
+    NAFGPU_IO_INVALID_DATA = 2,  /* zstd stream corrupt, bad UTF-8 in text sequence/quality */
+    NAFGPU_IO_NOT_FOUND = 3,
+    NAFGPU_IO_IS_A_DIRECTORY = 4,
+    NAFGPU_IO_PERMISSION_DENIED = 5,
+    NAFGPU_IO_OTHER = 6
+} nafgpu_io_kind;
+
+typedef enum {                   /* nom::error::ErrorKind values parser.rs produces */
+    NAFGPU_NOM_NONE = 0,
+    NAFGPU_NOM_VERIFY = 1,       /* bad magic / separator (parser.rs:50-53, 87-91) */
+    NAFGPU_NOM_MAPRES = 2,       /* bad version / sequence type (parser.rs:55-73) */
+    NAFGPU_NOM_TOOLARGE = 3      /* varint overflow (parser.rs:38-45) */
+} nafgpu_nom_code;
+
+typedef struct {
+    int32_t status;              /* nafgpu_status */
+    int32_t io_kind;             /* nafgpu_io_kind */
+    int32_t os_errno;            /* errno for NAFGPU_E_IO raised by the OS, else 0 */
+    int32_t nom_code;            /* nafgpu_nom_code */
+    char message[192];           /* NUL-terminated, human readable */
+} nafgpu_error;
+
+/* ---- DecoderBuilder (decoder/mod.rs:53-148) -------------------------------- */
+typedef struct {
+    uint8_t id;                  /* mod.rs:117  default 1 */
+    uint8_t comment;             /* mod.rs:124  default 1 */
+    uint8_t sequence;            /* mod.rs:131  default 1 */
+    uint8_t quality;             /* mod.rs:138  default 1 */
+    uint8_t mask;                /* mod.rs:145  default 1 */
+    uint8_t spec_mask;           /* 0 = reference behaviour incl. the record-end mask quirk
+                                    (mod.rs:410-415); 1 = lower-case every masked base */
+    uint8_t reserved[2];
+    uint64_t buffer_size;        /* mod.rs:110: accepted for API parity; sizes the host read-back window */
+    int32_t device;              /* HIP device ordinal; -1 = current device */
+    int32_t shard_rank;          /* multi-GPU: this process decodes shard `shard_rank` of `shard_count` */
+    int32_t shard_count;         /* contiguous zstd-block ranges of the sequence section; 1 = everything */
+    int32_t reserved2;
+} nafgpu_opts;
+
+/* DecoderBuilder::new() (mod.rs:67-76) */
+void nafgpu_opts_default(nafgpu_opts *opts);
+/* DecoderBuilder::from_flags (mod.rs:93-101): quality/sequence/mask/comment follow `flags`
+ * (a data.rs:80-97 flag byte); `id` stays on. */
+void nafgpu_opts_from_flags(nafgpu_opts *opts, uint8_t flags);
+
+/* ---- Header (data.rs:198-237) ------------------------------------------------ */
+typedef struct {
+    uint8_t format_version;      /* 1 | 2                          data.rs:46-50 */
+    uint8_t sequence_type;       /* 0 dna, 1 rna, 2 protein, 3 text  data.rs:56-73 */
+    uint8_t flags;               /* bit0 quality, 1 sequence, 2 mask, 3 length, 4 comment, 5 id,
+                                    6 title, 7 extended             data.rs:80-97 */
+    uint8_t name_separator;
+    uint32_t reserved;
+    uint64_t line_length;
+    uint64_t number_of_sequences;
+} nafgpu_header;
+
+/* ---- Record (data.rs:29-40) --------------------------------------------------- */
+typedef struct {
+    const uint8_t *ptr;          /* host memory owned by the decoder; NOT NUL-terminated */
+    uint64_t len;
+    uint8_t present;             /* Option::is_some() */
+    uint8_t reserved[7];
+} nafgpu_field;
+
+typedef struct {
+    nafgpu_field id, comment, sequence, quality;
+    uint64_t length;
+    uint8_t has_length;
+    uint8_t reserved[7];
+} nafgpu_record;
+
+typedef struct nafgpu_decoder nafgpu_decoder;
+
+/* reader callbacks for nafgpu_open_io: R: Read + Seek (decoder/mod.rs:169-172, ioslice.rs) */
+typedef int64_t (*nafgpu_read_fn)(void *ctx, uint8_t *buf, uint64_t cap); /* bytes read, 0 = EOF, <0 = -errno */
+typedef int64_t (*nafgpu_seek_fn)(void *ctx, int64_t offset, int whence); /* new position or <0 = -errno */
+
+/* DecoderBuilder::with_path (mod.rs:159-166) / Decoder::from_path (mod.rs:304-306) */
+int nafgpu_open_path(const char *path, const nafgpu_opts *opts, nafgpu_decoder **out, nafgpu_error *err);
+/* DecoderBuilder::with_bytes (mod.rs:151-156); `bytes` is borrowed until nafgpu_close */
+int nafgpu_open_bytes(const uint8_t *bytes, size_t n, const nafgpu_opts *opts, nafgpu_decoder **out,
+                      nafgpu_error *err);
+/* DecoderBuilder::with_reader (mod.rs:169-256) */
+int nafgpu_open_io(nafgpu_read_fn read, nafgpu_seek_fn seek, void *ctx, const nafgpu_opts *opts,
+                   nafgpu_decoder **out, nafgpu_error *err);
+
+/* Decoder::header (mod.rs:322-325) */
+void nafgpu_get_header(const nafgpu_decoder *dec, nafgpu_header *out);
+/* ExactSizeIterator::len (mod.rs:453-457): number_of_sequences - records yielded */
+uint64_t nafgpu_remaining(const nafgpu_decoder *dec);
+/* Iterator::next (mod.rs:444-451) -> NAFGPU_OK with *rec filled, NAFGPU_END, or an error.
+ * Field pointers stay valid until the next call on this decoder; the shim copies them into
+ * owned strings to honour Record<'static>.  An error does not fuse the iterator (mod.rs:391). */
+int nafgpu_next(nafgpu_decoder *dec, nafgpu_record *rec);
+/* Drop for Decoder / into_inner (mod.rs:343-350) */
+void nafgpu_close(nafgpu_decoder *dec);
+/* last error raised on this decoder (or by the failed open when dec == NULL is not possible:
+ * open failures report through their `err` argument) */
+void nafgpu_last_error(const nafgpu_decoder *dec, nafgpu_error *err);
+
+/* ---- bulk device path (bench / GPU consumers) -------------------------------------
+ * Decodes every selected section on the GPU and leaves the results in HBM.  Replaces a
+ * full drain of the iterator (`for r in decoder`) without the per-record host copies. */
+typedef struct {
+    /* device pointers (HIP device memory owned by the decoder, valid until close / next decode_all) */
+    const uint8_t *d_sequence;   /* masked ASCII bases (DNA/RNA) or raw text; length n_bases */
+    const uint8_t *d_quality;    /* quality bytes; length n_quality */
+    const uint64_t *d_record_end;/* inclusive prefix sum of record lengths; n_records entries */
+    const uint8_t *d_ids;        /* NUL-terminated ids, concatenated */
+    const uint8_t *d_comments;
+    uint64_t n_bases, n_quality, n_records, n_ids_bytes, n_comments_bytes;
+    uint64_t packed_bytes;       /* decoded 4-bit bytes of the sequence section (DNA/RNA), else 0 */
+    uint64_t compressed_bytes;   /* compressed bytes read by the GPU over all decoded sections */
+    uint64_t seq_compressed_bytes;
+    uint64_t n_zstd_blocks;      /* sequence section */
+    uint64_t n_huf_streams;      /* sequence section */
+    uint64_t first_record;       /* shard: index of the first record starting in this shard */
+    uint8_t carry;               /* shard: 1 if the shard starts on an odd nibble */
+    uint8_t reserved[7];
+    /* timing of the last decode_all, milliseconds (HIP events on the decoder's stream) */
+    float ms_total;              /* first kernel launch -> last kernel done */
+    float ms_huf;                /* sum over launches of the Huffman literal kernel */
+    float ms_unpack;             /* 4-bit -> ASCII kernel */
+    float ms_seq_lz;             /* FSE sequence decode + LZ execute kernels */
+    float ms_other;
+    float ms_host_plan;          /* host: frame walk + table build (outside ms_total) */
+    float ms_h2d;                /* host->device upload of archive + task lists (outside ms_total) */
+    uint32_t n_huf_launches;
+} nafgpu_device_result;
+
+int nafgpu_decode_all_device(nafgpu_decoder *dec, nafgpu_device_result *out);
+
+/* ---- L0 replacement on its own: one NAF section payload ------------------------------
+ * Replaces zstd::stream::read::Decoder + include_magicbytes(false) (decoder/mod.rs:221-223)
+ * for a whole section: `src` is the magicless Zstandard frame(s), `dst` receives up to `cap`
+ * decoded bytes.  Host buffers in, host buffer out; the decode runs on the GPU. */
+int nafgpu_zstd_decompress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *produced,
+                           int device, nafgpu_error *err);
+
+/* ---- synthetic archives (format per encoder/mod.rs:334-384) ------
+ * Writes a NAF v1 DNA archive with Length+Sequence (+Mask) sections whose sequence section is
+ * ONE magicless zstd frame of 128 KiB Huffman-literal blocks (what `ennaf` / zstd level 1
+ * produce on DNA).  Deterministic in (seed, n_bases, flags).  Host-only, multi-threaded. */
+typedef struct {
+    uint64_t n_bases;            /* total nucleotides */
+    uint64_t seed;
+    uint8_t with_mask;           /* add a Mask section (runs stay inside records) */
+    uint8_t iupac_permille;      /* 0..255: per-mille of non-ACGT codes (N, R, Y, ...) */
+    uint8_t reserved[6];
+    uint32_t threads;            /* 0 = hardware concurrency */
+    uint32_t reserved2;
+} nafgpu_synth_spec;
+
+typedef struct {
+    uint8_t *bytes;              /* malloc'ed archive; free with nafgpu_synth_free */
+    uint64_t n;
+    uint64_t n_records, n_bases;
+    uint64_t seq_hash;           /* nafgpu_hash64 of the expected ASCII bases (after masking) */
+    uint64_t offsets_hash;       /* nafgpu_hash64 of the u64 record_end table */
+} nafgpu_synth_archive;
+
+int nafgpu_synth_write(const nafgpu_synth_spec *spec, nafgpu_synth_archive *out);
+void nafgpu_synth_free(nafgpu_synth_archive *a);
+
+/* order-sensitive 64-bit checksum used for full-size parity checks ("checksum of checksums"):
+ * sum over 4 KiB chunks c of mix(c, sum_i (byte_i + 1) * (2 i + 1)) -- see hash64.h */
+uint64_t nafgpu_hash64_host(const uint8_t *p, uint64_t n);
+int nafgpu_hash64_device(const nafgpu_decoder *dec, const void *d_ptr, uint64_t n, uint64_t *out);
+
+/* library / device identification, for logs */
+int nafgpu_abi_version(void);
+int nafgpu_device_info(int device, char *name, size_t cap, uint64_t *hbm_bytes, int *compute_units);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAFGPU_H */

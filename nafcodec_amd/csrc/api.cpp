@@ -1,0 +1,505 @@
+// api.cpp -- the C-ABI of include/nafgpu.h on top of ArchiveJob.
+//
+// Host-side mirror of nafcodec's Decoder iterator (nafcodec/src/decoder/mod.rs:285-461):
+// open = header + section table only (cheap, errors as the reference raises them at open);
+// the first next() / decode_all_device() runs the whole GPU decode; next() then slices
+// records out of the decoded sections exactly as next_record (mod.rs:356-399) zips its readers.
+#include <cerrno>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <sys/stat.h>
+
+#include "../../include/nafgpu.h"
+#include "container.h"
+#include "engine.h"
+#include "hash64.h"
+
+using namespace nafgpu;
+
+namespace {
+
+// Pinned read-back window over one decoded section in HBM (sequence / quality): records are
+// consumed front to back, so one sliding window replaces the reference's per-record Strings.
+class HostWindow {
+public:
+    ~HostWindow() {
+        if (buf_) (void)hipHostFree(buf_);
+    }
+    void bind(ArchiveJob *job, const uint8_t *d_base, uint64_t total, uint64_t window) {
+        job_ = job;
+        d_base_ = d_base;
+        total_ = total;
+        window_ = window;
+        lo_ = hi_ = 0;
+    }
+    // pointer to bytes [start, start+len) on the host; nullptr on failure
+    const uint8_t *get(uint64_t start, uint64_t len, Failure *f) {
+        if (len == 0) return reinterpret_cast<const uint8_t *>("");
+        if (start >= lo_ && start + len <= hi_) return buf_ + (start - lo_);
+        uint64_t want = std::max(len, std::min(window_, total_ - start));
+        if (want > cap_) {
+            if (buf_) (void)hipHostFree(buf_);
+            buf_ = nullptr;
+            void *p = nullptr;
+            if (hipHostMalloc(&p, want) != hipSuccess) {
+                *f = Failure::make(NAFGPU_E_DEVICE, "cannot allocate the pinned read-back window");
+                cap_ = 0;
+                return nullptr;
+            }
+            buf_ = static_cast<uint8_t *>(p);
+            cap_ = want;
+        }
+        *f = job_->copy_to_host(buf_, d_base_ + start, want);
+        if (!f->ok()) return nullptr;
+        lo_ = start;
+        hi_ = start + want;
+        return buf_;
+    }
+
+private:
+    ArchiveJob *job_ = nullptr;
+    const uint8_t *d_base_ = nullptr;
+    uint64_t total_ = 0, window_ = 0, lo_ = 0, hi_ = 0, cap_ = 0;
+    uint8_t *buf_ = nullptr;
+};
+
+bool utf8_valid(const uint8_t *p, uint64_t n) {
+    uint64_t i = 0;
+    while (i < n) {
+        const uint8_t c = p[i];
+        if (c < 0x80) {
+            i++;
+            continue;
+        }
+        int extra;
+        uint32_t cp, min;
+        if ((c & 0xE0) == 0xC0) {
+            extra = 1; cp = c & 0x1F; min = 0x80;
+        } else if ((c & 0xF0) == 0xE0) {
+            extra = 2; cp = c & 0x0F; min = 0x800;
+        } else if ((c & 0xF8) == 0xF0) {
+            extra = 3; cp = c & 0x07; min = 0x10000;
+        } else {
+            return false;
+        }
+        if (i + uint64_t(extra) >= n) return false;
+        for (int k = 1; k <= extra; k++) {
+            if ((p[i + uint64_t(k)] & 0xC0) != 0x80) return false;
+            cp = (cp << 6) | (p[i + uint64_t(k)] & 0x3F);
+        }
+        if (cp < min || cp > 0x10FFFF || (cp >= 0xD800 && cp <= 0xDFFF)) return false;
+        i += uint64_t(extra) + 1;
+    }
+    return true;
+}
+
+}  // namespace
+
+struct nafgpu_decoder {
+    nafgpu_opts opts{};
+    nafgpu_header header{};
+    SectionInfo sec[kNumSections];
+    std::vector<uint8_t> owned;          // archive bytes when we read them ourselves
+    const uint8_t *bytes = nullptr;
+    size_t n_bytes = 0;
+    ArchiveJob job;
+    bool device_ready = false, decoded = false;
+    Failure fatal;                       // device failure: every later call reports it
+    Failure last;
+    // iterator state (mod.rs:285-296)
+    uint64_t n = 0;                      // records yielded
+    uint64_t ids_pos = 0, com_pos = 0;   // CStringReader cursors
+    uint64_t rec_idx = 0;                // LengthReader cursor
+    std::vector<uint8_t> ids, comments;
+    std::vector<uint64_t> rec_ends;
+    HostWindow seq_win, qual_win;
+    uint64_t mask_covered = 0;           // bases the mask section covers (see next())
+    bool use[kNumSections] = {false, false, false, false, false, false};
+};
+
+namespace {
+
+Failure ensure_decoded(nafgpu_decoder *d) {
+    if (!d->fatal.ok()) return d->fatal;
+    if (d->decoded) return Failure();
+    if (!d->device_ready) {
+        Failure f = d->job.init(d->opts.device);
+        if (!f.ok()) return d->fatal = f;
+        ArchiveOptions ao;
+        const bool want[kNumSections] = {d->opts.id != 0, d->opts.comment != 0, true, d->opts.mask != 0,
+                                         d->opts.sequence != 0, d->opts.quality != 0};
+        for (int s = 0; s < kNumSections; s++) ao.want[s] = want[s];
+        ao.spec_mask = d->opts.spec_mask != 0;
+        f = d->job.upload(d->bytes, d->n_bytes, d->header, d->sec, ao);
+        if (!f.ok()) return d->fatal = f;
+        d->device_ready = true;
+    }
+    Failure f = d->job.decode();
+    if (!f.ok()) return d->fatal = f;
+    // small sections come back to the host whole; sequence / quality through sliding windows
+    auto fetch = [&](int s, std::vector<uint8_t> *dst) -> Failure {
+        if (!d->job.job(s).ready() || !d->job.section_failure(s).ok()) return Failure();
+        dst->resize(static_cast<size_t>(d->job.section_size(s)));
+        return d->job.copy_to_host(dst->data(), d->job.d_section(s), dst->size());
+    };
+    if (!(f = fetch(kIds, &d->ids)).ok()) return d->fatal = f;
+    if (!(f = fetch(kComments, &d->comments)).ok()) return d->fatal = f;
+    if (d->job.job(kLengths).ready() && d->job.section_failure(kLengths).ok()) {
+        d->rec_ends.resize(static_cast<size_t>(d->job.n_records()));
+        f = d->job.copy_to_host(d->rec_ends.data(), d->job.d_rec_ends(), d->rec_ends.size() * sizeof(uint64_t));
+        if (!f.ok()) return d->fatal = f;
+    }
+    const uint64_t window = std::max<uint64_t>(d->opts.buffer_size, uint64_t(64) << 20);
+    d->seq_win.bind(&d->job, d->job.d_sequence(), d->job.n_sequence_bytes(), window);
+    d->qual_win.bind(&d->job, d->job.d_section(kQuality), d->job.section_size(kQuality), window);
+    // MaskReader yields units until their sum reaches the nucleotide count (reader.rs:200-202);
+    // a record ending beyond what the units cover raises "failed to get mask unit" (mod.rs:430-435)
+    const uint64_t total = d->sec[kSequence].present ? d->sec[kSequence].original_size : 0;
+    d->mask_covered = d->job.mask_sum() >= total ? UINT64_MAX : d->job.mask_sum();
+    d->decoded = true;
+    return Failure();
+}
+
+int fail(nafgpu_decoder *d, const Failure &f) {
+    d->last = f;
+    return f.status;
+}
+
+// CStringReader::next (reader.rs:22-30) over a fully decoded section
+int cstring_next(const std::vector<uint8_t> &buf, uint64_t *pos, nafgpu_field *out, Failure *f) {
+    if (*pos >= buf.size()) return 0;   // read_until -> Ok(0) -> None
+    const uint8_t *start = buf.data() + *pos;
+    const void *nul = std::memchr(start, 0, buf.size() - static_cast<size_t>(*pos));
+    if (!nul) {
+        *f = Failure::make(NAFGPU_E_PANIC, "string section does not end with NUL (reference: expect() panic)");
+        return -1;
+    }
+    out->ptr = start;
+    out->len = static_cast<uint64_t>(static_cast<const uint8_t *>(nul) - start);
+    out->present = 1;
+    *pos += out->len + 1;
+    if (!utf8_valid(out->ptr, out->len)) {
+        *f = Failure::make(NAFGPU_E_PANIC, "invalid UTF-8 in id/comment (reference: expect(\"TODO\") panic, mod.rs:362)");
+        return -1;
+    }
+    return 1;
+}
+
+int open_common(std::unique_ptr<nafgpu_decoder> d, const nafgpu_opts *opts, nafgpu_decoder **out, nafgpu_error *err) {
+    if (opts)
+        d->opts = *opts;
+    else
+        nafgpu_opts_default(&d->opts);
+    if (d->opts.shard_count <= 0) d->opts.shard_count = 1;
+    Failure f = parse_archive(d->bytes, d->n_bytes, &d->header, d->sec);
+    if (!f.ok()) {
+        f.to_c(err);
+        return f.status;
+    }
+    const bool want[kNumSections] = {d->opts.id != 0, d->opts.comment != 0, true, d->opts.mask != 0,
+                                     d->opts.sequence != 0, d->opts.quality != 0};
+    for (int s = 0; s < kNumSections; s++) d->use[s] = d->sec[s].present && want[s];
+    *out = d.release();
+    if (err) Failure().to_c(err);
+    return NAFGPU_OK;
+}
+
+Failure errno_failure(const char *what, int e) {
+    int kind = NAFGPU_IO_OTHER;
+    if (e == ENOENT) kind = NAFGPU_IO_NOT_FOUND;
+    else if (e == EISDIR) kind = NAFGPU_IO_IS_A_DIRECTORY;
+    else if (e == EACCES || e == EPERM) kind = NAFGPU_IO_PERMISSION_DENIED;
+    return Failure::io(kind, std::string(what) + ": " + std::strerror(e), e);
+}
+
+}  // namespace
+
+extern "C" {
+
+void nafgpu_opts_default(nafgpu_opts *o) {
+    std::memset(o, 0, sizeof *o);
+    o->id = o->comment = o->sequence = o->quality = o->mask = 1;   // mod.rs:67-76
+    o->buffer_size = 4096;
+    o->device = -1;
+    o->shard_rank = 0;
+    o->shard_count = 1;
+}
+
+void nafgpu_opts_from_flags(nafgpu_opts *o, uint8_t flags) {
+    nafgpu_opts_default(o);                                        // mod.rs:93-101: `id` is left on
+    o->quality = (flags & 0x01) != 0;
+    o->sequence = (flags & 0x02) != 0;
+    o->mask = (flags & 0x04) != 0;
+    o->comment = (flags & 0x10) != 0;
+}
+
+int nafgpu_open_bytes(const uint8_t *bytes, size_t n, const nafgpu_opts *opts, nafgpu_decoder **out, nafgpu_error *err) {
+    if (!out || (!bytes && n)) return NAFGPU_E_INVALID_ARG;
+    std::unique_ptr<nafgpu_decoder> d(new (std::nothrow) nafgpu_decoder);
+    if (!d) return NAFGPU_E_DEVICE;
+    d->bytes = bytes;
+    d->n_bytes = n;
+    return open_common(std::move(d), opts, out, err);
+}
+
+int nafgpu_open_path(const char *path, const nafgpu_opts *opts, nafgpu_decoder **out, nafgpu_error *err) {
+    if (!out || !path) return NAFGPU_E_INVALID_ARG;
+    std::unique_ptr<nafgpu_decoder> d(new (std::nothrow) nafgpu_decoder);
+    if (!d) return NAFGPU_E_DEVICE;
+    FILE *fp = std::fopen(path, "rb");                             // File::open, mod.rs:163
+    if (!fp) {
+        Failure f = errno_failure(path, errno);
+        f.to_c(err);
+        return f.status;
+    }
+    struct stat stt;
+    if (fstat(fileno(fp), &stt) == 0 && S_ISDIR(stt.st_mode)) {
+        std::fclose(fp);
+        Failure f = errno_failure(path, EISDIR);
+        f.to_c(err);
+        return f.status;
+    }
+    // one bulk read replaces the IoSlice lock+seek+read refills (ioslice.rs:28-41)
+    std::vector<uint8_t> &buf = d->owned;
+    if (stt.st_size > 0) buf.reserve(static_cast<size_t>(stt.st_size));
+    uint8_t chunk[1 << 16];
+    for (;;) {
+        size_t got = std::fread(chunk, 1, sizeof chunk, fp);
+        if (got) buf.insert(buf.end(), chunk, chunk + got);
+        if (got < sizeof chunk) {
+            if (std::ferror(fp)) {
+                int e = errno;
+                std::fclose(fp);
+                Failure f = errno_failure(path, e);
+                f.to_c(err);
+                return f.status;
+            }
+            break;
+        }
+    }
+    std::fclose(fp);
+    d->bytes = buf.data();
+    d->n_bytes = buf.size();
+    return open_common(std::move(d), opts, out, err);
+}
+
+int nafgpu_open_io(nafgpu_read_fn read, nafgpu_seek_fn seek, void *ctx, const nafgpu_opts *opts, nafgpu_decoder **out,
+                   nafgpu_error *err) {
+    if (!out || !read) return NAFGPU_E_INVALID_ARG;
+    std::unique_ptr<nafgpu_decoder> d(new (std::nothrow) nafgpu_decoder);
+    if (!d) return NAFGPU_E_DEVICE;
+    (void)seek;   // the whole reader is drained front to back: no seeks are needed any more
+    std::vector<uint8_t> &buf = d->owned;
+    std::vector<uint8_t> chunk(1 << 20);
+    for (;;) {
+        int64_t got = read(ctx, chunk.data(), chunk.size());
+        if (got < 0) {
+            Failure f = errno_failure("read", static_cast<int>(-got));
+            f.to_c(err);
+            return f.status;
+        }
+        if (got == 0) break;
+        buf.insert(buf.end(), chunk.begin(), chunk.begin() + got);
+    }
+    d->bytes = buf.data();
+    d->n_bytes = buf.size();
+    return open_common(std::move(d), opts, out, err);
+}
+
+void nafgpu_get_header(const nafgpu_decoder *d, nafgpu_header *out) { *out = d->header; }
+
+uint64_t nafgpu_remaining(const nafgpu_decoder *d) { return d->header.number_of_sequences - d->n; }
+
+void nafgpu_close(nafgpu_decoder *d) { delete d; }
+
+void nafgpu_last_error(const nafgpu_decoder *d, nafgpu_error *err) {
+    if (d) d->last.to_c(err);
+}
+
+int nafgpu_next(nafgpu_decoder *d, nafgpu_record *rec) {
+    if (!d || !rec) return NAFGPU_E_INVALID_ARG;
+    if (d->n >= d->header.number_of_sequences) return NAFGPU_END;          // mod.rs:447-449
+    if (d->opts.shard_count > 1)
+        return fail(d, Failure::make(NAFGPU_E_INVALID_ARG, "record iteration needs the whole archive (shard_count == 1)"));
+    Failure f = ensure_decoded(d);
+    if (!f.ok()) return fail(d, f);
+    std::memset(rec, 0, sizeof *rec);
+    // state consumed before an error is not rolled back, as in the reference (mod.rs:391)
+    if (d->use[kIds]) {
+        if (!d->job.section_failure(kIds).ok()) return fail(d, d->job.section_failure(kIds));
+        if (cstring_next(d->ids, &d->ids_pos, &rec->id, &f) < 0) return fail(d, f);
+    }
+    if (d->use[kComments]) {
+        if (!d->job.section_failure(kComments).ok()) return fail(d, d->job.section_failure(kComments));
+        if (cstring_next(d->comments, &d->com_pos, &rec->comment, &f) < 0) return fail(d, f);
+    }
+    uint64_t start = 0, end = 0;
+    if (d->use[kLengths]) {
+        if (!d->job.section_failure(kLengths).ok()) return fail(d, d->job.section_failure(kLengths));
+        if (d->rec_idx < d->rec_ends.size()) {                             // else LengthReader -> None
+            start = d->rec_idx ? d->rec_ends[d->rec_idx - 1] : 0;
+            end = d->rec_ends[d->rec_idx];
+            d->rec_idx++;
+            rec->has_length = 1;
+            rec->length = end - start;
+        }
+    }
+    if (rec->has_length) {                                                 // mod.rs:373
+        const uint64_t l = rec->length;
+        if (d->use[kSequence]) {
+            if (!d->job.section_failure(kSequence).ok()) return fail(d, d->job.section_failure(kSequence));
+            if (end > d->job.n_sequence_bytes())
+                return fail(d, Failure::io(NAFGPU_IO_UNEXPECTED_EOF, "sequence section ends before the record does"));
+            const uint8_t *p = d->seq_win.get(start, l, &f);
+            if (!p) return fail(d, f);
+            if (d->header.sequence_type > 1 && !utf8_valid(p, l))          // reader.rs:108-109
+                return fail(d, Failure::io(NAFGPU_IO_INVALID_DATA, "invalid UTF-8 in sequence"));
+            rec->sequence.ptr = p;
+            rec->sequence.len = l;
+            rec->sequence.present = 1;
+        }
+        if (d->use[kQuality]) {
+            if (!d->job.section_failure(kQuality).ok()) return fail(d, d->job.section_failure(kQuality));
+            if (end > d->job.section_size(kQuality))
+                return fail(d, Failure::io(NAFGPU_IO_UNEXPECTED_EOF, "quality section ends before the record does"));
+            const uint8_t *p = d->qual_win.get(start, l, &f);
+            if (!p) return fail(d, f);
+            if (!utf8_valid(p, l)) return fail(d, Failure::io(NAFGPU_IO_INVALID_DATA, "invalid UTF-8 in quality"));
+            rec->quality.ptr = p;
+            rec->quality.len = l;
+            rec->quality.present = 1;
+        }
+        if (rec->sequence.present && d->use[kMask]) {                      // mod.rs:386-388
+            if (!d->job.section_failure(kMask).ok()) return fail(d, d->job.section_failure(kMask));
+            if (end > d->mask_covered)
+                return fail(d, Failure::io(NAFGPU_IO_UNEXPECTED_EOF, "failed to get mask unit"));
+        }
+    }
+    d->n += 1;
+    return NAFGPU_OK;
+}
+
+int nafgpu_decode_all_device(nafgpu_decoder *d, nafgpu_device_result *out) {
+    if (!d || !out) return NAFGPU_E_INVALID_ARG;
+    d->decoded = false;                                                    // every call re-runs the kernels
+    Failure f = ensure_decoded(d);
+    if (!f.ok()) return fail(d, f);
+    for (int s = 0; s < kNumSections; s++)
+        if (d->use[s] && !d->job.section_failure(s).ok()) return fail(d, d->job.section_failure(s));
+    std::memset(out, 0, sizeof *out);
+    const ArchiveJob &j = d->job;
+    out->d_sequence = d->use[kSequence] ? j.d_sequence() : nullptr;
+    const bool nuc = d->header.sequence_type <= 1;
+    out->n_bases = d->use[kSequence] ? (nuc ? d->sec[kSequence].original_size : j.n_sequence_bytes()) : 0;
+    out->d_quality = j.d_section(kQuality);
+    out->n_quality = j.section_size(kQuality);
+    out->d_record_end = d->use[kLengths] ? j.d_rec_ends() : nullptr;
+    out->n_records = j.n_records();
+    out->d_ids = j.d_section(kIds);
+    out->n_ids_bytes = j.section_size(kIds);
+    out->d_comments = j.d_section(kComments);
+    out->n_comments_bytes = j.section_size(kComments);
+    out->packed_bytes = j.packed_bytes();
+    out->compressed_bytes = j.compressed_bytes();
+    out->seq_compressed_bytes = d->use[kSequence] ? d->sec[kSequence].compressed_size : 0;
+    out->n_zstd_blocks = j.job(kSequence).n_blocks();
+    out->n_huf_streams = j.job(kSequence).n_streams();
+    const StageTimes &t = j.times();
+    out->ms_total = t.total;
+    out->ms_huf = t.huf;
+    out->ms_unpack = t.unpack;
+    out->ms_seq_lz = t.seq_lz;
+    out->ms_other = t.other;
+    out->n_huf_launches = t.huf_launches;
+    out->ms_host_plan = j.host_plan_ms();
+    out->ms_h2d = j.h2d_ms();
+    return NAFGPU_OK;
+}
+
+int nafgpu_hash64_device(const nafgpu_decoder *d, const void *d_ptr, uint64_t n, uint64_t *out) {
+    if (!d || !out) return NAFGPU_E_INVALID_ARG;
+    Failure f = const_cast<nafgpu_decoder *>(d)->job.hash_device(d_ptr, n, out);
+    return f.status;
+}
+
+uint64_t nafgpu_hash64_host(const uint8_t *p, uint64_t n) { return hash64_host(p, n); }
+
+int nafgpu_zstd_decompress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *produced, int device,
+                           nafgpu_error *err) {
+    // one section = one job on a private stream (zstd::stream::read::Decoder, mod.rs:221-223)
+    Failure f;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        f = Failure::make(NAFGPU_E_DEVICE, "no HIP device available: libnafgpu decodes on the GPU only");
+        f.to_c(err);
+        return f.status;
+    }
+    if (device >= 0) (void)hipSetDevice(device);
+    hipStream_t stream = nullptr;
+    if (hipStreamCreate(&stream) != hipSuccess) {
+        f = Failure::make(NAFGPU_E_DEVICE, "hipStreamCreate failed");
+        f.to_c(err);
+        return f.status;
+    }
+    {
+        DevBuf d_src;
+        SectionJob job;
+        // the decoded size is not part of a NAF-less call: take it from a host-side walk when the
+        // frame is literal-only, else trust `cap` as the exact size
+        ZPlan probe;
+        bool trunc = false;
+        std::string perr = build_zplan(src, n, &probe, &trunc);
+        if (!perr.empty()) {
+            f = Failure::io(trunc ? NAFGPU_IO_UNEXPECTED_EOF : NAFGPU_IO_INVALID_DATA, "zstd: " + perr);
+        } else {
+            const uint64_t expect = probe.seq_blocks.empty() ? probe.known_out : cap;
+            if (expect > cap) {
+                f = Failure::io(NAFGPU_IO_INVALID_DATA, "zstd: destination buffer too small");
+            } else if (!d_src.alloc(kSrcFrontPad + n + kSrcBackPad)) {
+                f = Failure::make(NAFGPU_E_DEVICE, "out of device memory");
+            } else {
+                (void)hipMemsetAsync(d_src.bytes(), 0, kSrcFrontPad, stream);
+                (void)hipMemsetAsync(d_src.bytes() + kSrcFrontPad + n, 0, kSrcBackPad, stream);
+                (void)hipMemcpyAsync(d_src.bytes() + kSrcFrontPad, src, n, hipMemcpyHostToDevice, stream);
+                f = job.prepare(src, n, expect, d_src.bytes() + kSrcFrontPad, stream);
+                if (f.ok()) {
+                    job.run(stream, nullptr);
+                    f = job.check(stream);
+                }
+                if (f.ok() && expect) {
+                    if (hipMemcpyAsync(dst, job.out(), expect, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                        hipStreamSynchronize(stream) != hipSuccess)
+                        f = Failure::make(NAFGPU_E_DEVICE, "device-to-host copy failed");
+                }
+                if (f.ok() && produced) *produced = static_cast<size_t>(expect);
+            }
+        }
+    }
+    (void)hipStreamDestroy(stream);
+    f.to_c(err);
+    return f.status;
+}
+
+int nafgpu_abi_version(void) { return NAFGPU_ABI_VERSION; }
+
+int nafgpu_device_info(int device, char *name, size_t cap, uint64_t *hbm_bytes, int *compute_units) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return NAFGPU_E_DEVICE;
+    if (device < 0) device = 0;
+    if (device >= count) return NAFGPU_E_INVALID_ARG;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return NAFGPU_E_DEVICE;
+    if (name && cap) {
+        std::snprintf(name, cap, "%s (%s)", p.name, p.gcnArchName);
+    }
+    if (hbm_bytes) *hbm_bytes = p.totalGlobalMem;
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    return NAFGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,362 @@
+// engine.cpp -- see engine.h
+#include "engine.h"
+
+#include <chrono>
+#include <cstring>
+
+namespace nafgpu {
+
+namespace {
+inline bool hip_ok(hipError_t e) { return e == hipSuccess; }
+
+Failure dev_fail(const char *what, hipError_t e) {
+    return Failure::make(NAFGPU_E_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+const char *status_text(uint32_t code) {
+    switch (code) {
+    case kStHufBadEnd: return "zstd: Huffman literal stream is corrupt";
+    case kStSeqBadEnd: return "zstd: sequence bitstream is corrupt";
+    case kStSeqLiterals: return "zstd: sequences use more literals than the block holds";
+    case kStBadOffset: return "zstd: match offset reaches before the frame start";
+    case kStSizeMismatch: return "zstd: decoded size differs from the size recorded in the archive";
+    case kStRunsOverflow: return "run table overflow";
+    default: return "zstd: device decoder reported an error";
+    }
+}
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+// ------------------------------------------------------------------ DevBuf
+bool DevBuf::alloc(size_t bytes) {
+    if (ptr_ && bytes <= size_) return true;
+    release();
+    void *p = nullptr;
+    if (!hip_ok(hipMalloc(&p, bytes ? bytes : 16))) return false;
+    ptr_ = p;
+    size_ = bytes ? bytes : 16;
+    return true;
+}
+
+bool DevBuf::upload(const void *host, size_t bytes, hipStream_t stream) {
+    if (!alloc(bytes)) return false;
+    if (bytes == 0) return true;
+    return hip_ok(hipMemcpyAsync(ptr_, host, bytes, hipMemcpyHostToDevice, stream));
+}
+
+void DevBuf::release() {
+    if (ptr_) (void)hipFree(ptr_);
+    ptr_ = nullptr;
+    size_ = 0;
+}
+
+// ------------------------------------------------------------------ StageTimer
+StageTimer::~StageTimer() {
+    for (hipEvent_t e : pool_) (void)hipEventDestroy(e);
+    if (t0_) (void)hipEventDestroy(t0_);
+    if (t1_) (void)hipEventDestroy(t1_);
+}
+
+hipEvent_t StageTimer::get() {
+    if (used_ == pool_.size()) {
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        pool_.push_back(e);
+    }
+    return pool_[used_++];
+}
+
+void StageTimer::reset() {
+    spans_.clear();
+    used_ = 0;
+    open_ = false;
+}
+
+void StageTimer::begin(hipStream_t s, Cat c) {
+    Span sp{get(), get(), c};
+    (void)hipEventRecord(sp.a, s);
+    spans_.push_back(sp);
+    open_ = true;
+}
+
+void StageTimer::end(hipStream_t s) {
+    if (!open_) return;
+    (void)hipEventRecord(spans_.back().b, s);
+    open_ = false;
+}
+
+void StageTimer::mark_total_begin(hipStream_t s) {
+    if (!t0_) (void)hipEventCreate(&t0_);
+    if (!t1_) (void)hipEventCreate(&t1_);
+    (void)hipEventRecord(t0_, s);
+}
+
+void StageTimer::mark_total_end(hipStream_t s) { (void)hipEventRecord(t1_, s); }
+
+StageTimes StageTimer::collect() {
+    StageTimes t;
+    for (const Span &sp : spans_) {
+        float ms = 0;
+        if (!hip_ok(hipEventElapsedTime(&ms, sp.a, sp.b))) continue;
+        switch (sp.cat) {
+        case kHuf: t.huf += ms; t.huf_launches++; break;
+        case kSeqLz: t.seq_lz += ms; break;
+        case kUnpack: t.unpack += ms; break;
+        default: t.other += ms; break;
+        }
+    }
+    if (t0_ && t1_) (void)hipEventElapsedTime(&t.total, t0_, t1_);
+    return t;
+}
+
+// ------------------------------------------------------------------ SectionJob
+Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expect_size, const uint8_t *d_payload,
+                            hipStream_t stream) {
+    ready_ = false;
+    plan_ = ZPlan();
+    const double t0 = now_ms();
+    bool truncated = false;
+    std::string err = build_zplan(host_payload, n, &plan_, &truncated);
+    plan_ms_ = static_cast<float>(now_ms() - t0);
+    if (!err.empty())
+        return Failure::io(truncated ? NAFGPU_IO_UNEXPECTED_EOF : NAFGPU_IO_INVALID_DATA, "zstd: " + err);
+    expect_ = expect_size;
+    d_src_ = d_payload;
+    n_blocks_ = plan_.blk_size.size();
+    n_streams_ = plan_.streams.size();
+    n_tasks_ = plan_.tasks.size();
+    n_copies_ = plan_.copies.size();
+    n_seq_blocks_ = plan_.seq_blocks.size();
+    if (plan_.seq_blocks.empty() && plan_.known_out != expect_size)
+        return Failure::io(NAFGPU_IO_INVALID_DATA, "zstd: decoded size differs from the size recorded in the archive");
+    max_tbl_entries_ = 0;
+    for (const HufTask &t : plan_.tasks) {
+        uint32_t e = 0;
+        for (uint32_t k = 0; k < t.n_copies; k++) {
+            const HufTblCopy &c = plan_.tbl_copies[t.first_copy + k];
+            e = std::max(e, c.lds_off + c.n_entries);
+        }
+        max_tbl_entries_ = std::max(max_tbl_entries_, e);
+    }
+    bool ok = d_out_.alloc(static_cast<size_t>(expect_size) + 64) && d_status_.alloc(64) &&
+              d_blk_size_.upload(plan_.blk_size.data(), n_blocks_ * sizeof(uint32_t), stream) &&
+              d_blk_base_.alloc((n_blocks_ + 1) * sizeof(uint64_t)) && d_scan_tmp_.alloc(scan_tmp_bytes(n_blocks_)) &&
+              d_streams_.upload(plan_.streams.data(), n_streams_ * sizeof(HufStream), stream) &&
+              d_tasks_.upload(plan_.tasks.data(), n_tasks_ * sizeof(HufTask), stream) &&
+              d_tbl_copies_.upload(plan_.tbl_copies.data(), plan_.tbl_copies.size() * sizeof(HufTblCopy), stream) &&
+              d_pool_.upload(plan_.huf_pool.data(), plan_.huf_pool.size() * sizeof(uint16_t), stream) &&
+              d_copies_.upload(plan_.copies.data(), n_copies_ * sizeof(CopyTask), stream) &&
+              d_seq_blocks_.upload(plan_.seq_blocks.data(), n_seq_blocks_ * sizeof(SeqBlock), stream) &&
+              d_cells_.upload(plan_.fse_pool.data(), plan_.fse_pool.size() * sizeof(SeqCell), stream) &&
+              d_lit_.alloc(static_cast<size_t>(plan_.lit_bytes) + 64) &&
+              d_seqs_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(Seq) + 16);
+    if (!ok) return Failure::make(NAFGPU_E_DEVICE, "out of device memory while preparing a section");
+    // the host vectors were consumed by asynchronous copies: keep them until the stream drains
+    if (!hip_ok(hipStreamSynchronize(stream))) return Failure::make(NAFGPU_E_DEVICE, "upload of task lists failed");
+    // only the counts are needed from here on
+    std::vector<HufStream>().swap(plan_.streams);
+    std::vector<uint16_t>().swap(plan_.huf_pool);
+    std::vector<SeqCell>().swap(plan_.fse_pool);
+    std::vector<CopyTask>().swap(plan_.copies);
+    ready_ = true;
+    return Failure();
+}
+
+void SectionJob::run(hipStream_t stream, StageTimer *timer) {
+    if (!ready_) return;
+    uint32_t *status = d_status_.as<uint32_t>();
+    (void)hipMemsetAsync(status, 0, 64, stream);
+    if (n_seq_blocks_) {
+        if (timer) timer->begin(stream, StageTimer::kSeqLz);
+        // blk_size of blocks with sequences is rewritten in full by k_seq_decode: re-runs are idempotent
+        launch_seq_decode(stream, d_src_, d_seq_blocks_.as<SeqBlock>(), static_cast<uint32_t>(n_seq_blocks_),
+                          d_cells_.as<SeqCell>(), d_seqs_.as<Seq>(), d_blk_size_.as<uint32_t>(), status);
+        if (timer) timer->end(stream);
+    }
+    if (timer) timer->begin(stream, StageTimer::kOther);
+    launch_scan_blocks(stream, d_blk_size_.as<uint32_t>(), n_blocks_, d_blk_base_.as<uint64_t>(), d_scan_tmp_.bytes(),
+                       expect_, status);
+    launch_copy_fill(stream, d_src_, d_copies_.as<CopyTask>(), static_cast<uint32_t>(n_copies_),
+                     d_blk_base_.as<uint64_t>(), d_out_.bytes(), d_lit_.bytes(), status);
+    if (timer) timer->end(stream);
+    if (n_tasks_) {
+        if (timer) timer->begin(stream, StageTimer::kHuf);
+        launch_huf_decode(stream, d_src_, d_tasks_.as<HufTask>(), static_cast<uint32_t>(n_tasks_),
+                          d_tbl_copies_.as<HufTblCopy>(), d_streams_.as<HufStream>(), d_pool_.as<uint16_t>(),
+                          d_blk_base_.as<uint64_t>(), d_out_.bytes(), d_lit_.bytes(), max_tbl_entries_, status);
+        if (timer) timer->end(stream);
+    }
+    if (n_seq_blocks_) {
+        if (timer) timer->begin(stream, StageTimer::kSeqLz);
+        launch_lz_execute(stream, d_seq_blocks_.as<SeqBlock>(), static_cast<uint32_t>(n_seq_blocks_), d_seqs_.as<Seq>(),
+                          d_lit_.bytes(), d_blk_base_.as<uint64_t>(), d_out_.bytes(), status);
+        if (timer) timer->end(stream);
+    }
+}
+
+Failure SectionJob::check(hipStream_t stream) {
+    if (!ready_) return Failure();
+    uint32_t st[2] = {0, 0};
+    if (!hip_ok(hipMemcpyAsync(st, d_status_.bytes(), sizeof st, hipMemcpyDeviceToHost, stream)) ||
+        !hip_ok(hipStreamSynchronize(stream)))
+        return Failure::make(NAFGPU_E_DEVICE, "device status read-back failed");
+    if (st[0] != 0) return Failure::io(NAFGPU_IO_INVALID_DATA, status_text(st[0]));
+    return Failure();
+}
+
+// ------------------------------------------------------------------ ArchiveJob
+ArchiveJob::~ArchiveJob() {
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+Failure ArchiveJob::init(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (!hip_ok(e) || count <= 0)
+        return Failure::make(NAFGPU_E_DEVICE, "no HIP device available: libnafgpu decodes on the GPU only");
+    if (device < 0) {
+        if (!hip_ok(hipGetDevice(&device))) device = 0;
+    }
+    if (device >= count) return Failure::make(NAFGPU_E_INVALID_ARG, "device ordinal out of range");
+    e = hipSetDevice(device);
+    if (!hip_ok(e)) return dev_fail("hipSetDevice", e);
+    device_ = device;
+    if (!stream_) {
+        e = hipStreamCreate(&stream_);
+        if (!hip_ok(e)) return dev_fail("hipStreamCreate", e);
+    }
+    return Failure();
+}
+
+Failure ArchiveJob::upload(const uint8_t *bytes, size_t n, const nafgpu_header &h, const SectionInfo sec[kNumSections],
+                           const ArchiveOptions &opt) {
+    (void)hipSetDevice(device_);
+    h_ = h;
+    opt_ = opt;
+    is_nuc_ = h.sequence_type <= 1;
+    // ---- archive bytes -> HBM, once
+    const double t0 = now_ms();
+    if (!d_archive_.alloc(kSrcFrontPad + n + kSrcBackPad)) return Failure::make(NAFGPU_E_DEVICE, "out of device memory");
+    (void)hipMemsetAsync(d_archive_.bytes(), 0, kSrcFrontPad, stream_);
+    (void)hipMemsetAsync(d_archive_.bytes() + kSrcFrontPad + n, 0, kSrcBackPad, stream_);
+    if (n && !hip_ok(hipMemcpyAsync(d_archive_.bytes() + kSrcFrontPad, bytes, n, hipMemcpyHostToDevice, stream_)))
+        return Failure::make(NAFGPU_E_DEVICE, "archive upload failed");
+    if (!hip_ok(hipStreamSynchronize(stream_))) return Failure::make(NAFGPU_E_DEVICE, "archive upload failed");
+    h2d_ms_ = static_cast<float>(now_ms() - t0);
+    // ---- per-section host plan + task upload
+    plan_ms_ = 0;
+    compressed_ = 0;
+    for (int s = 0; s < kNumSections; s++) {
+        fail_[s] = Failure();
+        if (!sec[s].present || !opt.want[s]) continue;
+        if (sec[s].offset > n || sec[s].compressed_size > n - sec[s].offset) {
+            fail_[s] = Failure::io(NAFGPU_IO_UNEXPECTED_EOF, "archive ends inside a section");
+            continue;
+        }
+        uint64_t expect = sec[s].original_size;
+        if (s == kSequence && is_nuc_) expect = (expect + 1) / 2;     // nucleotides -> packed bytes
+        fail_[s] = job_[s].prepare(bytes + sec[s].offset, static_cast<size_t>(sec[s].compressed_size), expect,
+                                   d_archive_.bytes() + kSrcFrontPad + sec[s].offset, stream_);
+        plan_ms_ += job_[s].host_plan_ms();
+        if (fail_[s].status == NAFGPU_E_DEVICE) return fail_[s];
+        if (fail_[s].ok()) compressed_ += sec[s].compressed_size;
+    }
+    // ---- derived tables
+    bool ok = d_totals_.alloc(4 * sizeof(ScanTotals)) && d_status_.alloc(64) && d_hash_.alloc(16);
+    if (job_[kLengths].ready()) {
+        rec_cap_ = job_[kLengths].size() / 4;
+        ok = ok && d_rec_ends_.alloc((rec_cap_ + 1) * sizeof(uint64_t));
+    }
+    mask_total_bases_ = sec[kSequence].present ? sec[kSequence].original_size : 0;   // mod.rs:236,241,250
+    if (job_[kMask].ready()) {
+        mask_cap_ = job_[kMask].size();
+        ok = ok && d_mask_ends_.alloc((mask_cap_ + 1) * sizeof(uint64_t));
+    }
+    ok = ok && d_scan_tmp_.alloc(scan_tmp_bytes(std::max(rec_cap_, mask_cap_)));
+    if (job_[kSequence].ready() && is_nuc_) ok = ok && d_ascii_.alloc(static_cast<size_t>(2 * job_[kSequence].size()) + 64);
+    if (!ok) return Failure::make(NAFGPU_E_DEVICE, "out of device memory");
+    return Failure();
+}
+
+Failure ArchiveJob::decode() {
+    (void)hipSetDevice(device_);
+    timer_.reset();
+    uint32_t *status = d_status_.as<uint32_t>();
+    ScanTotals *totals = d_totals_.as<ScanTotals>();
+    (void)hipMemsetAsync(status, 0, 64, stream_);
+    (void)hipMemsetAsync(totals, 0, 4 * sizeof(ScanTotals), stream_);
+    timer_.mark_total_begin(stream_);
+    for (int s = 0; s < kNumSections; s++) job_[s].run(stream_, &timer_);
+    if (job_[kLengths].ready()) {                                  // LengthReader, reader.rs:48-67
+        timer_.begin(stream_, StageTimer::kOther);
+        launch_scan_runs_u32(stream_, job_[kLengths].out(), rec_cap_, d_rec_ends_.as<uint64_t>(), rec_cap_,
+                             d_scan_tmp_.bytes(), &totals[0], status);
+        timer_.end(stream_);
+    }
+    if (job_[kSequence].ready() && is_nuc_) {                      // SequenceReader, reader.rs:121-172
+        timer_.begin(stream_, StageTimer::kUnpack);
+        launch_unpack4(stream_, job_[kSequence].out(), job_[kSequence].size(), d_ascii_.bytes(),
+                       2 * job_[kSequence].size(), h_.sequence_type == 1 ? 'U' : 'T', status);
+        timer_.end(stream_);
+    }
+    if (job_[kMask].ready() && job_[kSequence].ready() && job_[kLengths].ready()) {   // mod.rs:386-388, 402-441
+        timer_.begin(stream_, StageTimer::kOther);
+        launch_scan_runs_u8(stream_, job_[kMask].out(), mask_cap_, d_mask_ends_.as<uint64_t>(), mask_cap_,
+                            d_scan_tmp_.bytes(), &totals[1], status);
+        uint8_t *seq = is_nuc_ ? d_ascii_.bytes() : job_[kSequence].out_mut();
+        const uint64_t n_seq = is_nuc_ ? mask_total_bases_ : std::min<uint64_t>(mask_total_bases_, job_[kSequence].size());
+        launch_mask_apply(stream_, seq, std::min<uint64_t>(n_seq, n_sequence_bytes()), d_mask_ends_.as<uint64_t>(),
+                          &totals[1], d_rec_ends_.as<uint64_t>(), &totals[0], mask_cap_, opt_.spec_mask ? 1 : 0, status);
+        timer_.end(stream_);
+    }
+    timer_.mark_total_end(stream_);
+    ScanTotals host_totals[2] = {{0, 0}, {0, 0}};
+    if (!hip_ok(hipMemcpyAsync(host_totals, totals, sizeof host_totals, hipMemcpyDeviceToHost, stream_)) ||
+        !hip_ok(hipStreamSynchronize(stream_)))
+        return Failure::make(NAFGPU_E_DEVICE, std::string("decode failed: ") + hipGetErrorString(hipGetLastError()));
+    rec_totals_ = host_totals[0];
+    mask_totals_ = host_totals[1];
+    times_ = timer_.collect();
+    for (int s = 0; s < kNumSections; s++) {
+        if (!job_[s].ready()) continue;
+        Failure f = job_[s].check(stream_);
+        if (f.status == NAFGPU_E_DEVICE) return f;
+        if (!f.ok()) fail_[s] = f;
+    }
+    return Failure();
+}
+
+const uint8_t *ArchiveJob::d_sequence() const {
+    if (!job_[kSequence].ready()) return nullptr;
+    return is_nuc_ ? d_ascii_.bytes() : job_[kSequence].out();
+}
+
+uint64_t ArchiveJob::n_sequence_bytes() const {
+    if (!job_[kSequence].ready()) return 0;
+    return is_nuc_ ? 2 * job_[kSequence].size() : job_[kSequence].size();
+}
+
+Failure ArchiveJob::copy_to_host(void *dst, const void *d_src, size_t n) {
+    if (!n) return Failure();
+    (void)hipSetDevice(device_);
+    if (!hip_ok(hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, stream_)) || !hip_ok(hipStreamSynchronize(stream_)))
+        return Failure::make(NAFGPU_E_DEVICE, "device-to-host copy failed");
+    return Failure();
+}
+
+Failure ArchiveJob::hash_device(const void *d_ptr, uint64_t n, uint64_t *out) {
+    (void)hipSetDevice(device_);
+    unsigned long long *acc = d_hash_.as<unsigned long long>();
+    (void)hipMemsetAsync(acc, 0, 8, stream_);
+    launch_hash64(stream_, static_cast<const uint8_t *>(d_ptr), n, acc);
+    unsigned long long v = 0;
+    Failure f = copy_to_host(&v, acc, 8);
+    *out = v;
+    return f;
+}
+
+}  // namespace nafgpu

@@ -1,0 +1,163 @@
+// engine.h -- device-side orchestration: buffers in HBM, kernel sequence per section, timing.
+//
+// Data layout in HBM (all hipMalloc'ed, 256-byte aligned, sized for a 288 GB device):
+//   archive   [256 B pad][archive bytes][64 B pad]      compressed input, uploaded once
+//   per zstd section:
+//     out       decoded bytes (packed 4-bit for DNA/RNA sequence, text otherwise)
+//     lit       literal buffer, only for blocks that have LZ sequences (16-B aligned per block)
+//     seqs      {ll, ml, offset_value} triples of those blocks
+//     blk_size  u32 per zstd block / blk_base u64 exclusive scan (+ total)
+//     task lists (plan.h) and the Huffman / FSE table pools
+//   ascii     one byte per base, masked, contiguous over all records   (DNA/RNA only)
+//   rec_ends  u64 inclusive prefix sum of record lengths
+//   mask_ends u64 inclusive prefix sum of mask runs
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "container.h"
+#include "kernels.h"
+#include "zplan.h"
+
+namespace nafgpu {
+
+class DevBuf {
+public:
+    DevBuf() = default;
+    ~DevBuf() { release(); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    bool alloc(size_t bytes);                 // contents undefined
+    bool upload(const void *host, size_t bytes, hipStream_t stream);   // alloc + async H2D
+    void release();
+    template <class T>
+    T *as() const { return static_cast<T *>(ptr_); }
+    uint8_t *bytes() const { return static_cast<uint8_t *>(ptr_); }
+    size_t size() const { return size_; }
+
+private:
+    void *ptr_ = nullptr;
+    size_t size_ = 0;
+};
+
+struct StageTimes {          // milliseconds, summed over launches of the last run
+    float huf = 0, seq_lz = 0, unpack = 0, other = 0, total = 0;
+    uint32_t huf_launches = 0;
+};
+
+// Records HIP events around kernel groups on one stream and sums them per category afterwards.
+class StageTimer {
+public:
+    enum Cat { kHuf = 0, kSeqLz, kUnpack, kOther, kNumCats };
+    ~StageTimer();
+    void begin(hipStream_t s, Cat c);
+    void end(hipStream_t s);
+    void mark_total_begin(hipStream_t s);
+    void mark_total_end(hipStream_t s);
+    StageTimes collect();                     // call after the stream is synchronised
+    void reset();
+
+private:
+    struct Span {
+        hipEvent_t a, b;
+        Cat cat;
+    };
+    hipEvent_t get();
+    std::vector<Span> spans_;
+    std::vector<hipEvent_t> pool_;
+    size_t used_ = 0;
+    hipEvent_t t0_ = nullptr, t1_ = nullptr;
+    bool open_ = false;
+};
+
+// One Zstandard-compressed NAF section resident on the device.
+class SectionJob {
+public:
+    // Walks the payload on the host (zplan), allocates HBM, uploads the task lists.
+    // d_payload points at the same bytes in device memory (>= 256 B readable in front, 64 behind).
+    Failure prepare(const uint8_t *host_payload, size_t n, uint64_t expect_size, const uint8_t *d_payload,
+                    hipStream_t stream);
+    // Enqueues the decode kernels.  Results: out() holds size() bytes once the stream is done.
+    void run(hipStream_t stream, StageTimer *timer);
+    // After synchronisation: device status -> Failure
+    Failure check(hipStream_t stream);
+
+    const uint8_t *out() const { return d_out_.bytes(); }
+    uint8_t *out_mut() const { return d_out_.bytes(); }
+    uint64_t size() const { return expect_; }
+    bool ready() const { return ready_; }
+    const ZPlan &plan() const { return plan_; }
+    uint64_t n_blocks() const { return n_blocks_; }
+    uint64_t n_streams() const { return n_streams_; }
+    float host_plan_ms() const { return plan_ms_; }
+
+private:
+    ZPlan plan_;
+    uint64_t expect_ = 0, n_blocks_ = 0, n_streams_ = 0, n_tasks_ = 0, n_copies_ = 0, n_seq_blocks_ = 0;
+    uint32_t max_tbl_entries_ = 0;
+    const uint8_t *d_src_ = nullptr;
+    float plan_ms_ = 0;
+    bool ready_ = false;
+    DevBuf d_out_, d_lit_, d_seqs_, d_blk_size_, d_blk_base_, d_scan_tmp_, d_status_;
+    DevBuf d_streams_, d_tasks_, d_tbl_copies_, d_pool_, d_copies_, d_seq_blocks_, d_cells_;
+};
+
+struct ArchiveOptions {
+    bool want[kNumSections] = {true, true, true, true, true, true};
+    bool spec_mask = false;
+};
+
+// A whole archive on one GPU: sections -> record table -> ASCII bases.
+class ArchiveJob {
+public:
+    ~ArchiveJob();
+    Failure init(int device);
+    // bytes must stay valid until upload() returns
+    Failure upload(const uint8_t *bytes, size_t n, const nafgpu_header &h, const SectionInfo sec[kNumSections],
+                   const ArchiveOptions &opt);
+    // (re)runs every kernel; synchronises; fills times
+    Failure decode();
+
+    // device results (valid after decode())
+    const uint8_t *d_sequence() const;       // ASCII (nucleotides) or text
+    uint64_t n_sequence_bytes() const;       // nucleotides: 2 * packed bytes (incl. a possible pad nibble)
+    uint64_t packed_bytes() const { return is_nuc_ && job_[kSequence].ready() ? job_[kSequence].size() : 0; }
+    const uint8_t *d_section(int s) const { return job_[s].ready() ? job_[s].out() : nullptr; }
+    uint64_t section_size(int s) const { return job_[s].ready() ? job_[s].size() : 0; }
+    const uint64_t *d_rec_ends() const { return d_rec_ends_.as<uint64_t>(); }
+    uint64_t n_records() const { return rec_totals_.count; }
+    uint64_t sum_lengths() const { return rec_totals_.sum; }
+    uint64_t mask_sum() const { return mask_totals_.sum; }
+    const SectionJob &job(int s) const { return job_[s]; }
+    Failure section_failure(int s) const { return fail_[s]; }
+    const StageTimes &times() const { return times_; }
+    float host_plan_ms() const { return plan_ms_; }
+    float h2d_ms() const { return h2d_ms_; }
+    uint64_t compressed_bytes() const { return compressed_; }
+    hipStream_t stream() const { return stream_; }
+    int device() const { return device_; }
+    Failure copy_to_host(void *dst, const void *d_src, size_t n);
+    Failure hash_device(const void *d_ptr, uint64_t n, uint64_t *out);
+
+private:
+    int device_ = -1;
+    hipStream_t stream_ = nullptr;
+    StageTimer timer_;
+    StageTimes times_;
+    nafgpu_header h_{};
+    ArchiveOptions opt_;
+    bool is_nuc_ = false;
+    DevBuf d_archive_;
+    SectionJob job_[kNumSections];
+    Failure fail_[kNumSections];
+    DevBuf d_ascii_, d_rec_ends_, d_mask_ends_, d_scan_tmp_, d_totals_, d_status_, d_hash_;
+    uint64_t rec_cap_ = 0, mask_cap_ = 0, mask_total_bases_ = 0;
+    ScanTotals rec_totals_{0, 0}, mask_totals_{0, 0};
+    float plan_ms_ = 0, h2d_ms_ = 0;
+    uint64_t compressed_ = 0;
+};
+
+}  // namespace nafgpu

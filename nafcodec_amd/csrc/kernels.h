@@ -1,0 +1,61 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels in kernels.hip.
+// All pointers are device pointers; every launch is asynchronous on `stream`.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "plan.h"
+
+namespace nafgpu {
+
+struct ScanTotals {          // written by the scan kernels
+    uint64_t sum;            // sum of all values
+    uint64_t count;          // number of run terminators (runs modes) or elements (exclusive mode)
+};
+
+// K2: FSE sequence decode, one lane per block with sequences.  Adds match bytes to blk_size[].
+void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *blocks, uint32_t n_blocks,
+                       const SeqCell *cells, Seq *seqs, uint32_t *blk_size, uint32_t *status);
+
+// K3: exclusive scan of u32 block sizes -> u64 bases (n+1 entries; the last is the total).
+// `tile_tmp` needs scan_tmp_bytes(n) bytes.  Flags status if the total differs from `expect_total`.
+size_t scan_tmp_bytes(uint64_t n);
+void launch_scan_blocks(hipStream_t stream, const uint32_t *blk_size, uint64_t n, uint64_t *blk_base, void *tile_tmp,
+                        uint64_t expect_total, uint32_t *status);
+
+// K6 / mask runs: values with a continuation sentinel (0xFFFFFFFF words / 0xFF bytes).
+// ends[k] = position (inclusive prefix sum) where run k ends; totals->count = number of runs.
+void launch_scan_runs_u32(hipStream_t stream, const uint8_t *words, uint64_t n_words, uint64_t *ends, uint64_t cap,
+                          void *tile_tmp, ScanTotals *totals, uint32_t *status);
+void launch_scan_runs_u8(hipStream_t stream, const uint8_t *bytes, uint64_t n_bytes, uint64_t *ends, uint64_t cap,
+                         void *tile_tmp, ScanTotals *totals, uint32_t *status);
+
+// raw / RLE blocks and literal sections
+void launch_copy_fill(hipStream_t stream, const uint8_t *src, const CopyTask *tasks, uint32_t n_tasks,
+                      const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t *status);
+
+// K1: Huffman literal streams, one lane per stream, one wave per task.
+// max_tbl_entries = largest staged-table footprint over the tasks (sizes the dynamic LDS).
+void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *tasks, uint32_t n_tasks,
+                       const HufTblCopy *copies, const HufStream *streams, const uint16_t *pool,
+                       const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t max_tbl_entries,
+                       uint32_t *status);
+
+// K4: LZ77 sequence execution (literal scatter + ordered match copy)
+void launch_lz_execute(hipStream_t stream, const SeqBlock *blocks, uint32_t n_blocks, const Seq *seqs,
+                       const uint8_t *lit, const uint64_t *blk_base, uint8_t *out, uint32_t *status);
+
+// K5: 4-bit -> IUPAC ASCII; t_char = 'T' (DNA) or 'U' (RNA)
+void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed, uint8_t *ascii, uint64_t n_bases,
+                    uint32_t t_char, uint32_t *status);
+
+// soft-mask: lower-case the masked runs (odd-numbered runs of mask_ends) honouring record ends
+void launch_mask_apply(hipStream_t stream, uint8_t *ascii, uint64_t n_bases, const uint64_t *mask_ends,
+                       const ScanTotals *mask_totals, const uint64_t *rec_ends, const ScanTotals *rec_totals,
+                       uint64_t max_runs, int spec_mask, uint32_t *status);
+
+// order-sensitive checksum of a device buffer (see hash64.h); *result must be zeroed first
+void launch_hash64(hipStream_t stream, const uint8_t *p, uint64_t n, unsigned long long *result);
+
+}  // namespace nafgpu

@@ -1,0 +1,823 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the NAF decode path.
+//
+// Everything here is integer / bit manipulation bound by HBM and LDS, not by MFMA:
+//   k_huf_decode   K1  Huffman literal streams (zstd literals section)        lane = stream
+//   k_seq_decode   K2  FSE sequence decode (LL / OF / ML)                     lane = block
+//   k_scan_*       K3/K6  tile scans: block bases, record ends, mask run ends
+//   k_copy_fill        Raw / RLE blocks and literal sections
+//   k_lz_execute   K4  literal scatter + ordered match copy
+//   k_unpack4      K5  4-bit -> IUPAC ASCII (reader.rs:121-172)
+//   k_mask_apply       soft-mask lower-casing incl. the record-end rule (mod.rs:402-441)
+//   k_hash64           checksum used by full-size parity tests
+// Reference counterparts are cited per kernel.  Format: RFC 8878 / SURVEY.md Appendix B.
+#include <hip/hip_runtime.h>
+
+#include "hash64.h"
+#include "kernels.h"
+#include "plan.h"
+
+namespace nafgpu {
+
+namespace {
+
+__device__ inline void flag_error(uint32_t *status, uint32_t code, uint32_t detail) {
+    if (atomicCAS(&status[0], 0u, code) == 0u) status[1] = detail;
+}
+
+// ======================================================================================
+// K1  Huffman literal streams
+// ======================================================================================
+// One wave per task, one lane per stream.  Each lane walks its backward
+// bitstream with a 64-bit window {hi, lo} plus one look-ahead word; words come from a per-lane
+// 16-word ring in LDS that the lane refills with 16-byte aligned global loads (one chunk in
+// flight).  Symbols are packed four to a dword, staged as 64-byte rows in LDS and flushed
+// cooperatively so that every global store instruction writes whole 64-byte segments.
+constexpr int kRowWords = 20;        // 80-byte padded LDS rows (64 used): conflict-free b128 access
+constexpr int kRingMask = 15;
+
+struct HufLane {
+    uint32_t hi, lo, nw;   // bit window: hi = word under the cursor, lo = next, nw = the one after
+    uint32_t c;            // bits of hi already consumed, kept in [1, 32]
+    uint32_t rp;           // ring index of hi
+};
+
+#define HUF_STEP(ACC, SHIFT, LEN_EXPR)                                                        \
+    {                                                                                         \
+        const uint32_t peek = static_cast<uint32_t>(((static_cast<uint64_t>(L.hi) << 32) | L.lo) >> (32u - L.c)); \
+        const uint32_t e = tbl[peek >> sh];                                                   \
+        const uint32_t len = (LEN_EXPR);                                                      \
+        L.c += len;                                                                           \
+        ACC |= (e & 0xFFu) << (SHIFT);                                                        \
+        const bool adv = L.c > 32u;                                                           \
+        L.hi = adv ? L.lo : L.hi;                                                             \
+        L.lo = adv ? L.nw : L.lo;                                                             \
+        L.c = adv ? L.c - 32u : L.c;                                                          \
+        L.rp += adv ? 1u : 0u;                                                                \
+        L.nw = ring[(L.rp + 2u) & kRingMask];                                                 \
+    }
+
+__global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ src, const HufTask *__restrict__ tasks,
+                                                   const HufTblCopy *__restrict__ copies,
+                                                   const HufStream *__restrict__ streams,
+                                                   const uint16_t *__restrict__ pool,
+                                                   const uint64_t *__restrict__ blk_base, uint8_t *out, uint8_t *lit,
+                                                   uint32_t *status) {
+    HIP_DYNAMIC_SHARED(uint16_t, s_tbl)
+    __shared__ __attribute__((aligned(16))) uint32_t s_ring[64 * kRowWords];
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[64 * kRowWords];
+    __shared__ uint64_t s_dst[64];
+    __shared__ uint32_t s_n[64];
+    __shared__ uint32_t s_nmax;
+
+    if (status[0] != 0) return;
+    const uint32_t lane = threadIdx.x;
+    const HufTask task = tasks[blockIdx.x];
+
+    for (uint32_t k = 0; k < task.n_copies; k++) {
+        const HufTblCopy cp = copies[task.first_copy + k];
+        for (uint32_t e = lane; e < cp.n_entries; e += 64) s_tbl[cp.lds_off + e] = pool[cp.pool_off + e];
+    }
+    if (lane == 0) s_nmax = 0;
+
+    const bool have = lane < task.n_streams;
+    HufStream st{};
+    if (have) st = streams[task.first_stream + lane];
+    const uint32_t n = st.n_syms;
+    const uint32_t sh = 32u - st.max_bits;
+    const uint16_t *tbl = s_tbl + st.tbl_lds;
+    uint32_t *ring = s_ring + lane * kRowWords;
+    uint32_t *orow = s_out + lane * kRowWords;
+
+    HufLane L{0, 0, 0, 1, 0};
+    const uint8_t *ctop = nullptr;       // 16-byte chunk holding the stream's last byte
+    uint32_t wp = 0, lp = 0;             // chunks written to the ring / issued
+    uint4 pend = make_uint4(0, 0, 0, 0);
+    uint32_t c0 = 1, rp0 = 0, bits_total = 0;
+    bool bad = false;
+    if (have) {
+        const uint8_t *lastp = src + st.src_end - 1;
+        const uint32_t lastb = *lastp;
+        bad = lastb == 0;                                        // no end mark
+        const uint32_t hb = 31u - static_cast<uint32_t>(__clz(static_cast<int>(lastb | 1u)));
+        bits_total = (st.src_len - 1u) * 8u + hb;
+        const uintptr_t a = reinterpret_cast<uintptr_t>(lastp);
+        ctop = reinterpret_cast<const uint8_t *>(a & ~static_cast<uintptr_t>(15));
+        L.rp = 3u - static_cast<uint32_t>((a >> 2) & 3u);
+        L.c = (3u - static_cast<uint32_t>(a & 3u)) * 8u + (8u - hb);
+        c0 = L.c;
+        rp0 = L.rp;
+        for (uint32_t j = 0; j < 3; j++) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(ctop - 16 * j);
+            *reinterpret_cast<uint4 *>(ring + 4 * j) = make_uint4(v.w, v.z, v.y, v.x);
+        }
+        wp = 3;
+        pend = *reinterpret_cast<const uint4 *>(ctop - 48);
+        lp = 4;
+        L.hi = ring[L.rp];
+        L.lo = ring[L.rp + 1];
+        L.nw = ring[L.rp + 2];
+        s_dst[lane] = reinterpret_cast<uint64_t>((st.flags & 1) ? lit + st.dst : out + blk_base[st.blk] + st.dst);
+    } else {
+        s_dst[lane] = 0;
+    }
+    s_n[lane] = n;
+    __syncthreads();
+    atomicMax(&s_nmax, n);
+    __syncthreads();
+    const uint32_t nmax = s_nmax;
+
+    for (uint32_t base = 0; base < nmax; base += 64) {
+        if (base < n) {
+#pragma unroll 1
+            for (uint32_t g = 0; g < 8; g++) {
+                const uint32_t i0 = base + g * 8;
+                if (i0 >= n) break;
+                // ---- service the input ring: land the chunk in flight, then issue the next one
+                if (lp > wp) {
+                    *reinterpret_cast<uint4 *>(ring + ((4 * wp) & kRingMask)) = make_uint4(pend.w, pend.z, pend.y, pend.x);
+                    wp++;
+                }
+                if (4 * lp + 3 < L.rp + 16) {
+                    pend = *reinterpret_cast<const uint4 *>(ctop - 16 * static_cast<size_t>(lp));
+                    lp++;
+                }
+                uint32_t a0 = 0, a1 = 0;
+                if (i0 + 8 <= n) {
+                    HUF_STEP(a0, 0, e >> 8)
+                    HUF_STEP(a0, 8, e >> 8)
+                    HUF_STEP(a0, 16, e >> 8)
+                    HUF_STEP(a0, 24, e >> 8)
+                    HUF_STEP(a1, 0, e >> 8)
+                    HUF_STEP(a1, 8, e >> 8)
+                    HUF_STEP(a1, 16, e >> 8)
+                    HUF_STEP(a1, 24, e >> 8)
+                } else {                                         // last group of this stream: freeze past n
+                    HUF_STEP(a0, 0, (i0 + 0 < n) ? e >> 8 : 0u)
+                    HUF_STEP(a0, 8, (i0 + 1 < n) ? e >> 8 : 0u)
+                    HUF_STEP(a0, 16, (i0 + 2 < n) ? e >> 8 : 0u)
+                    HUF_STEP(a0, 24, (i0 + 3 < n) ? e >> 8 : 0u)
+                    HUF_STEP(a1, 0, (i0 + 4 < n) ? e >> 8 : 0u)
+                    HUF_STEP(a1, 8, (i0 + 5 < n) ? e >> 8 : 0u)
+                    HUF_STEP(a1, 16, (i0 + 6 < n) ? e >> 8 : 0u)
+                    HUF_STEP(a1, 24, (i0 + 7 < n) ? e >> 8 : 0u)
+                }
+                *reinterpret_cast<uint2 *>(orow + 2 * g) = make_uint2(a0, a1);
+            }
+        }
+        __syncthreads();
+        // ---- cooperative flush: lane j stores 16 bytes of row (j/4 + 16k); 4 lanes cover a 64-byte row
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t row = (lane >> 2) + 16 * k;
+            const uint32_t col = (lane & 3) * 16;
+            const uint32_t rn = s_n[row];
+            if (rn > base) {
+                const uint32_t valid = rn - base < 64u ? rn - base : 64u;
+                if (col < valid) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(s_out + row * kRowWords + (col >> 2));
+                    uint8_t *d = reinterpret_cast<uint8_t *>(s_dst[row]) + base + col;
+                    if (col + 16 <= valid) {
+                        if ((reinterpret_cast<uintptr_t>(d) & 15) == 0) {
+                            *reinterpret_cast<uint4 *>(d) = v;
+                        } else {
+                            __builtin_memcpy(d, &v, 16);
+                        }
+                    } else {
+                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                        for (uint32_t b = 0; b < valid - col; b++) d[b] = static_cast<uint8_t>(w[b >> 2] >> (8 * (b & 3)));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (have) {
+        const uint32_t consumed = 32u * (L.rp - rp0) + L.c - c0;
+        if (bad || consumed != bits_total) flag_error(status, kStHufBadEnd, task.first_stream + lane);
+    }
+}
+
+// ======================================================================================
+// K2  FSE sequence decode (App. B "Sequence decode loop")
+// ======================================================================================
+struct BackBits {
+    const uint8_t *p;     // first byte of the bitstream
+    int64_t pos;          // unread bits below the cursor (may go negative on corrupt input)
+    __device__ uint32_t read(uint32_t nb) {
+        pos -= nb;
+        if (nb == 0) return 0;
+        int64_t lo = pos;
+        uint32_t lsh = 0;
+        if (lo < 0) {                       // bits below the start read as zero
+            if (lo + static_cast<int64_t>(nb) <= 0) return 0;
+            lsh = static_cast<uint32_t>(-lo);
+            nb -= lsh;
+            lo = 0;
+        }
+        const uint8_t *q = p + (lo >> 3);
+        uint64_t v = static_cast<uint64_t>(q[0]) | (static_cast<uint64_t>(q[1]) << 8) |
+                     (static_cast<uint64_t>(q[2]) << 16) | (static_cast<uint64_t>(q[3]) << 24) |
+                     (static_cast<uint64_t>(q[4]) << 32);   // the source buffer is padded at the back
+        v >>= (lo & 7);
+        return static_cast<uint32_t>(v & ((1ull << nb) - 1)) << lsh;
+    }
+};
+
+__global__ __launch_bounds__(64) void k_seq_decode(const uint8_t *__restrict__ src, const SeqBlock *__restrict__ blocks,
+                                                   uint32_t n_blocks, const SeqCell *__restrict__ cells, Seq *seqs,
+                                                   uint32_t *blk_size, uint32_t *status) {
+    if (status[0] != 0) return;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const SeqBlock sb = blocks[b];
+    const uint8_t *bits = src + sb.bits_off;
+    const uint32_t lastb = bits[sb.bits_len - 1];   // host checked: non-zero
+    BackBits r{bits, static_cast<int64_t>(sb.bits_len - 1) * 8 + (31 - __clz(static_cast<int>(lastb | 1u)))};
+    const SeqCell *tll = cells + sb.ll_tbl, *tof = cells + sb.of_tbl, *tml = cells + sb.ml_tbl;
+    uint32_t sll = r.read(sb.ll_al), sof = r.read(sb.of_al), sml = r.read(sb.ml_al);
+    Seq *dst = seqs + sb.seq_first;
+    uint64_t sum_ll = 0, sum_ml = 0;
+    for (uint32_t i = 0; i < sb.n_seq; i++) {
+        const SeqCell cl = tll[sll], co = tof[sof], cm = tml[sml];
+        Seq s;
+        s.ofv = co.base_value + r.read(co.extra_bits);   // extra bits in the order OF, ML, LL
+        s.ml = cm.base_value + r.read(cm.extra_bits);
+        s.ll = cl.base_value + r.read(cl.extra_bits);
+        if (i + 1 < sb.n_seq) {                          // state updates LL, ML, OF; none after the last
+            sll = cl.next_base + r.read(cl.nb);
+            sml = cm.next_base + r.read(cm.nb);
+            sof = co.next_base + r.read(co.nb);
+        }
+        if (r.pos < 0) break;
+        dst[i] = s;
+        sum_ll += s.ll;
+        sum_ml += s.ml;
+    }
+    if (r.pos != 0) {
+        flag_error(status, kStSeqBadEnd, sb.blk);
+        return;
+    }
+    if (sum_ll > sb.lit_size) {
+        flag_error(status, kStSeqLiterals, sb.blk);
+        return;
+    }
+    if (sb.lit_size + sum_ml > kBlockMax) {
+        flag_error(status, kStSizeMismatch, sb.blk);
+        return;
+    }
+    blk_size[sb.blk] = sb.lit_size + static_cast<uint32_t>(sum_ml);
+}
+
+// ======================================================================================
+// K3 / K6  tile scans
+// ======================================================================================
+// One generic three-pass scan over "items" that carry a value and a terminator bit:
+//   exclusive mode : item = u32 block size          -> out[i] = sum of items before i
+//   runs modes     : item = length word / mask byte -> ends[k] = inclusive sum at the k-th
+//                    terminator (value != sentinel).  Record k therefore spans
+//                    [ends[k-1], ends[k]) -- LengthReader (reader.rs:48-67) and MaskReader
+//                    (reader.rs:198-231) folded into one prefix sum.
+constexpr uint32_t kScanThreads = 256;
+constexpr uint32_t kScanItems = 8;
+constexpr uint32_t kScanTile = kScanThreads * kScanItems;
+
+struct TileAgg {
+    uint64_t sum;
+    uint64_t cnt;
+};
+
+enum ScanMode { kModeExcl = 0, kModeRunsU32 = 1, kModeRunsU8 = 2 };
+
+template <int MODE>
+__device__ inline void scan_item(const uint8_t *in, uint64_t i, uint64_t n, uint64_t *v, uint32_t *t) {
+    if (i >= n) {
+        *v = 0;
+        *t = 0;
+        return;
+    }
+    if (MODE == kModeRunsU8) {
+        const uint32_t b = in[i];
+        *v = b;
+        *t = b != 0xFFu;
+    } else {
+        const uint8_t *q = in + 4 * i;      // length words are not guaranteed 4-byte aligned in memory
+        const uint32_t w = static_cast<uint32_t>(q[0]) | (static_cast<uint32_t>(q[1]) << 8) |
+                           (static_cast<uint32_t>(q[2]) << 16) | (static_cast<uint32_t>(q[3]) << 24);
+        *v = w;
+        *t = MODE == kModeExcl ? 1u : (w != 0xFFFFFFFFu);
+    }
+}
+
+// block-wide exclusive scan of one (sum, cnt) pair per thread; returns the block total in *tot
+__device__ inline void block_scan_pair(uint64_t &sum, uint32_t &cnt, TileAgg *tot, uint64_t *s_sum, uint32_t *s_cnt) {
+    const uint32_t t = threadIdx.x;
+    s_sum[t] = sum;
+    s_cnt[t] = cnt;
+    __syncthreads();
+    for (uint32_t d = 1; d < kScanThreads; d <<= 1) {
+        uint64_t a = 0;
+        uint32_t c = 0;
+        if (t >= d) {
+            a = s_sum[t - d];
+            c = s_cnt[t - d];
+        }
+        __syncthreads();
+        s_sum[t] += a;
+        s_cnt[t] += c;
+        __syncthreads();
+    }
+    tot->sum = s_sum[kScanThreads - 1];
+    tot->cnt = s_cnt[kScanThreads - 1];
+    const uint64_t incl_s = s_sum[t];
+    const uint32_t incl_c = s_cnt[t];
+    __syncthreads();
+    sum = incl_s - sum;
+    cnt = incl_c - cnt;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_scan_reduce(const uint8_t *in, uint64_t n, TileAgg *tiles) {
+    // (no early-out on the status word: these kernels are memory-safe on any input, and a
+    //  multi-wave workgroup must reach its barriers with uniform control flow)
+    __shared__ uint64_t s_sum[kScanThreads];
+    __shared__ uint32_t s_cnt[kScanThreads];
+    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kScanTile + threadIdx.x * kScanItems;
+    uint64_t sum = 0;
+    uint32_t cnt = 0;
+    for (uint32_t k = 0; k < kScanItems; k++) {
+        uint64_t v;
+        uint32_t t;
+        scan_item<MODE>(in, base + k, n, &v, &t);
+        sum += v;
+        cnt += t;
+    }
+    TileAgg tot;
+    block_scan_pair(sum, cnt, &tot, s_sum, s_cnt);
+    if (threadIdx.x == 0) tiles[blockIdx.x] = tot;
+}
+
+// single workgroup: exclusive scan of the tile aggregates in place; grand total -> totals
+__global__ __launch_bounds__(256) void k_scan_tiles(TileAgg *tiles, uint64_t n_tiles, ScanTotals *totals) {
+    __shared__ uint64_t s_sum[kScanThreads];
+    __shared__ uint32_t s_cnt[kScanThreads];
+    uint64_t run_sum = 0, run_cnt = 0;
+    for (uint64_t base = 0; base < n_tiles; base += kScanThreads) {
+        const uint64_t i = base + threadIdx.x;
+        TileAgg a{0, 0};
+        if (i < n_tiles) a = tiles[i];
+        uint64_t sum = a.sum;
+        uint32_t cnt = static_cast<uint32_t>(a.cnt);     // a tile holds at most kScanTile terminators
+        TileAgg tot;
+        block_scan_pair(sum, cnt, &tot, s_sum, s_cnt);
+        if (i < n_tiles) tiles[i] = TileAgg{run_sum + sum, run_cnt + cnt};
+        run_sum += tot.sum;
+        run_cnt += tot.cnt;
+    }
+    if (threadIdx.x == 0) {
+        totals->sum = run_sum;
+        totals->count = run_cnt;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_scan_emit(const uint8_t *in, uint64_t n, const TileAgg *tiles, uint64_t *out,
+                                                   uint64_t cap, uint32_t *status) {
+    __shared__ uint64_t s_sum[kScanThreads];
+    __shared__ uint32_t s_cnt[kScanThreads];
+    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kScanTile + threadIdx.x * kScanItems;
+    uint64_t v[kScanItems];
+    uint32_t t[kScanItems];
+    uint64_t sum = 0;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kScanItems; k++) {
+        scan_item<MODE>(in, base + k, n, &v[k], &t[k]);
+        sum += v[k];
+        cnt += t[k];
+    }
+    TileAgg tot;
+    block_scan_pair(sum, cnt, &tot, s_sum, s_cnt);
+    const TileAgg tile = tiles[blockIdx.x];
+    uint64_t run = tile.sum + sum;          // exclusive prefix of this thread's first item
+    uint64_t idx = tile.cnt + cnt;
+#pragma unroll
+    for (uint32_t k = 0; k < kScanItems; k++) {
+        if (base + k >= n) break;
+        if (MODE == kModeExcl) {
+            out[base + k] = run;
+            run += v[k];
+        } else {
+            run += v[k];
+            if (t[k]) {
+                if (idx < cap)
+                    out[idx] = run;
+                else
+                    flag_error(status, kStRunsOverflow, 0);
+                idx++;
+            }
+        }
+    }
+}
+
+__global__ void k_scan_finish_blocks(uint64_t *blk_base, uint64_t n, const ScanTotals *totals, uint64_t expect,
+                                     uint32_t *status) {
+    if (status[0] != 0) return;
+    blk_base[n] = totals->sum;
+    if (totals->sum != expect) flag_error(status, kStSizeMismatch, 0xFFFFFFFFu);
+}
+
+// ======================================================================================
+// Raw / RLE blocks and literal sections
+// ======================================================================================
+__global__ __launch_bounds__(256) void k_copy_fill(const uint8_t *__restrict__ src, const CopyTask *__restrict__ tasks,
+                                                   const uint64_t *__restrict__ blk_base, uint8_t *out, uint8_t *lit,
+                                                   const uint32_t *status) {
+    if (status[0] != 0) return;
+    const CopyTask t = tasks[blockIdx.x];
+    uint8_t *d = (t.flags & 1) ? lit + t.dst : out + blk_base[t.blk] + t.dst;
+    if (t.flags & 2) {
+        const uint8_t v = static_cast<uint8_t>(t.src_off);
+        for (uint32_t i = threadIdx.x; i < t.len; i += blockDim.x) d[i] = v;
+    } else {
+        const uint8_t *s = src + t.src_off;
+        for (uint32_t i = threadIdx.x; i < t.len; i += blockDim.x) d[i] = s[i];
+    }
+}
+
+// ======================================================================================
+// K4  LZ77 execution (App. B "Repeat offsets" + "Execute")
+// ======================================================================================
+// Round-1 shape: ONE workgroup walks the blocks that have sequences in frame order, so every
+// cross-block dependency (repeat offsets, window matches) is satisfied by construction.
+// Literal-only blocks were already written by K1.  Inside a batch of 256 sequences the
+// literal copies run in parallel and the matches in order (a match may read the previous one).
+__global__ __launch_bounds__(256) void k_lz_execute(const SeqBlock *__restrict__ blocks, uint32_t n_blocks,
+                                                    const Seq *__restrict__ seqs, const uint8_t *__restrict__ lit,
+                                                    const uint64_t *__restrict__ blk_base, uint8_t *out,
+                                                    uint32_t *status) {
+    __shared__ uint32_t s_ll[256], s_ml[256], s_off[256], s_lpos[256];
+    __shared__ uint64_t s_opos[256];
+    __shared__ uint64_t s_rep[3];
+    __shared__ uint64_t s_cur_o;
+    __shared__ uint32_t s_cur_l, s_frame;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) {
+        s_frame = 0xFFFFFFFFu;
+        s_cur_l = status[0];            // broadcast the abort decision: barriers need uniform control flow
+    }
+    __syncthreads();
+    if (s_cur_l != 0) return;
+    __syncthreads();
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        const SeqBlock sb = blocks[b];
+        const uint64_t obase = blk_base[sb.blk];
+        const uint64_t fstart = blk_base[sb.frame_first_blk];
+        const uint8_t *blit = lit + sb.lit_off;
+        if (tid == 0) {
+            if (s_frame != sb.frame_first_blk) {        // repeat offsets restart with each frame
+                s_frame = sb.frame_first_blk;
+                s_rep[0] = 1;
+                s_rep[1] = 4;
+                s_rep[2] = 8;
+            }
+            s_cur_o = obase;
+            s_cur_l = 0;
+        }
+        __syncthreads();
+        for (uint32_t s0 = 0; s0 < sb.n_seq; s0 += 256) {
+            const uint32_t cnt = sb.n_seq - s0 < 256u ? sb.n_seq - s0 : 256u;
+            if (tid < cnt) {
+                const Seq q = seqs[sb.seq_first + s0 + tid];
+                s_ll[tid] = q.ll;
+                s_ml[tid] = q.ml;
+                s_off[tid] = q.ofv;
+            }
+            __syncthreads();
+            if (tid == 0) {                              // serial: repeat-offset history + positions
+                uint64_t r0 = s_rep[0], r1 = s_rep[1], r2 = s_rep[2];
+                uint64_t o = s_cur_o;
+                uint32_t l = s_cur_l;
+                for (uint32_t i = 0; i < cnt; i++) {
+                    const uint32_t ll = s_ll[i], ofv = s_off[i];
+                    uint64_t off;
+                    if (ofv > 3) {
+                        off = ofv - 3;
+                        r2 = r1;
+                        r1 = r0;
+                        r0 = off;
+                    } else {
+                        const uint32_t idx = ofv - 1 + (ll == 0 ? 1u : 0u);
+                        if (idx == 0) {
+                            off = r0;
+                        } else {
+                            off = idx == 1 ? r1 : (idx == 2 ? r2 : r0 - 1);
+                            if (idx > 1) r2 = r1;
+                            r1 = r0;
+                            r0 = off;
+                        }
+                    }
+                    s_opos[i] = o;
+                    s_lpos[i] = l;
+                    o += ll;
+                    l += ll;
+                    if (off == 0 || off > o - fstart) {   // reaches before the frame: corrupt
+                        flag_error(status, kStBadOffset, sb.blk);
+                        s_ml[i] = 0x80000000u | s_ml[i];  // keep the length for positions, skip the copy
+                        off = 1;
+                    }
+                    s_off[i] = static_cast<uint32_t>(off);
+                    o += s_ml[i] & 0x7FFFFFFFu;
+                }
+                s_rep[0] = r0;
+                s_rep[1] = r1;
+                s_rep[2] = r2;
+                s_cur_o = o;
+                s_cur_l = l;
+            }
+            __syncthreads();
+            if (tid < cnt) {                             // literal runs: independent of each other
+                uint8_t *d = out + s_opos[tid];
+                const uint8_t *s = blit + s_lpos[tid];
+                const uint32_t ll = s_ll[tid];
+                for (uint32_t k = 0; k < ll; k++) d[k] = s[k];
+            }
+            __syncthreads();
+            for (uint32_t i = 0; i < cnt; i++) {         // matches: in order
+                const uint32_t mlf = s_ml[i];
+                if (!(mlf & 0x80000000u)) {
+                    const uint32_t ml = mlf, off = s_off[i];
+                    uint8_t *d = out + s_opos[i] + s_ll[i];
+                    const uint8_t *s = d - off;
+                    if (off >= ml) {
+                        for (uint32_t k = tid; k < ml; k += 256) d[k] = s[k];
+                    } else {
+                        for (uint32_t k = tid; k < ml; k += 256) d[k] = s[k % off];   // overlapping: periodic
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        {                                                // literals after the last sequence
+            const uint32_t l = s_cur_l;
+            uint8_t *d = out + s_cur_o;
+            for (uint32_t k = tid; k < sb.lit_size - l; k += 256) d[k] = blit[l + k];
+        }
+        __syncthreads();
+    }
+}
+
+// ======================================================================================
+// K5  4-bit -> IUPAC ASCII (SequenceReader::read_nucleotide / decode, reader.rs:121-172)
+// ======================================================================================
+// Byte b of the packed stream yields LUT[b & 15] then LUT[b >> 4]; records are contiguous in
+// nibble space, so record k is bases [end[k-1], end[k]) of this one flat array -- the odd-nibble
+// `cache` of reader.rs:92-94,138-143 is just an odd offset here.
+__device__ inline uint32_t lut4(uint32_t nib, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
+    const uint32_t sel = nib & 0x07070707u;
+    const uint32_t lo = __builtin_amdgcn_perm(t1, t0, sel);
+    const uint32_t hi = __builtin_amdgcn_perm(t3, t2, sel);
+    const uint32_t m = ((nib >> 3) & 0x01010101u) * 0xFFu;
+    return (hi & m) | (lo & ~m);
+}
+
+__device__ inline void unpack_dword(uint32_t w, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t *o0,
+                                    uint32_t *o1) {
+    const uint32_t L = lut4(w & 0x0F0F0F0Fu, t0, t1, t2, t3);
+    const uint32_t H = lut4((w >> 4) & 0x0F0F0F0Fu, t0, t1, t2, t3);
+    *o0 = __builtin_amdgcn_perm(H, L, 0x05010400u);   // L0 H0 L1 H1
+    *o1 = __builtin_amdgcn_perm(H, L, 0x07030602u);   // L2 H2 L3 H3
+}
+
+__global__ __launch_bounds__(256) void k_unpack4(const uint8_t *__restrict__ packed, uint64_t n_packed,
+                                                 uint8_t *__restrict__ ascii, uint64_t n_bases, uint32_t t_char,
+                                                 const uint32_t *status) {
+    if (status[0] != 0) return;
+    // "-TGKCYSBAWRDMHVN" with index 1 = 'T' (DNA) or 'U' (RNA)
+    const uint32_t t0 = 0x4B47002Du | (t_char << 8);  // '-' T 'G' 'K'
+    const uint32_t t1 = 0x42535943u;                  // 'C' 'Y' 'S' 'B'
+    const uint32_t t2 = 0x44525741u;                  // 'A' 'W' 'R' 'D'
+    const uint32_t t3 = 0x4E56484Du;                  // 'M' 'H' 'V' 'N'
+    const uint64_t n_vec = n_bases / 32;              // whole 16-byte input groups that are fully in range
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+        const uint4 in = *reinterpret_cast<const uint4 *>(packed + 16 * i);
+        uint4 a, b;
+        unpack_dword(in.x, t0, t1, t2, t3, &a.x, &a.y);
+        unpack_dword(in.y, t0, t1, t2, t3, &a.z, &a.w);
+        unpack_dword(in.z, t0, t1, t2, t3, &b.x, &b.y);
+        unpack_dword(in.w, t0, t1, t2, t3, &b.z, &b.w);
+        uint4 *o = reinterpret_cast<uint4 *>(ascii + 32 * i);
+        o[0] = a;
+        o[1] = b;
+    }
+    // tail (< 32 bases): one thread, byte by byte
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t tt[4] = {t0, t1, t2, t3};
+        for (uint64_t k = n_vec * 32; k < n_bases; k++) {
+            const uint64_t byte = k >> 1;
+            if (byte >= n_packed) break;
+            const uint32_t nib = (k & 1) ? packed[byte] >> 4 : packed[byte] & 15u;
+            ascii[k] = static_cast<uint8_t>(tt[nib >> 2] >> (8 * (nib & 3)));
+        }
+    }
+}
+
+// ======================================================================================
+// soft mask (MaskReader + Decoder::mask_sequence, reader.rs:198-231, mod.rs:402-441)
+// ======================================================================================
+// Runs alternate unmasked / masked starting unmasked; run k covers [ends[k-1], ends[k]).
+// The reference lower-cases a masked run only where it ENDS strictly inside the current record
+// (mod.rs:410-415); the part of a run that reaches or crosses a record end stays upper case
+// (SURVEY App. D-1).  In global coordinates: for a masked run [s, e) let r be the record that
+// holds base e-1; it is lower-cased over [max(s, start_r), e) iff e < end_r.  spec_mask != 0
+// lower-cases the whole run instead.
+__device__ inline uint32_t lower4(uint32_t w, uint32_t byte_mask) {
+    uint32_t r = w;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t c = (w >> (8 * k)) & 0xFFu;
+        if (((byte_mask >> k) & 1u) && c - 'A' < 26u) r |= 0x20u << (8 * k);
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_bases, const uint64_t *__restrict__ mask_ends,
+                                                    const ScanTotals *mask_totals, const uint64_t *__restrict__ rec_ends,
+                                                    const ScanTotals *rec_totals, int spec_mask, const uint32_t *status) {
+    if (status[0] != 0) return;
+    const uint64_t n_runs = mask_totals->count;
+    const uint64_t n_rec = rec_totals->count;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+    for (uint64_t k = 2 * wave + 1; k < n_runs; k += 2 * n_waves) {     // odd runs are the masked ones
+        uint64_t s = mask_ends[k - 1];
+        uint64_t e = mask_ends[k];
+        if (s >= n_bases) break;
+        if (e > n_bases) {                       // MaskReader stops at `total`; the overshoot is never applied
+            if (!spec_mask) continue;
+            e = n_bases;
+        }
+        if (e <= s) continue;
+        if (!spec_mask) {
+            // record holding base e-1: first record whose end is > e-1
+            uint64_t lo = 0, hi = n_rec;
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (rec_ends[mid] > e - 1)
+                    hi = mid;
+                else
+                    lo = mid + 1;
+            }
+            if (lo >= n_rec) continue;           // beyond the last record
+            const uint64_t rend = rec_ends[lo];
+            const uint64_t rstart = lo ? rec_ends[lo - 1] : 0;
+            if (e >= rend) continue;             // run reaches the record end: stays upper case
+            if (s < rstart) s = rstart;
+        }
+        // lower-case [s, e): aligned dwords, byte masks at both edges
+        const uint64_t w0 = s >> 2, w1 = (e + 3) >> 2;
+        uint32_t *words = reinterpret_cast<uint32_t *>(ascii);
+        for (uint64_t w = w0 + lane; w < w1; w += 64) {
+            uint32_t bm = 0xFu;
+            if (w == w0) bm &= 0xFu << (s & 3);
+            if (w == w1 - 1 && (e & 3)) bm &= 0xFu >> (4 - (e & 3));
+            if (bm == 0xFu) {
+                words[w] = lower4(words[w], 0xFu);
+            } else {                              // edge dword: touch only our bytes (neighbours belong to other waves)
+                for (uint32_t b = 0; b < 4; b++)
+                    if ((bm >> b) & 1u) {
+                        const uint8_t c = ascii[4 * w + b];
+                        if (static_cast<uint32_t>(c) - 'A' < 26u) ascii[4 * w + b] = c | 0x20;
+                    }
+            }
+        }
+    }
+}
+
+// ======================================================================================
+// checksum (hash64.h)
+// ======================================================================================
+__global__ __launch_bounds__(256) void k_hash64(const uint8_t *__restrict__ p, uint64_t n, unsigned long long *result) {
+    __shared__ uint64_t s_part[256];
+    const uint64_t n_chunks = (n + kHashChunk - 1) / kHashChunk;
+    uint64_t acc = 0;
+    for (uint64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const uint64_t lo = c * kHashChunk;
+        uint64_t s = 0;
+        for (uint32_t k = 0; k < kHashChunk / 256; k++) {
+            const uint64_t i = threadIdx.x + 256ull * k;
+            if (lo + i < n) s += (static_cast<uint64_t>(p[lo + i]) + 1) * (2 * i + 1);
+        }
+        s_part[threadIdx.x] = s;
+        __syncthreads();
+        for (uint32_t d = 128; d > 0; d >>= 1) {
+            if (threadIdx.x < d) s_part[threadIdx.x] += s_part[threadIdx.x + d];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) acc += hash_chunk_final(c, s_part[0]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && acc) atomicAdd(result, static_cast<unsigned long long>(acc));
+}
+
+}  // namespace
+
+// ======================================================================================
+// launchers
+// ======================================================================================
+void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *blocks, uint32_t n_blocks,
+                       const SeqCell *cells, Seq *seqs, uint32_t *blk_size, uint32_t *status) {
+    if (!n_blocks) return;
+    hipLaunchKernelGGL(k_seq_decode, dim3((n_blocks + 63) / 64), dim3(64), 0, stream, src, blocks, n_blocks, cells, seqs,
+                       blk_size, status);
+}
+
+size_t scan_tmp_bytes(uint64_t n) { return static_cast<size_t>((n + kScanTile - 1) / kScanTile + 1) * sizeof(TileAgg); }
+
+template <int MODE>
+static void scan_generic(hipStream_t stream, const uint8_t *in, uint64_t n, uint64_t *out, uint64_t cap, void *tile_tmp,
+                         ScanTotals *totals, uint32_t *status) {
+    const uint64_t n_tiles = (n + kScanTile - 1) / kScanTile;
+    TileAgg *tiles = static_cast<TileAgg *>(tile_tmp);
+    if (n_tiles)
+        hipLaunchKernelGGL(k_scan_reduce<MODE>, dim3(static_cast<uint32_t>(n_tiles)), dim3(kScanThreads), 0, stream, in, n,
+                           tiles);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(kScanThreads), 0, stream, tiles, n_tiles, totals);
+    if (n_tiles)
+        hipLaunchKernelGGL(k_scan_emit<MODE>, dim3(static_cast<uint32_t>(n_tiles)), dim3(kScanThreads), 0, stream, in, n,
+                           tiles, out, cap, status);
+}
+
+void launch_scan_blocks(hipStream_t stream, const uint32_t *blk_size, uint64_t n, uint64_t *blk_base, void *tile_tmp,
+                        uint64_t expect_total, uint32_t *status) {
+    // totals live right behind the tile aggregates
+    TileAgg *tiles = static_cast<TileAgg *>(tile_tmp);
+    ScanTotals *totals = reinterpret_cast<ScanTotals *>(tiles + (n + kScanTile - 1) / kScanTile);
+    scan_generic<kModeExcl>(stream, reinterpret_cast<const uint8_t *>(blk_size), n, blk_base, n, tile_tmp, totals, status);
+    hipLaunchKernelGGL(k_scan_finish_blocks, dim3(1), dim3(1), 0, stream, blk_base, n, totals, expect_total, status);
+}
+
+void launch_scan_runs_u32(hipStream_t stream, const uint8_t *words, uint64_t n_words, uint64_t *ends, uint64_t cap,
+                          void *tile_tmp, ScanTotals *totals, uint32_t *status) {
+    scan_generic<kModeRunsU32>(stream, words, n_words, ends, cap, tile_tmp, totals, status);
+}
+
+void launch_scan_runs_u8(hipStream_t stream, const uint8_t *bytes, uint64_t n_bytes, uint64_t *ends, uint64_t cap,
+                         void *tile_tmp, ScanTotals *totals, uint32_t *status) {
+    scan_generic<kModeRunsU8>(stream, bytes, n_bytes, ends, cap, tile_tmp, totals, status);
+}
+
+void launch_copy_fill(hipStream_t stream, const uint8_t *src, const CopyTask *tasks, uint32_t n_tasks,
+                      const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t *status) {
+    if (!n_tasks) return;
+    hipLaunchKernelGGL(k_copy_fill, dim3(n_tasks), dim3(256), 0, stream, src, tasks, blk_base, out, lit, status);
+}
+
+void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *tasks, uint32_t n_tasks,
+                       const HufTblCopy *copies, const HufStream *streams, const uint16_t *pool,
+                       const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t max_tbl_entries,
+                       uint32_t *status) {
+    if (!n_tasks) return;
+    const uint32_t lds = ((max_tbl_entries * 2u) + 15u) & ~15u;
+    hipLaunchKernelGGL(k_huf_decode, dim3(n_tasks), dim3(64), lds, stream, src, tasks, copies, streams, pool, blk_base,
+                       out, lit, status);
+}
+
+void launch_lz_execute(hipStream_t stream, const SeqBlock *blocks, uint32_t n_blocks, const Seq *seqs,
+                       const uint8_t *lit, const uint64_t *blk_base, uint8_t *out, uint32_t *status) {
+    if (!n_blocks) return;
+    hipLaunchKernelGGL(k_lz_execute, dim3(1), dim3(256), 0, stream, blocks, n_blocks, seqs, lit, blk_base, out, status);
+}
+
+void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed, uint8_t *ascii, uint64_t n_bases,
+                    uint32_t t_char, uint32_t *status) {
+    if (!n_bases) return;
+    const uint64_t n_vec = n_bases / 32;
+    uint64_t blocks = (n_vec + 255) / 256;
+    if (blocks > 256u * 16u) blocks = 256u * 16u;      // grid-stride: 16 workgroups per CU
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_unpack4, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, packed, n_packed, ascii,
+                       n_bases, t_char, status);
+}
+
+void launch_mask_apply(hipStream_t stream, uint8_t *ascii, uint64_t n_bases, const uint64_t *mask_ends,
+                       const ScanTotals *mask_totals, const uint64_t *rec_ends, const ScanTotals *rec_totals,
+                       uint64_t max_runs, int spec_mask, uint32_t *status) {
+    if (!n_bases || !max_runs) return;
+    uint64_t waves = (max_runs + 1) / 2;
+    uint64_t blocks = (waves + 3) / 4;
+    if (blocks > 256u * 8u) blocks = 256u * 8u;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_mask_apply, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, ascii, n_bases, mask_ends,
+                       mask_totals, rec_ends, rec_totals, spec_mask, status);
+}
+
+void launch_hash64(hipStream_t stream, const uint8_t *p, uint64_t n, unsigned long long *result) {
+    if (!n) return;
+    uint64_t chunks = (n + kHashChunk - 1) / kHashChunk;
+    if (chunks > 256u * 32u) chunks = 256u * 32u;
+    hipLaunchKernelGGL(k_hash64, dim3(static_cast<uint32_t>(chunks)), dim3(256), 0, stream, p, n, result);
+}
+
+}  // namespace nafgpu

@@ -1,0 +1,83 @@
+// plan.h -- plain-data descriptors shared by the host front end (zplan.cpp) and the HIP
+// kernels (kernels.hip).  The host walks a section's Zstandard frame(s) ONCE, builds the
+// entropy tables per block, and hands the GPU flat task lists; nothing here owns memory.
+#pragma once
+#include <cstdint>
+
+namespace nafgpu {
+
+constexpr uint32_t kBlockMax = 128u << 10;   // zstd Block_Maximum_Size
+constexpr int kHufWave = 64;                 // one Huffman stream per lane, one wave per workgroup
+constexpr uint32_t kHufLdsEntries = 4096;    // u16 decode-table entries a wave task may stage in LDS
+constexpr uint32_t kSrcFrontPad = 256;       // bytes readable in front of any device source buffer
+constexpr uint32_t kSrcBackPad = 64;
+
+// One Huffman-coded literal stream = one lane of k_huf_decode.
+struct alignas(16) HufStream {
+    uint64_t src_end;    // offset one past the stream's last byte, from the section payload base
+    uint64_t dst;        // flags&1: absolute offset in the literal buffer; else offset inside block `blk`
+    uint32_t src_len;    // bytes in the stream (>= 1)
+    uint32_t n_syms;     // symbols to regenerate
+    uint32_t blk;        // zstd block index (for blk_base[])
+    uint16_t tbl_lds;    // first entry of this stream's table inside the task's LDS table area
+    uint8_t max_bits;    // table is 2^max_bits entries of (len << 8 | symbol)
+    uint8_t flags;       // bit0: write to the literal buffer (block has sequences)
+};
+static_assert(sizeof(HufStream) == 32, "HufStream layout");
+
+struct HufTblCopy {      // stage pool[pool_off .. +n_entries) at LDS entry lds_off
+    uint32_t pool_off, lds_off, n_entries, pad;
+};
+
+struct HufTask {         // one workgroup of k_huf_decode: <= 64 streams, tables <= kHufLdsEntries
+    uint32_t first_stream, n_streams, first_copy, n_copies;
+};
+
+struct CopyTask {        // Raw/RLE blocks and Raw/RLE literal sections
+    uint64_t src_off;    // payload offset of the first source byte (fill: the byte itself)
+    uint64_t dst;        // as HufStream::dst
+    uint32_t len;
+    uint32_t blk;
+    uint32_t flags;      // bit0: to literal buffer, bit1: fill with one byte (RLE)
+    uint32_t pad;
+};
+
+struct SeqCell {         // one FSE state of an LL / OF / ML table with its code->value baked in:
+    uint16_t next_base;  //   next state = next_base + read(nb)           (App. B "FSE table build")
+    uint8_t nb;
+    uint8_t extra_bits;  //   value = base_value + read(extra_bits)       (App. B "Code->value")
+    uint32_t base_value;
+};
+static_assert(sizeof(SeqCell) == 8, "SeqCell layout");
+
+struct SeqBlock {        // one compressed block with nbSeq > 0
+    uint64_t bits_off;   // payload offset of the sequence bitstream
+    uint64_t lit_off;    // absolute offset of this block's literals in the literal buffer
+    uint64_t seq_first;  // index of its first sequence in the sequence buffer
+    uint32_t bits_len;
+    uint32_t n_seq;
+    uint32_t ll_tbl, of_tbl, ml_tbl;   // SeqCell pool offsets
+    uint32_t blk;
+    uint32_t lit_size;
+    uint32_t frame_first_blk;          // first block of the frame this block belongs to
+    uint8_t ll_al, of_al, ml_al, pad;
+    uint32_t pad2;
+};
+static_assert(sizeof(SeqBlock) == 64, "SeqBlock layout");
+
+struct Seq {             // one decoded sequence (offset still in "offset_value" form)
+    uint32_t ll, ml, ofv;
+};
+
+// device status words
+enum : uint32_t {
+    kStOk = 0,
+    kStHufBadEnd = 1,      // Huffman stream did not end exactly at its start / no sentinel
+    kStSeqBadEnd = 2,      // sequence bitstream over/under-run, bad code
+    kStSeqLiterals = 3,    // sum of literal lengths exceeds the block's literals
+    kStBadOffset = 4,      // match offset reaches before the frame start
+    kStSizeMismatch = 5,   // decoded size != section original size / block too large
+    kStRunsOverflow = 6,
+};
+
+}  // namespace nafgpu

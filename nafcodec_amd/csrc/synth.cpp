@@ -1,0 +1,635 @@
+// synth.cpp -- synthetic NAF archive writer (host only).
+//
+// SURVEY.md section 8d needs 10-80 GB DNA archives that the reference's own Encoder cannot
+// produce fast enough (single-threaded, flushes per record, never writes a Mask section --
+// nafcodec/src/encoder/mod.rs:240,271,298,319).  This writer emits the same container
+// (layout per encoder/mod.rs:334-384: header, then (original_size, compressed_size, payload)
+// per section) with the sequence section as ONE magicless Zstandard frame of 128 KiB blocks
+// whose literals are 4-stream Huffman coded -- the shape `ennaf` / zstd level 1 give DNA
+// (1 Huffman + 127 treeless blocks, ~0 sequences).  Blocks are encoded in
+// parallel; the result depends only on (seed, n_bases, options), never on the thread count.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/nafgpu.h"
+#include "hash64.h"
+#include "plan.h"
+
+namespace {
+
+using nafgpu::kBlockMax;
+
+// ---------------------------------------------------------------- rng
+struct Rng {
+    uint64_t s;
+    explicit Rng(uint64_t seed) : s(seed) {}
+    uint64_t next() {                       // splitmix64
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    double uniform() { return (next() >> 11) * (1.0 / 9007199254740992.0); }
+};
+
+void put_varint(std::vector<uint8_t> &out, uint64_t v) {   // encoder/mod.rs:22-35
+    uint8_t tmp[10];
+    int k = 0;
+    tmp[k++] = v & 0x7F;
+    v >>= 7;
+    while (v) {
+        tmp[k++] = 0x80 | (v & 0x7F);
+        v >>= 7;
+    }
+    while (k) out.push_back(tmp[--k]);
+}
+
+// a section of raw zstd blocks (what masked.naf uses for its small sections)
+void raw_frame(const std::vector<uint8_t> &data, std::vector<uint8_t> &out) {
+    out.push_back(0x00);   // FHD: no content size, no checksum, no dictionary
+    out.push_back(0x48);   // window 512 KiB
+    size_t pos = 0;
+    do {
+        const size_t n = std::min<size_t>(kBlockMax, data.size() - pos);
+        const bool last = pos + n == data.size();
+        const uint32_t bh = static_cast<uint32_t>(n << 3) | (last ? 1u : 0u);
+        out.push_back(bh & 0xFF);
+        out.push_back((bh >> 8) & 0xFF);
+        out.push_back((bh >> 16) & 0xFF);
+        out.insert(out.end(), data.begin() + static_cast<long>(pos), data.begin() + static_cast<long>(pos + n));
+        pos += n;
+    } while (pos < data.size());
+}
+
+// ---------------------------------------------------------------- Huffman code construction
+inline int highbit(uint32_t v) { return 31 - __builtin_clz(v); }
+
+struct HufCode {
+    uint8_t len[256];       // 0 = symbol absent
+    uint16_t code[256];
+    uint8_t weight[256];
+    int max_bits = 0;
+    int max_sym = -1;
+    bool valid = false;
+};
+
+// code lengths limited to 11 bits (counts are halved until the tree is shallow enough)
+bool build_lengths(const uint32_t *count, uint8_t *len) {
+    uint32_t c[256];
+    int nsym = 0;
+    for (int s = 0; s < 256; s++) {
+        c[s] = count[s];
+        nsym += count[s] != 0;
+    }
+    if (nsym < 2) return false;
+    for (;;) {
+        // O(n^2) two-smallest merge: n <= 256 and this runs once per 128 KiB block
+        struct Node {
+            uint64_t w;
+            int parent;
+        };
+        Node nodes[512];
+        int alive[256], n_alive = 0, n_nodes = 0, leaf_of[256];
+        for (int s = 0; s < 256; s++)
+            if (c[s]) {
+                nodes[n_nodes] = {c[s], -1};
+                leaf_of[s] = n_nodes;
+                alive[n_alive++] = n_nodes++;
+            }
+        while (n_alive > 1) {
+            int a = 0, b = 1;
+            if (nodes[alive[b]].w < nodes[alive[a]].w) std::swap(a, b);
+            for (int k = 2; k < n_alive; k++) {
+                if (nodes[alive[k]].w < nodes[alive[a]].w) {
+                    b = a;
+                    a = k;
+                } else if (nodes[alive[k]].w < nodes[alive[b]].w) {
+                    b = k;
+                }
+            }
+            nodes[n_nodes] = {nodes[alive[a]].w + nodes[alive[b]].w, -1};
+            nodes[alive[a]].parent = n_nodes;
+            nodes[alive[b]].parent = n_nodes;
+            const int lo = std::min(a, b), hi = std::max(a, b);
+            alive[lo] = n_nodes++;
+            alive[hi] = alive[--n_alive];
+        }
+        int maxlen = 0;
+        for (int s = 0; s < 256; s++) {
+            len[s] = 0;
+            if (!c[s]) continue;
+            int d = 0;
+            for (int v = leaf_of[s]; nodes[v].parent >= 0; v = nodes[v].parent) d++;
+            len[s] = static_cast<uint8_t>(d);
+            maxlen = std::max(maxlen, d);
+        }
+        if (maxlen <= 11) return true;
+        for (int s = 0; s < 256; s++)
+            if (c[s]) c[s] = (c[s] + 1) / 2;
+    }
+}
+
+// canonical codes in the order the Zstandard decoder fills its table (App. B): weight 1 first,
+// ascending symbol inside a weight, each symbol spanning 2^(w-1) table entries
+void assign_codes(HufCode *h) {
+    int max_len = 0;
+    h->max_sym = -1;
+    for (int s = 0; s < 256; s++)
+        if (h->len[s]) {
+            max_len = std::max<int>(max_len, h->len[s]);
+            h->max_sym = s;
+        }
+    h->max_bits = max_len;
+    uint32_t pos = 0;
+    for (int s = 0; s < 256; s++) h->weight[s] = h->len[s] ? static_cast<uint8_t>(max_len + 1 - h->len[s]) : 0;
+    for (int w = 1; w <= max_len; w++)
+        for (int s = 0; s < 256; s++)
+            if (h->weight[s] == w) {
+                h->code[s] = static_cast<uint16_t>(pos >> (w - 1));
+                pos += 1u << (w - 1);
+            }
+    h->valid = pos == (1u << max_len);
+}
+
+// ---------------------------------------------------------------- FSE-compressed weights
+// Inverse of App. B "FSE table description" + the two-state weight stream.  Returns false if
+// the description does not fit the 127-byte limit (the caller then falls back to a raw block).
+struct FseDec {
+    int al;
+    uint8_t sym[64], nb[64];
+    uint16_t base[64];
+};
+
+bool fse_build_dec(const int16_t *norm, int nsym, int al, FseDec *t) {
+    const int S = 1 << al;
+    uint16_t next[16];
+    int high = S - 1;
+    t->al = al;
+    for (int s = 0; s < nsym; s++) {
+        if (norm[s] == -1) {
+            t->sym[high--] = static_cast<uint8_t>(s);
+            next[s] = 1;
+        } else {
+            next[s] = static_cast<uint16_t>(norm[s]);
+        }
+    }
+    const int step = (S >> 1) + (S >> 3) + 3, mask = S - 1;
+    int pos = 0;
+    for (int s = 0; s < nsym; s++)
+        for (int k = 0; k < norm[s]; k++) {
+            t->sym[pos] = static_cast<uint8_t>(s);
+            do pos = (pos + step) & mask;
+            while (pos > high);
+        }
+    if (pos != 0) return false;
+    for (int i = 0; i < S; i++) {
+        const uint16_t d = next[t->sym[i]]++;
+        const int nb = al - highbit(d);
+        t->nb[i] = static_cast<uint8_t>(nb);
+        t->base[i] = static_cast<uint16_t>((d << nb) - S);
+    }
+    return true;
+}
+
+struct BitSink {            // LSB-first writer
+    std::vector<uint8_t> bytes;
+    uint64_t acc = 0;
+    int n = 0;
+    void put(uint32_t v, int nb) {
+        acc |= static_cast<uint64_t>(v) << n;
+        n += nb;
+        while (n >= 8) {
+            bytes.push_back(acc & 0xFF);
+            acc >>= 8;
+            n -= 8;
+        }
+    }
+    void flush() {
+        if (n) bytes.push_back(acc & 0xFF);
+        acc = 0;
+        n = 0;
+    }
+};
+
+bool write_weights(const uint8_t *w, int nw, std::vector<uint8_t> &out) {
+    // nw = number of explicit weights (the last symbol's weight is implied)
+    if (nw < 2 || nw > 255) return false;
+    int cnt[13] = {0}, max_w = 0;
+    for (int i = 0; i < nw; i++) {
+        cnt[w[i]]++;
+        max_w = std::max<int>(max_w, w[i]);
+    }
+    for (int s = 0; s <= max_w; s++)
+        if (cnt[s] == nw) return false;              // a single distinct weight: FSE cannot code it
+    const int al = 6, S = 1 << al;
+    // normalise: every present weight gets >= 1 slot, the rest proportionally, remainder to the largest
+    int16_t norm[13];
+    int total = 0, largest = 0;
+    for (int s = 0; s <= max_w; s++) {
+        norm[s] = 0;
+        if (!cnt[s]) continue;
+        int v = static_cast<int>((static_cast<int64_t>(cnt[s]) * S) / nw);
+        if (v < 1) v = 1;
+        norm[s] = static_cast<int16_t>(v);
+        total += v;
+        if (cnt[s] > cnt[largest] || !cnt[largest]) largest = s;
+    }
+    norm[largest] = static_cast<int16_t>(norm[largest] + (S - total));
+    if (norm[largest] < 1) return false;
+    if (norm[largest] >= S) return false;            // a probability of 1 leaves zero-bit states everywhere
+    const int nsym = max_w + 1;
+    FseDec t;
+    if (!fse_build_dec(norm, nsym, al, &t)) return false;
+    // ---- table description
+    BitSink hdr;
+    hdr.put(static_cast<uint32_t>(al - 5), 4);
+    int remaining = S;
+    for (int s = 0; s < nsym && remaining > 0;) {
+        const int max = remaining + 1;
+        const int bits = highbit(static_cast<uint32_t>(max)) + 1;
+        const uint32_t low = (1u << (bits - 1)) - 1;
+        const uint32_t thr = (1u << bits) - 1 - static_cast<uint32_t>(max);
+        const uint32_t v = static_cast<uint32_t>(norm[s] + 1);
+        if (v < thr)
+            hdr.put(v, bits - 1);
+        else
+            hdr.put(v <= low ? v : v + thr, bits);
+        remaining -= norm[s];
+        const bool zero = norm[s] == 0;
+        s++;
+        if (zero) {
+            int z = 0;
+            while (s + z < nsym && norm[s + z] == 0) z++;
+            s += z;
+            while (z >= 3) {
+                hdr.put(3, 2);
+                z -= 3;
+            }
+            hdr.put(static_cast<uint32_t>(z), 2);
+        }
+    }
+    if (remaining != 0) return false;
+    hdr.flush();
+    // ---- weight stream, two interleaved states (even indices on state 1, odd on state 2)
+    auto pick = [&](int sym, int want_state) -> int {        // a state of `sym`; want_state<0: most bits
+        int best = -1;
+        for (int i = 0; i < S; i++) {
+            if (t.sym[i] != sym) continue;
+            if (want_state >= 0) {
+                if (t.base[i] <= want_state && want_state < t.base[i] + (1 << t.nb[i])) return i;
+            } else if (best < 0 || t.nb[i] > t.nb[best]) {
+                best = i;
+            }
+        }
+        return best;
+    };
+    int state[2];
+    state[(nw - 1) & 1] = pick(w[nw - 1], -1);
+    state[(nw - 2) & 1] = pick(w[nw - 2], -1);
+    if (state[0] < 0 || state[1] < 0 || t.nb[state[(nw - 2) & 1]] == 0) return false;
+    std::vector<std::pair<uint32_t, int>> upd(static_cast<size_t>(std::max(0, nw - 2)));   // update bits of symbol k
+    for (int k = nw - 3; k >= 0; k--) {
+        const int p = k & 1;
+        const int i = pick(w[k], state[p]);
+        if (i < 0) return false;
+        upd[static_cast<size_t>(k)] = {static_cast<uint32_t>(state[p] - t.base[i]), t.nb[i]};
+        state[p] = i;
+    }
+    // read order: s1, s2, upd[0], upd[1], ... ; first-read field sits right below the end mark
+    int total_bits = 2 * al;
+    for (auto &u : upd) total_bits += u.second;
+    std::vector<uint8_t> stream(static_cast<size_t>(total_bits / 8 + 1), 0);
+    int pos = total_bits;
+    auto place = [&](uint32_t v, int nb) {
+        pos -= nb;
+        for (int b = 0; b < nb; b++)
+            if ((v >> b) & 1) stream[static_cast<size_t>((pos + b) >> 3)] |= static_cast<uint8_t>(1u << ((pos + b) & 7));
+    };
+    place(static_cast<uint32_t>(state[0]), al);
+    place(static_cast<uint32_t>(state[1]), al);
+    for (auto &u : upd) place(u.first, u.second);
+    stream[static_cast<size_t>(total_bits >> 3)] |= static_cast<uint8_t>(1u << (total_bits & 7));   // end mark
+    const size_t csize = hdr.bytes.size() + stream.size();
+    if (csize >= 128) return false;
+    out.push_back(static_cast<uint8_t>(csize));
+    out.insert(out.end(), hdr.bytes.begin(), hdr.bytes.end());
+    out.insert(out.end(), stream.begin(), stream.end());
+    return true;
+}
+
+// ---------------------------------------------------------------- one compressed block
+void encode_stream(const HufCode &h, const uint8_t *sym, size_t n, std::vector<uint8_t> &out) {
+    uint64_t acc = 0;
+    int nbits = 0;
+    for (size_t i = n; i-- > 0;) {             // last symbol first: it is read last (backward stream)
+        acc |= static_cast<uint64_t>(h.code[sym[i]]) << nbits;
+        nbits += h.len[sym[i]];
+        while (nbits >= 8) {
+            out.push_back(acc & 0xFF);
+            acc >>= 8;
+            nbits -= 8;
+        }
+    }
+    acc |= 1ull << nbits;                      // end mark
+    out.push_back(acc & 0xFF);
+}
+
+// Appends one zstd block (header included) holding `n` literal bytes and no sequences.
+// `prev` is the table of the previous block in the same chunk (treeless reuse) and is updated.
+void encode_block(const uint8_t *data, size_t n, bool last, HufCode *prev, std::vector<uint8_t> &out) {
+    auto raw_block = [&]() {
+        const uint32_t bh = static_cast<uint32_t>(n << 3) | (last ? 1u : 0u);
+        out.push_back(bh & 0xFF);
+        out.push_back((bh >> 8) & 0xFF);
+        out.push_back((bh >> 16) & 0xFF);
+        out.insert(out.end(), data, data + n);
+    };
+    if (n < 64) return raw_block();
+    uint32_t count[256] = {0};
+    for (size_t i = 0; i < n; i++) count[data[i]]++;
+    HufCode cur{};
+    std::vector<uint8_t> tree;
+    bool have_new = build_lengths(count, cur.len);
+    if (have_new) {
+        assign_codes(&cur);
+        have_new = cur.valid && write_weights(cur.weight, cur.max_sym, tree);   // weights of symbols 0..max_sym-1
+    }
+    uint64_t cost_new = UINT64_MAX, cost_old = UINT64_MAX;
+    if (have_new) {
+        cost_new = tree.size() * 8;
+        for (int s = 0; s < 256; s++) cost_new += static_cast<uint64_t>(count[s]) * cur.len[s];
+    }
+    if (prev->valid) {
+        cost_old = 0;
+        for (int s = 0; s < 256; s++) {
+            if (!count[s]) continue;
+            if (!prev->len[s]) {
+                cost_old = UINT64_MAX;
+                break;
+            }
+            cost_old += static_cast<uint64_t>(count[s]) * prev->len[s];
+        }
+    }
+    if (cost_new == UINT64_MAX && cost_old == UINT64_MAX) return raw_block();
+    const bool treeless = cost_old <= cost_new;
+    const HufCode &h = treeless ? *prev : cur;
+    std::vector<uint8_t> body;                                   // tree + jump table + streams
+    if (!treeless) body = tree;
+    const size_t q = (n + 3) / 4;
+    std::vector<uint8_t> st[4];
+    encode_stream(h, data, q, st[0]);
+    encode_stream(h, data + q, q, st[1]);
+    encode_stream(h, data + 2 * q, q, st[2]);
+    encode_stream(h, data + 3 * q, n - 3 * q, st[3]);
+    for (int k = 0; k < 3; k++) {
+        if (st[k].size() > 0xFFFF) return raw_block();
+        body.push_back(st[k].size() & 0xFF);
+        body.push_back(static_cast<uint8_t>(st[k].size() >> 8));
+    }
+    for (int k = 0; k < 4; k++) body.insert(body.end(), st[k].begin(), st[k].end());
+    const size_t comp = body.size();
+    // literals header: 4 streams, size format by magnitude
+    uint8_t lh[5];
+    size_t lhn;
+    const uint32_t type = treeless ? 3u : 2u;
+    if (n <= 1023 && comp <= 1023) {
+        const uint32_t v = type | (1u << 2) | (static_cast<uint32_t>(n) << 4) | (static_cast<uint32_t>(comp) << 14);
+        lh[0] = v & 0xFF; lh[1] = (v >> 8) & 0xFF; lh[2] = (v >> 16) & 0xFF;
+        lhn = 3;
+    } else if (n <= 16383 && comp <= 16383) {
+        const uint32_t v = type | (2u << 2) | (static_cast<uint32_t>(n) << 4) | (static_cast<uint32_t>(comp) << 18);
+        lh[0] = v & 0xFF; lh[1] = (v >> 8) & 0xFF; lh[2] = (v >> 16) & 0xFF; lh[3] = (v >> 24) & 0xFF;
+        lhn = 4;
+    } else {
+        const uint64_t v = type | (3u << 2) | (static_cast<uint64_t>(n) << 4) | (static_cast<uint64_t>(comp) << 22);
+        for (int k = 0; k < 5; k++) lh[k] = (v >> (8 * k)) & 0xFF;
+        lhn = 5;
+    }
+    const size_t bsize = lhn + comp + 1;                         // + "0 sequences" byte
+    if (bsize >= n || bsize > kBlockMax) return raw_block();
+    const uint32_t bh = static_cast<uint32_t>(bsize << 3) | (2u << 1) | (last ? 1u : 0u);
+    out.push_back(bh & 0xFF);
+    out.push_back((bh >> 8) & 0xFF);
+    out.push_back((bh >> 16) & 0xFF);
+    out.insert(out.end(), lh, lh + lhn);
+    out.insert(out.end(), body.begin(), body.end());
+    out.push_back(0x00);                                         // Number_of_Sequences = 0
+    if (!treeless) *prev = cur;
+}
+
+// ---------------------------------------------------------------- the archive
+constexpr size_t kChunkBlocks = 64;     // blocks encoded as one unit (first block carries a fresh table)
+
+struct MaskRun {
+    uint64_t start, end;                // masked interval in base coordinates
+};
+
+void fill_block(uint8_t *dst, size_t n, uint64_t seed, uint64_t block_index, uint32_t iupac_permille) {
+    Rng r(seed ^ (0xD1B54A32D192ED03ull * (block_index + 1)));
+    size_t i = 0;
+    while (i < n) {
+        uint64_t x = r.next();
+        for (int k = 0; k < 16 && i < n; k++, x >>= 4) {
+            const uint32_t lo = 1u << (x & 3), hi = 1u << ((x >> 2) & 3);     // A=8 C=4 G=2 T=1
+            dst[i++] = static_cast<uint8_t>(lo | (hi << 4));
+        }
+    }
+    if (iupac_permille) {
+        static const uint8_t kExtra[8] = {15, 15, 15, 15, 10, 5, 9, 6};      // N N N N R Y W S
+        const size_t hits = (2 * n * iupac_permille) / 1000;
+        for (size_t h = 0; h < hits; h++) {
+            const uint64_t x = r.next();
+            const size_t nib = static_cast<size_t>(x % (2 * n));
+            const uint8_t code = kExtra[(x >> 40) & 7];
+            uint8_t &b = dst[nib >> 1];
+            b = (nib & 1) ? static_cast<uint8_t>((b & 0x0F) | (code << 4)) : static_cast<uint8_t>((b & 0xF0) | code);
+        }
+    }
+}
+
+const char kLut[17] = "-TGKCYSBAWRDMHVN";
+
+}  // namespace
+
+extern "C" int nafgpu_synth_write(const nafgpu_synth_spec *spec, nafgpu_synth_archive *out) {
+    if (!spec || !out || spec->n_bases == 0) return NAFGPU_E_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    const uint64_t n_bases = spec->n_bases;
+    const uint64_t n_packed = (n_bases + 1) / 2;
+    Rng rng(spec->seed * 0x9E3779B97F4A7C15ull + 0x4E4146);
+
+    // ---- record lengths: half fixed 151, half log-uniform in [1e3, 1e7]
+    std::vector<uint64_t> rec_end;
+    {
+        uint64_t pos = 0;
+        while (pos < n_bases) {
+            uint64_t len;
+            if (rng.next() & 1) {
+                len = 151;
+            } else {
+                len = static_cast<uint64_t>(std::floor(1000.0 * std::pow(10000.0, rng.uniform())));
+                len = std::min<uint64_t>(std::max<uint64_t>(len, 1000), 10000000);
+            }
+            len = std::min(len, n_bases - pos);
+            pos += len;
+            rec_end.push_back(pos);
+        }
+    }
+    const uint64_t n_rec = rec_end.size();
+    std::vector<uint8_t> len_bytes;
+    len_bytes.reserve(n_rec * 4);
+    for (uint64_t k = 0; k < n_rec; k++) {
+        const uint64_t l = rec_end[k] - (k ? rec_end[k - 1] : 0);
+        const uint32_t w = static_cast<uint32_t>(l);               // < 2^32 - 1 by construction
+        for (int b = 0; b < 4; b++) len_bytes.push_back((w >> (8 * b)) & 0xFF);
+    }
+
+    // ---- mask runs: unmasked ~Geom(3000), masked ~Geom(600), masked runs strictly inside records
+    std::vector<MaskRun> runs;
+    std::vector<uint8_t> mask_bytes;
+    if (spec->with_mask) {
+        auto put_run = [&](uint64_t n) {
+            while (n >= 255) {
+                mask_bytes.push_back(0xFF);
+                n -= 255;
+            }
+            mask_bytes.push_back(static_cast<uint8_t>(n));
+        };
+        uint64_t pos = 0, rec = 0, forced = 0;
+        while (pos < n_bases) {
+            auto geom = [&](double mean) {
+                const double u = std::max(rng.uniform(), 1e-12);
+                return static_cast<uint64_t>(1 + std::floor(-std::log(u) * mean));
+            };
+            uint64_t un = geom(3000.0), mk = geom(600.0);
+            if (forced == 3) { un = 255; }                         // run of exactly 255: FF 00
+            if (forced == 5) { mk = 255; }
+            if (forced == 7) { un = 70000; }                       // run longer than 65 535
+            forced++;
+            uint64_t s = std::min(pos + un, n_bases);
+            while (rec < n_rec && rec_end[rec] <= s) rec++;        // record holding base s
+            if (s >= n_bases || rec >= n_rec) {
+                put_run(n_bases - pos);                            // trailing unmasked run
+                pos = n_bases;
+                break;
+            }
+            // keep [s, e) strictly inside the record: e < record end
+            uint64_t e = std::min(s + mk, rec_end[rec] - 1);
+            if (e <= s) {                                          // no room: extend the unmasked run past the record
+                s = std::min<uint64_t>(rec_end[rec] + 1, n_bases);
+                put_run(s - pos);
+                put_run(0);                                        // empty masked run keeps the alternation
+                pos = s;
+                continue;
+            }
+            put_run(s - pos);
+            put_run(e - s);
+            runs.push_back({s, e});
+            pos = e;
+        }
+    }
+
+    // ---- sequence section: blocks in parallel, chunks of kChunkBlocks
+    const uint64_t n_blocks = (n_packed + kBlockMax - 1) / kBlockMax;
+    const uint64_t n_chunks = (n_blocks + kChunkBlocks - 1) / kChunkBlocks;
+    std::vector<std::vector<uint8_t>> chunk_out(n_chunks);
+    std::vector<uint64_t> chunk_hash(n_chunks, 0);
+    std::atomic<uint64_t> next_chunk{0};
+    unsigned n_threads = spec->threads ? spec->threads : std::max(1u, std::thread::hardware_concurrency());
+    n_threads = static_cast<unsigned>(std::min<uint64_t>(n_threads, n_chunks));
+    auto worker = [&]() {
+        std::vector<uint8_t> packed(kBlockMax), ascii(2 * kBlockMax);
+        for (;;) {
+            const uint64_t c = next_chunk.fetch_add(1);
+            if (c >= n_chunks) break;
+            HufCode prev{};
+            std::vector<uint8_t> &o = chunk_out[c];
+            o.reserve(kChunkBlocks * (kBlockMax / 2 + 64));
+            uint64_t h = 0;
+            for (uint64_t b = c * kChunkBlocks; b < std::min(n_blocks, (c + 1) * kChunkBlocks); b++) {
+                const uint64_t p0 = b * kBlockMax;
+                const size_t n = static_cast<size_t>(std::min<uint64_t>(kBlockMax, n_packed - p0));
+                fill_block(packed.data(), n, spec->seed, b, spec->iupac_permille);
+                if (b == n_blocks - 1 && (n_bases & 1)) packed[n - 1] &= 0x0F;   // pad nibble (writer.rs:21-28)
+                encode_block(packed.data(), n, b == n_blocks - 1, &prev, o);
+                // expected ASCII of this block (for the checksum): unpack, then lower-case masked runs
+                const uint64_t b0 = 2 * p0, b1 = std::min<uint64_t>(n_bases, b0 + 2 * n);
+                for (size_t i = 0; i < n; i++) {
+                    ascii[2 * i] = static_cast<uint8_t>(kLut[packed[i] & 15]);
+                    ascii[2 * i + 1] = static_cast<uint8_t>(kLut[packed[i] >> 4]);
+                }
+                if (!runs.empty()) {
+                    auto it = std::lower_bound(runs.begin(), runs.end(), b0,
+                                               [](const MaskRun &r, uint64_t v) { return r.end <= v; });
+                    for (; it != runs.end() && it->start < b1; ++it) {
+                        const uint64_t s = std::max(it->start, b0), e = std::min(it->end, b1);
+                        for (uint64_t k = s; k < e; k++) {
+                            uint8_t &ch = ascii[static_cast<size_t>(k - b0)];
+                            if (ch >= 'A' && ch <= 'Z') ch |= 0x20;
+                        }
+                    }
+                }
+                h += nafgpu::hash64_host(ascii.data(), b1 - b0, b0 / nafgpu::kHashChunk);
+            }
+            chunk_hash[c] = h;
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < n_threads; t++) pool.emplace_back(worker);
+        worker();
+        for (auto &t : pool) t.join();
+    }
+    uint64_t seq_csize = 2;
+    for (auto &c : chunk_out) seq_csize += c.size();
+
+    // ---- assemble (encoder/mod.rs:334-384): header, then Length, [Mask], Sequence
+    std::vector<uint8_t> head;
+    head.insert(head.end(), {0x01, 0xF9, 0xEC, 0x01});                       // magic, format version 1 (DNA)
+    head.push_back(static_cast<uint8_t>(0x08 | 0x02 | (spec->with_mask ? 0x04 : 0)));
+    head.push_back(' ');
+    put_varint(head, 60);
+    put_varint(head, n_rec);
+    std::vector<uint8_t> len_frame, mask_frame;
+    raw_frame(len_bytes, len_frame);
+    put_varint(head, len_bytes.size());
+    put_varint(head, len_frame.size());
+    head.insert(head.end(), len_frame.begin(), len_frame.end());
+    if (spec->with_mask) {
+        raw_frame(mask_bytes, mask_frame);
+        put_varint(head, mask_bytes.size());
+        put_varint(head, mask_frame.size());
+        head.insert(head.end(), mask_frame.begin(), mask_frame.end());
+    }
+    put_varint(head, n_bases);                                               // nucleotides, not bytes (mod.rs:241)
+    put_varint(head, seq_csize);
+    const uint64_t total = head.size() + seq_csize;
+    uint8_t *buf = static_cast<uint8_t *>(std::malloc(total));
+    if (!buf) return NAFGPU_E_DEVICE;
+    std::memcpy(buf, head.data(), head.size());
+    uint64_t pos = head.size();
+    buf[pos++] = 0x00;                                                       // FHD
+    buf[pos++] = 0x48;                                                       // window 512 KiB
+    for (auto &c : chunk_out) {
+        std::memcpy(buf + pos, c.data(), c.size());
+        pos += c.size();
+        std::vector<uint8_t>().swap(c);
+    }
+    out->bytes = buf;
+    out->n = total;
+    out->n_records = n_rec;
+    out->n_bases = n_bases;
+    for (uint64_t h : chunk_hash) out->seq_hash += h;
+    out->offsets_hash = nafgpu::hash64_host(reinterpret_cast<const uint8_t *>(rec_end.data()), n_rec * 8);
+    return NAFGPU_OK;
+}
+
+extern "C" void nafgpu_synth_free(nafgpu_synth_archive *a) {
+    if (a && a->bytes) std::free(a->bytes);
+    if (a) std::memset(a, 0, sizeof *a);
+}

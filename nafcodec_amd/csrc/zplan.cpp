@@ -1,0 +1,700 @@
+// zplan.cpp -- see zplan.h.  Host-side frame walk + table build, once per block.
+#include "zplan.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace nafgpu {
+namespace {
+
+struct Fail {
+    std::string msg;
+    bool truncated = false;
+};
+
+inline int highbit(uint32_t v) { return 31 - __builtin_clz(v); }
+
+// ---------------------------------------------------------------- bit readers
+struct FwdBits {            // LSB-first, used by FSE table descriptions
+    const uint8_t *p;
+    size_t n;
+    size_t bit = 0;
+    uint32_t peek(int nb) const {
+        uint64_t v = 0;
+        size_t byte = bit >> 3;
+        size_t avail = byte < n ? std::min<size_t>(8, n - byte) : 0;
+        std::memcpy(&v, p + byte, avail);
+        return static_cast<uint32_t>((v >> (bit & 7)) & ((1ull << nb) - 1));
+    }
+};
+
+struct BackBits {           // MSB-first from the end; only the tiny Huffman-weight streams use it here
+    const uint8_t *p = nullptr;
+    size_t n = 0;
+    int64_t pos = 0;        // unread bits below the cursor
+    bool init(const uint8_t *src, size_t len) {
+        if (len == 0 || src[len - 1] == 0) return false;
+        p = src;
+        n = len;
+        pos = static_cast<int64_t>(len - 1) * 8 + highbit(src[len - 1]);
+        return true;
+    }
+    uint32_t read(int nb) {
+        pos -= nb;
+        uint32_t v = 0;
+        for (int k = nb - 1; k >= 0; k--) {         // weight streams are <= 127 bytes: bitwise is fine
+            int64_t b = pos + k;
+            uint32_t bit = b >= 0 ? (p[b >> 3] >> (b & 7)) & 1u : 0u;
+            v = (v << 1) | bit;
+        }
+        return v;
+    }
+};
+
+// ---------------------------------------------------------------- FSE
+// App. B "FSE table description".  Returns bytes consumed, or -1.
+long read_fse_dist(const uint8_t *src, size_t n, int max_al, int max_sym, int16_t *norm, int *nsym, int *al_out,
+                   Fail &f) {
+    if (n == 0) {
+        f = {"FSE table description is empty", true};
+        return -1;
+    }
+    FwdBits b{src, n};
+    int al = static_cast<int>(b.peek(4)) + 5;
+    b.bit += 4;
+    if (al > max_al) {
+        f.msg = "FSE accuracy log too large";
+        return -1;
+    }
+    int remaining = 1 << al, sym = 0;
+    while (remaining > 0 && sym <= max_sym) {
+        int max = remaining + 1;
+        int bits = highbit(static_cast<uint32_t>(max)) + 1;
+        uint32_t v = b.peek(bits);
+        uint32_t low = (1u << (bits - 1)) - 1;
+        uint32_t thr = (1u << bits) - 1 - static_cast<uint32_t>(max);
+        if ((v & low) < thr) {
+            b.bit += bits - 1;
+            v &= low;
+        } else {
+            b.bit += bits;
+            if (v > low) v -= thr;
+        }
+        int p = static_cast<int>(v) - 1;
+        norm[sym++] = static_cast<int16_t>(p);
+        remaining -= p < 0 ? -p : p;
+        if (p == 0) {
+            for (;;) {
+                uint32_t rep = b.peek(2);
+                b.bit += 2;
+                for (uint32_t k = 0; k < rep && sym <= max_sym; k++) norm[sym++] = 0;
+                if (rep != 3) break;
+            }
+        }
+        if ((b.bit >> 3) > n) {
+            f = {"FSE table description runs past its section", true};
+            return -1;
+        }
+    }
+    if (remaining != 0) {
+        f.msg = "FSE probabilities do not sum to the table size";
+        return -1;
+    }
+    size_t used = (b.bit + 7) >> 3;
+    if (used > n) {
+        f = {"FSE table description runs past its section", true};
+        return -1;
+    }
+    *nsym = sym;
+    *al_out = al;
+    return static_cast<long>(used);
+}
+
+struct FseStates {          // generic decode table: parallel arrays of 1 << al states
+    int al = 0;
+    uint8_t sym[512];
+    uint8_t nb[512];
+    uint16_t base[512];
+};
+
+// App. B "FSE table build"
+bool build_fse(const int16_t *norm, int nsym, int al, FseStates *t) {
+    const int S = 1 << al;
+    uint16_t next[256];
+    int high = S - 1;
+    t->al = al;
+    for (int s = 0; s < nsym; s++) {
+        if (norm[s] == -1) {
+            t->sym[high--] = static_cast<uint8_t>(s);
+            next[s] = 1;
+        } else {
+            next[s] = static_cast<uint16_t>(norm[s]);
+        }
+    }
+    const int step = (S >> 1) + (S >> 3) + 3, mask = S - 1;
+    int pos = 0;
+    for (int s = 0; s < nsym; s++)
+        for (int k = 0; k < norm[s]; k++) {
+            t->sym[pos] = static_cast<uint8_t>(s);
+            do pos = (pos + step) & mask;
+            while (pos > high);
+        }
+    if (pos != 0) return false;
+    for (int i = 0; i < S; i++) {
+        uint16_t d = next[t->sym[i]]++;
+        int nb = al - highbit(d);
+        t->nb[i] = static_cast<uint8_t>(nb);
+        t->base[i] = static_cast<uint16_t>((d << nb) - S);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- sequence code tables (App. B)
+const int16_t kLLDefault[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
+                                2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+const int16_t kMLDefault[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+const int16_t kOFDefault[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+const uint32_t kLLBase[36] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,   10,  11,  12,   13,   14,   15,   16,    18,
+                              20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
+const uint8_t kLLBits[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                             1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+const uint32_t kMLBase[53] = {3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15,  16,  17,  18,   19,   20,
+                              21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33,  34,  35,  37,   39,   41,
+                              43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539};
+const uint8_t kMLBits[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                             0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+
+enum SeqKind { kLL = 0, kOF = 1, kML = 2 };
+struct KindInfo {
+    const int16_t *def;
+    int def_n, def_al, max_al, max_sym;
+};
+const KindInfo kKinds[3] = {{kLLDefault, 36, 6, 9, 35}, {kOFDefault, 29, 5, 8, 31}, {kMLDefault, 53, 6, 9, 52}};
+
+bool bake_cell(SeqKind kind, uint8_t code, SeqCell *c) {
+    switch (kind) {
+    case kLL:
+        if (code > 35) return false;
+        c->base_value = kLLBase[code];
+        c->extra_bits = kLLBits[code];
+        return true;
+    case kML:
+        if (code > 52) return false;
+        c->base_value = kMLBase[code];
+        c->extra_bits = kMLBits[code];
+        return true;
+    default:
+        if (code > 31) return false;
+        c->base_value = 1u << code;
+        c->extra_bits = code;
+        return true;
+    }
+}
+
+struct TableRef {
+    uint32_t off = 0;
+    uint8_t al = 0;
+    bool valid = false;
+};
+
+bool append_seq_table(ZPlan *plan, SeqKind kind, const FseStates &t, TableRef *ref) {
+    const int S = 1 << t.al;
+    ref->off = static_cast<uint32_t>(plan->fse_pool.size());
+    ref->al = static_cast<uint8_t>(t.al);
+    for (int i = 0; i < S; i++) {
+        SeqCell c{};
+        c.next_base = t.base[i];
+        c.nb = t.nb[i];
+        if (!bake_cell(kind, t.sym[i], &c)) return false;
+        plan->fse_pool.push_back(c);
+    }
+    ref->valid = true;
+    return true;
+}
+
+// ---------------------------------------------------------------- Huffman (App. B "Huffman tree description")
+struct HufRef {
+    uint32_t pool_off = 0;
+    uint8_t max_bits = 0;
+    bool valid = false;
+};
+
+// Parses the tree description at src, appends the 2^max_bits decode table to the pool.
+long read_huf_table(const uint8_t *src, size_t n, ZPlan *plan, HufRef *ref, Fail &f) {
+    uint8_t w[258];
+    int nw = 0;
+    if (n < 1) {
+        f = {"Huffman tree description is empty", true};
+        return -1;
+    }
+    const int hb = src[0];
+    size_t used;
+    if (hb >= 128) {                                  // direct 4-bit weights, high nibble first
+        nw = hb - 127;
+        size_t bytes = static_cast<size_t>(nw + 1) / 2;
+        if (1 + bytes > n) {
+            f = {"Huffman weights run past the literals section", true};
+            return -1;
+        }
+        for (int i = 0; i < nw; i++) {
+            uint8_t b = src[1 + i / 2];
+            w[i] = (i & 1) ? (b & 0xF) : (b >> 4);
+        }
+        used = 1 + bytes;
+    } else {                                          // FSE-compressed weights, two interleaved states
+        if (hb == 0 || static_cast<size_t>(hb) + 1 > n) {
+            f = {"Huffman weights run past the literals section", hb != 0};
+            return -1;
+        }
+        int16_t norm[256];
+        int nsym = 0, al = 0;
+        long r = read_fse_dist(src + 1, static_cast<size_t>(hb), 6, 255, norm, &nsym, &al, f);
+        if (r < 0) return -1;
+        FseStates t;
+        if (!build_fse(norm, nsym, al, &t)) {
+            f.msg = "bad FSE table for Huffman weights";
+            return -1;
+        }
+        BackBits b;
+        if (!b.init(src + 1 + r, static_cast<size_t>(hb) - static_cast<size_t>(r))) {
+            f.msg = "Huffman weight stream has no end mark";
+            return -1;
+        }
+        uint32_t s1 = b.read(al), s2 = b.read(al);
+        for (;;) {
+            if (nw >= 255) break;
+            w[nw++] = t.sym[s1];
+            if (b.pos < static_cast<int64_t>(t.nb[s1])) {       // stream exhausted: flush the other state
+                w[nw++] = t.sym[s2];
+                break;
+            }
+            s1 = t.base[s1] + b.read(t.nb[s1]);
+            if (nw >= 255) break;
+            w[nw++] = t.sym[s2];
+            if (b.pos < static_cast<int64_t>(t.nb[s2])) {
+                w[nw++] = t.sym[s1];
+                break;
+            }
+            s2 = t.base[s2] + b.read(t.nb[s2]);
+        }
+        used = 1 + static_cast<size_t>(hb);
+    }
+    if (nw > 255) {
+        f.msg = "too many Huffman weights";
+        return -1;
+    }
+    uint32_t total = 0;
+    for (int i = 0; i < nw; i++) {
+        if (w[i] > 11) {
+            f.msg = "Huffman weight above 11";
+            return -1;
+        }
+        if (w[i]) total += 1u << (w[i] - 1);
+    }
+    if (total == 0) {
+        f.msg = "all Huffman weights are zero";
+        return -1;
+    }
+    const int max_bits = highbit(total) + 1;
+    const uint32_t left = (1u << max_bits) - total;
+    if (max_bits > 11 || (left & (left - 1))) {
+        f.msg = "Huffman weights do not complete a tree";
+        return -1;
+    }
+    w[nw++] = static_cast<uint8_t>(highbit(left) + 1);
+    // table fill: weight 1 (longest codes) first, ascending symbol within a weight
+    const uint32_t size = 1u << max_bits;
+    ref->pool_off = static_cast<uint32_t>(plan->huf_pool.size());
+    ref->max_bits = static_cast<uint8_t>(max_bits);
+    ref->valid = true;
+    plan->huf_pool.resize(plan->huf_pool.size() + size);
+    uint16_t *tbl = plan->huf_pool.data() + ref->pool_off;
+    uint32_t pos = 0;
+    for (int wt = 1; wt <= max_bits; wt++) {
+        const uint32_t span = 1u << (wt - 1);
+        const uint16_t len = static_cast<uint16_t>((max_bits + 1 - wt) << 8);
+        for (int s = 0; s < nw; s++) {
+            if (w[s] != wt) continue;
+            if (pos + span > size) {
+                f.msg = "Huffman table overflow";
+                return -1;
+            }
+            for (uint32_t k = 0; k < span; k++) tbl[pos + k] = static_cast<uint16_t>(len | s);
+            pos += span;
+        }
+    }
+    if (pos != size) {
+        f.msg = "Huffman table underflow";
+        return -1;
+    }
+    plan->n_huf_tables++;
+    return static_cast<long>(used);
+}
+
+// ---------------------------------------------------------------- the walk
+struct Walker {
+    const uint8_t *p;
+    size_t n;
+    ZPlan *plan;
+    Fail fail;
+    std::vector<HufRef> stream_tbl;      // table of each emitted stream, for task packing
+    TableRef predefined[3];
+
+    bool need(size_t at, size_t k, const char *what) {
+        if (at > n || k > n - at) {
+            fail = {std::string("payload ends inside ") + what, true};
+            return false;
+        }
+        return true;
+    }
+    bool bad(const char *what) {
+        fail.msg = what;
+        return false;
+    }
+
+    bool seq_table(SeqKind kind, int mode, size_t &i, size_t end, TableRef *cur) {
+        const KindInfo &ki = kKinds[kind];
+        switch (mode) {
+        case 0: {                                                // Predefined
+            if (!predefined[kind].valid) {
+                FseStates t;
+                if (!build_fse(ki.def, ki.def_n, ki.def_al, &t)) return bad("internal: predefined table");
+                if (!append_seq_table(plan, kind, t, &predefined[kind])) return bad("internal: predefined table");
+            }
+            *cur = predefined[kind];
+            return true;
+        }
+        case 1: {                                                // RLE: one state, zero bits
+            if (i >= end) {
+                fail = {"payload ends inside a sequences header", false};
+                return false;
+            }
+            SeqCell c{};
+            if (!bake_cell(kind, p[i], &c)) return bad("RLE sequence code out of range");
+            cur->off = static_cast<uint32_t>(plan->fse_pool.size());
+            cur->al = 0;
+            cur->valid = true;
+            plan->fse_pool.push_back(c);
+            i += 1;
+            return true;
+        }
+        case 2: {                                                // FSE description
+            int16_t norm[256];
+            int nsym = 0, al = 0;
+            long r = read_fse_dist(p + i, end - i, ki.max_al, ki.max_sym, norm, &nsym, &al, fail);
+            if (r < 0) {
+                fail.truncated = false;                          // inside a complete block: corrupt, not short
+                return false;
+            }
+            FseStates t;
+            if (!build_fse(norm, nsym, al, &t)) return bad("bad FSE table in a sequences section");
+            if (!append_seq_table(plan, kind, t, cur)) return bad("sequence code out of range");
+            i += static_cast<size_t>(r);
+            return true;
+        }
+        default:                                                 // Repeat
+            if (!cur->valid) return bad("repeat mode without a previous table");
+            return true;
+        }
+    }
+
+    // one Compressed block occupying [i, end)
+    bool compressed_block(size_t i, size_t end, uint32_t blk, uint32_t frame_first_blk, HufRef *huf,
+                          TableRef seqtbl[3]) {
+        if (i >= end) return bad("empty compressed block");
+        // ---- literals section header
+        const int type = p[i] & 3, sf = (p[i] >> 2) & 3;
+        size_t regen = 0, comp = 0, hdr = 0;
+        int nstreams = 0;
+        if (type <= 1) {
+            if (sf == 0 || sf == 2) {
+                regen = p[i] >> 3;
+                hdr = 1;
+            } else if (sf == 1) {
+                if (end - i < 2) return bad("literals header cut short");
+                regen = (p[i] >> 4) + (static_cast<size_t>(p[i + 1]) << 4);
+                hdr = 2;
+            } else {
+                if (end - i < 3) return bad("literals header cut short");
+                regen = (p[i] >> 4) + (static_cast<size_t>(p[i + 1]) << 4) + (static_cast<size_t>(p[i + 2]) << 12);
+                hdr = 3;
+            }
+            comp = type == 0 ? regen : 1;
+        } else {
+            if (sf <= 1) {
+                if (end - i < 3) return bad("literals header cut short");
+                uint32_t v = p[i] | (uint32_t(p[i + 1]) << 8) | (uint32_t(p[i + 2]) << 16);
+                regen = (v >> 4) & 0x3FF;
+                comp = (v >> 14) & 0x3FF;
+                hdr = 3;
+                nstreams = sf == 0 ? 1 : 4;
+            } else if (sf == 2) {
+                if (end - i < 4) return bad("literals header cut short");
+                uint32_t v = p[i] | (uint32_t(p[i + 1]) << 8) | (uint32_t(p[i + 2]) << 16) | (uint32_t(p[i + 3]) << 24);
+                regen = (v >> 4) & 0x3FFF;
+                comp = (v >> 18) & 0x3FFF;
+                hdr = 4;
+                nstreams = 4;
+            } else {
+                if (end - i < 5) return bad("literals header cut short");
+                uint64_t v = p[i] | (uint64_t(p[i + 1]) << 8) | (uint64_t(p[i + 2]) << 16) |
+                             (uint64_t(p[i + 3]) << 24) | (uint64_t(p[i + 4]) << 32);
+                regen = static_cast<size_t>((v >> 4) & 0x3FFFF);
+                comp = static_cast<size_t>((v >> 22) & 0x3FFFF);
+                hdr = 5;
+                nstreams = 4;
+            }
+        }
+        if (regen > kBlockMax) return bad("literals larger than a block");
+        if (hdr + comp > end - i) return bad("literals section runs past its block");
+        const size_t lit_at = i + hdr;               // first byte after the literals header
+        size_t j = lit_at + comp;                    // sequences section
+        // ---- sequences section header (needed first: it decides where literals go)
+        if (j >= end) return bad("block has no sequences header");
+        size_t nseq;
+        if (p[j] == 0) {
+            nseq = 0;
+            j += 1;
+        } else if (p[j] < 128) {
+            nseq = p[j];
+            j += 1;
+        } else if (p[j] < 255) {
+            if (end - j < 2) return bad("sequences header cut short");
+            nseq = (static_cast<size_t>(p[j] - 128) << 8) + p[j + 1];
+            j += 2;
+        } else {
+            if (end - j < 3) return bad("sequences header cut short");
+            nseq = static_cast<size_t>(p[j + 1]) + (static_cast<size_t>(p[j + 2]) << 8) + 0x7F00;
+            j += 3;
+        }
+        const bool to_lit = nseq > 0;
+        const uint64_t lit_base = plan->lit_bytes;  // literal-buffer offset when to_lit
+        const uint8_t lflag = to_lit ? 1 : 0;
+        // ---- literals tasks
+        if (type == 0) {
+            if (regen) plan->copies.push_back(CopyTask{lit_at, to_lit ? lit_base : 0, uint32_t(regen), blk, lflag, 0});
+        } else if (type == 1) {
+            if (regen) plan->copies.push_back(CopyTask{p[lit_at], to_lit ? lit_base : 0, uint32_t(regen), blk, uint32_t(lflag | 2), 0});
+        } else {
+            size_t t = lit_at, tend = lit_at + comp;
+            if (type == 2) {
+                long r = read_huf_table(p + t, tend - t, plan, huf, fail);
+                if (r < 0) {
+                    fail.truncated = false;
+                    return false;
+                }
+                t += static_cast<size_t>(r);
+            } else if (!huf->valid) {
+                return bad("treeless literals without a previous Huffman table");
+            }
+            size_t sizes[4], counts[4];
+            if (nstreams == 1) {
+                sizes[0] = tend - t;
+                counts[0] = regen;
+            } else {
+                if (tend - t < 6) return bad("jump table cut short");
+                sizes[0] = p[t] | (size_t(p[t + 1]) << 8);
+                sizes[1] = p[t + 2] | (size_t(p[t + 3]) << 8);
+                sizes[2] = p[t + 4] | (size_t(p[t + 5]) << 8);
+                t += 6;
+                if (sizes[0] + sizes[1] + sizes[2] > tend - t) return bad("jump table exceeds the literals section");
+                sizes[3] = tend - t - sizes[0] - sizes[1] - sizes[2];
+                const size_t q = (regen + 3) / 4;
+                if (3 * q > regen) return bad("too few literals for four streams");
+                counts[0] = counts[1] = counts[2] = q;
+                counts[3] = regen - 3 * q;
+            }
+            uint64_t dst = to_lit ? lit_base : 0;
+            for (int s = 0; s < nstreams; s++) {
+                if (sizes[s] == 0) return bad("empty Huffman stream");
+                t += sizes[s];
+                HufStream hs{};
+                hs.src_end = t;
+                hs.dst = dst;
+                hs.src_len = static_cast<uint32_t>(sizes[s]);
+                hs.n_syms = static_cast<uint32_t>(counts[s]);
+                hs.blk = blk;
+                hs.max_bits = huf->max_bits;
+                hs.flags = lflag;
+                plan->streams.push_back(hs);
+                stream_tbl.push_back(*huf);
+                dst += counts[s];
+            }
+        }
+        // ---- sequences
+        if (nseq == 0) {
+            if (j != end) return bad("bytes after an empty sequences section");
+            plan->blk_size.push_back(static_cast<uint32_t>(regen));
+            plan->known_out += regen;
+            return true;
+        }
+        if (j >= end) return bad("sequences header cut short");
+        const int modes = p[j++];
+        if (modes & 3) return bad("reserved bits set in the sequences header");
+        if (!seq_table(kLL, (modes >> 6) & 3, j, end, &seqtbl[kLL])) return false;
+        if (!seq_table(kOF, (modes >> 4) & 3, j, end, &seqtbl[kOF])) return false;
+        if (!seq_table(kML, (modes >> 2) & 3, j, end, &seqtbl[kML])) return false;
+        if (j >= end) return bad("sequence bitstream is empty");
+        if (p[end - 1] == 0) return bad("sequence bitstream has no end mark");
+        SeqBlock sb{};
+        sb.bits_off = j;
+        sb.bits_len = static_cast<uint32_t>(end - j);
+        sb.n_seq = static_cast<uint32_t>(nseq);
+        sb.ll_tbl = seqtbl[kLL].off;
+        sb.of_tbl = seqtbl[kOF].off;
+        sb.ml_tbl = seqtbl[kML].off;
+        sb.ll_al = seqtbl[kLL].al;
+        sb.of_al = seqtbl[kOF].al;
+        sb.ml_al = seqtbl[kML].al;
+        sb.blk = blk;
+        sb.lit_size = static_cast<uint32_t>(regen);
+        sb.lit_off = lit_base;
+        sb.seq_first = plan->n_sequences;
+        sb.frame_first_blk = frame_first_blk;
+        plan->seq_blocks.push_back(sb);
+        plan->n_sequences += nseq;
+        plan->lit_bytes += (regen + 15) & ~size_t(15);       // keep each block's literals 16-B aligned
+        plan->blk_size.push_back(static_cast<uint32_t>(regen));   // + match bytes, added on the device
+        plan->known_out += regen;
+        return true;
+    }
+
+    bool frame(size_t &i) {
+        if (!need(i, 1, "a frame header")) return false;
+        const uint8_t fhd = p[i++];
+        const int fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, checksum = (fhd >> 2) & 1, dict_flag = fhd & 3;
+        if (fhd & 0x08) return bad("reserved bit set in the frame header");
+        uint64_t window = 0;
+        if (!single) {
+            if (!need(i, 1, "a frame header")) return false;
+            const uint8_t wd = p[i++];
+            const uint64_t base = 1ull << (10 + (wd >> 3));
+            window = base + (base / 8) * (wd & 7);
+        }
+        static const int kDictBytes[4] = {0, 1, 2, 4};
+        if (!need(i, size_t(kDictBytes[dict_flag]), "a frame header")) return false;
+        uint32_t dict_id = 0;
+        for (int k = 0; k < kDictBytes[dict_flag]; k++) dict_id |= uint32_t(p[i + size_t(k)]) << (8 * k);
+        i += size_t(kDictBytes[dict_flag]);
+        if (dict_id != 0) return bad("frame needs a dictionary");
+        const int fcs_bytes = fcs_flag == 0 ? (single ? 1 : 0) : (fcs_flag == 1 ? 2 : (fcs_flag == 2 ? 4 : 8));
+        if (!need(i, size_t(fcs_bytes), "a frame header")) return false;
+        uint64_t fcs = 0;
+        for (int k = 0; k < fcs_bytes; k++) fcs |= uint64_t(p[i + size_t(k)]) << (8 * k);
+        if (fcs_bytes == 2) fcs += 256;
+        i += size_t(fcs_bytes);
+        if (single) window = fcs;
+        plan->window_max = std::max(plan->window_max, window);
+        plan->n_frames++;
+        plan->has_checksum = plan->has_checksum || checksum;
+
+        const uint32_t frame_first_blk = static_cast<uint32_t>(plan->blk_size.size());
+        HufRef huf;                 // entropy tables live for one frame
+        TableRef seqtbl[3];
+        for (;;) {
+            if (!need(i, 3, "a block header")) return false;
+            const uint32_t bh = p[i] | (uint32_t(p[i + 1]) << 8) | (uint32_t(p[i + 2]) << 16);
+            i += 3;
+            const bool last = bh & 1;
+            const int type = (bh >> 1) & 3;
+            const size_t bsize = bh >> 3;
+            const uint32_t blk = static_cast<uint32_t>(plan->blk_size.size());
+            if (type == 0) {                                   // Raw
+                if (!need(i, bsize, "a raw block")) return false;
+                if (bsize > kBlockMax) return bad("raw block larger than 128 KiB");
+                if (bsize) plan->copies.push_back(CopyTask{i, 0, uint32_t(bsize), blk, 0, 0});
+                plan->blk_size.push_back(uint32_t(bsize));
+                plan->known_out += bsize;
+                i += bsize;
+            } else if (type == 1) {                            // RLE
+                if (!need(i, 1, "an RLE block")) return false;
+                if (bsize > kBlockMax) return bad("RLE block larger than 128 KiB");
+                if (bsize) plan->copies.push_back(CopyTask{p[i], 0, uint32_t(bsize), blk, 2, 0});
+                plan->blk_size.push_back(uint32_t(bsize));
+                plan->known_out += bsize;
+                i += 1;
+            } else if (type == 2) {                            // Compressed
+                if (!need(i, bsize, "a compressed block")) return false;
+                if (bsize > kBlockMax) return bad("compressed block larger than 128 KiB");
+                if (!compressed_block(i, i + bsize, blk, frame_first_blk, &huf, seqtbl)) return false;
+                i += bsize;
+            } else {
+                return bad("reserved block type");
+            }
+            if (last) break;
+        }
+        if (checksum) {
+            if (!need(i, 4, "the frame checksum")) return false;
+            i += 4;                                            // xxh64 low word: not verified
+        }
+        return true;
+    }
+
+    // Greedy packing of streams into wave tasks: <= 64 lanes, decode tables <= kHufLdsEntries.
+    void pack_tasks() {
+        struct Slot {
+            uint32_t pool_off, lds_off;
+        };
+        std::vector<Slot> slots;
+        HufTask cur{0, 0, 0, 0};
+        uint32_t lds_used = 0;
+        auto close = [&]() {
+            if (cur.n_streams) plan->tasks.push_back(cur);
+            cur.first_stream += cur.n_streams;
+            cur.n_streams = 0;
+            cur.first_copy = static_cast<uint32_t>(plan->tbl_copies.size());
+            cur.n_copies = 0;
+            slots.clear();
+            lds_used = 0;
+        };
+        for (size_t s = 0; s < plan->streams.size(); s++) {
+            const HufRef &t = stream_tbl[s];
+            const uint32_t entries = 1u << t.max_bits;
+            auto find = [&]() -> int {
+                for (size_t k = 0; k < slots.size(); k++)
+                    if (slots[k].pool_off == t.pool_off) return static_cast<int>(k);
+                return -1;
+            };
+            int k = find();
+            if (k < 0 && lds_used + entries > kHufLdsEntries) {
+                close();                                    // table does not fit beside the others
+            }
+            if (k < 0) {
+                slots.push_back(Slot{t.pool_off, lds_used});
+                plan->tbl_copies.push_back(HufTblCopy{t.pool_off, lds_used, entries, 0});
+                cur.n_copies++;
+                lds_used += entries;
+                k = static_cast<int>(slots.size()) - 1;
+            }
+            plan->streams[s].tbl_lds = static_cast<uint16_t>(slots[size_t(k)].lds_off);
+            cur.n_streams++;
+            if (cur.n_streams == kHufWave) close();
+        }
+        close();
+    }
+};
+
+}  // namespace
+
+std::string build_zplan(const uint8_t *payload, size_t n, ZPlan *plan, bool *truncated) {
+    Walker w{payload, n, plan, {}, {}, {}};
+    *truncated = false;
+    if (n == 0) {
+        *truncated = true;
+        return "empty section payload";
+    }
+    size_t i = 0;
+    while (i < n) {                 // a section may hold several frames back to back
+        if (!w.frame(i)) {
+            *truncated = w.fail.truncated;
+            return w.fail.msg.empty() ? std::string("malformed zstd frame") : w.fail.msg;
+        }
+    }
+    w.pack_tasks();
+    return std::string();
+}
+
+bool zplan_is_literal_only(const ZPlan &plan) { return plan.seq_blocks.empty(); }
+
+}  // namespace nafgpu

@@ -1,0 +1,172 @@
+"""Decoder / Record / open -- same names, arguments and error behaviour as the reference's Python
+API (nafcodec-py/nafcodec/lib.pyi:18-67, lib.rs:324-461, error mapping lib.rs:39-77)."""
+import ctypes
+import errno as _errno
+import io
+import os
+from ctypes import byref, c_void_p
+
+from . import _ffi
+
+SEQUENCE_TYPES = ("dna", "rna", "protein", "text")
+
+
+class Record:
+    """lib.pyi:18-33 -- five optional fields."""
+    __slots__ = ("id", "comment", "sequence", "quality", "length")
+
+    def __init__(self, *, id=None, comment=None, sequence=None, quality=None, length=None):
+        self.id, self.comment, self.sequence, self.quality, self.length = id, comment, sequence, quality, length
+
+    def __repr__(self):
+        args = ", ".join("%s=%r" % (k, getattr(self, k)) for k in self.__slots__ if getattr(self, k) is not None)
+        return "Record(%s)" % args
+
+
+def _raise(err):
+    """Error -> Python exception, as nafcodec-py/nafcodec/lib.rs:39-77 does."""
+    e = _ffi.NafError.from_c(err)
+    if e.status == _ffi.E_IO:
+        if e.io_kind == _ffi.IO_NOT_FOUND:
+            raise FileNotFoundError(e.os_errno or _errno.ENOENT, e.message)
+        if e.io_kind == _ffi.IO_IS_A_DIRECTORY:
+            raise IsADirectoryError(e.os_errno or _errno.EISDIR, e.message)
+        if e.io_kind == _ffi.IO_PERMISSION_DENIED:
+            raise PermissionError(e.os_errno or _errno.EACCES, e.message)
+        if e.io_kind == _ffi.IO_UNEXPECTED_EOF:
+            raise EOFError(e.message)
+        raise OSError(e.os_errno, e.message)
+    if e.status in (_ffi.E_NOM, _ffi.E_UTF8):
+        raise ValueError(e.message)
+    raise e
+
+
+class Decoder:
+    """lib.pyi:35-67.  `file` is a path or a binary file-like object."""
+
+    def __init__(self, file, *, id=True, comment=True, sequence=True, quality=True, mask=True, buffer_size=None,
+                 device=-1, spec_mask=False, _lib=None):
+        self._lib = _lib or _ffi.default()
+        self._h = None
+        opts = _ffi.Opts()
+        self._lib.c.nafgpu_opts_default(byref(opts))
+        opts.id, opts.comment, opts.sequence, opts.quality, opts.mask = map(int, (id, comment, sequence, quality, mask))
+        opts.spec_mask = int(spec_mask)
+        opts.buffer_size = io.DEFAULT_BUFFER_SIZE if buffer_size is None else int(buffer_size)  # lib.rs:350-354
+        opts.device = device
+        h, err = c_void_p(), _ffi.Error()
+        if isinstance(file, (str, bytes, os.PathLike)):
+            path = os.fsencode(file)
+            rc = self._lib.c.nafgpu_open_path(path, byref(opts), byref(h), byref(err))
+        else:
+            # file-like: drained once through read(), like PyFileRead (pyfile.rs:88-187) but without seeks
+            self._keep = file.read()
+            if not isinstance(self._keep, (bytes, bytearray)):
+                raise TypeError("expected a binary file-like object")
+            self._keep = bytes(self._keep)
+            rc = self._lib.c.nafgpu_open_bytes(self._keep, len(self._keep), byref(opts), byref(h), byref(err))
+        if rc != _ffi.OK:
+            _raise(err)
+        self._h = h
+        self._header = _ffi.Header()
+        self._lib.c.nafgpu_get_header(self._h, byref(self._header))
+
+    # ---- iteration -----------------------------------------------------------------------
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        rec = self.read()
+        if rec is None:
+            raise StopIteration
+        return rec
+
+    def read(self):
+        """lib.pyi:67 -- the next record, or None at the end of the archive."""
+        rec = _ffi.Record()
+        rc = self._lib.c.nafgpu_next(self._h, byref(rec))
+        if rc == _ffi.END:
+            return None
+        if rc != _ffi.OK:
+            err = _ffi.Error()
+            self._lib.c.nafgpu_last_error(self._h, byref(err))
+            _raise(err)
+
+        def text(f):
+            if not f.present:
+                return None
+            return ctypes.string_at(f.ptr, f.len).decode("utf-8") if f.len else ""
+
+        return Record(id=text(rec.id), comment=text(rec.comment), sequence=text(rec.sequence),
+                      quality=text(rec.quality), length=rec.length if rec.has_length else None)
+
+    def __len__(self):
+        return int(self._lib.c.nafgpu_remaining(self._h))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc_value, traceback):
+        self.close()
+        return False
+
+    def close(self):
+        if self._h:
+            self._lib.c.nafgpu_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- header properties (lib.pyi:56-66) ---------------------------------------------------
+    @property
+    def sequence_type(self):
+        return SEQUENCE_TYPES[self._header.sequence_type]
+
+    @property
+    def format_version(self):
+        return "v%d" % self._header.format_version
+
+    @property
+    def line_length(self):
+        return int(self._header.line_length)
+
+    @property
+    def name_separator(self):
+        return chr(self._header.name_separator)
+
+    @property
+    def number_of_sequences(self):
+        return int(self._header.number_of_sequences)
+
+    @property
+    def flags(self):
+        return int(self._header.flags)
+
+    # ---- bulk device path (no reference counterpart: what `for r in decoder` becomes on a GPU) ----
+    def decode_all_device(self):
+        """Decode every selected section on the GPU; returns the nafgpu_device_result struct."""
+        res = _ffi.DeviceResult()
+        rc = self._lib.c.nafgpu_decode_all_device(self._h, byref(res))
+        if rc != _ffi.OK:
+            err = _ffi.Error()
+            self._lib.c.nafgpu_last_error(self._h, byref(err))
+            _raise(err)
+        return res
+
+    def hash_device(self, d_ptr, n):
+        out = ctypes.c_uint64()
+        rc = self._lib.c.nafgpu_hash64_device(self._h, d_ptr, n, byref(out))
+        if rc != _ffi.OK:
+            raise RuntimeError("nafgpu_hash64_device failed: %d" % rc)
+        return out.value
+
+
+def open(file, mode="r", **options):
+    """nafcodec.open (lib.pyi:92-108).  Only mode "r" exists here: the encoder is outside the hot path."""
+    if mode != "r":
+        raise ValueError("invalid mode: %r (nafcodec_amd implements the decode path only)" % (mode,))
+    return Decoder(file, **options)

@@ -1,0 +1,136 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path behind the C-ABI
+(include/nafgpu.h via nafcodec_amd) against the CPU oracle on the same inputs.
+
+Bar: bit-exact (integer / byte work only on this path)."""
+import ctypes
+import io
+
+import numpy as np
+import pytest
+
+import zstd_ref
+from conftest import golden_bytes
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+FIXTURES = ["LuxC", "masked", "phix", "CP040672", "NZ_AAEN01000029"]
+FIELDS = ("id", "comment", "sequence", "quality", "length")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from nafcodec_amd import _ffi
+    L = _ffi.default()           # raises if libnafgpu.so is missing: no CPU fallback exists
+    name, hbm, cus = L.device_info(0)
+    assert "gfx950" in name, name
+    return L
+
+
+def same_records(got, want):
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        for f in FIELDS:
+            assert getattr(a, f) == getattr(b, f), (f, a.id)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_fixture_records_match_oracle(lib, name):
+    import nafcodec_amd
+    data = golden_bytes(name + ".naf")
+    got = list(nafcodec_amd.Decoder(io.BytesIO(data)))
+    same_records(got, list(oracle.Decoder(data)))
+
+
+@pytest.mark.parametrize("off", ["id", "comment", "sequence", "quality", "mask"])
+def test_fixture_field_selection(lib, off):
+    import nafcodec_amd
+    for name in ("phix", "masked"):
+        data = golden_bytes(name + ".naf")
+        got = list(nafcodec_amd.Decoder(io.BytesIO(data), **{off: False}))
+        same_records(got, list(oracle.Decoder(data, **{off: False})))
+
+
+def test_open_path_and_len(lib):
+    import os
+    import nafcodec_amd
+    from conftest import GOLDEN
+    d = nafcodec_amd.open(os.path.join(GOLDEN, "phix.naf"))
+    assert (len(d), d.sequence_type, d.format_version, d.line_length, d.name_separator) == (42, "dna", "v1", 301, " ")
+    next(d)
+    assert len(d) == 41
+    assert len(list(d)) == 41 and len(d) == 0
+    with pytest.raises(FileNotFoundError):
+        nafcodec_amd.Decoder("")
+    with pytest.raises(IsADirectoryError):
+        nafcodec_amd.Decoder(GOLDEN)
+
+
+def packed_dna(rng, n, alphabet=(1, 2, 4, 8)):
+    codes = np.array(alphabet, dtype=np.uint8)
+    return (codes[rng.integers(0, len(codes), n)] | (codes[rng.integers(0, len(codes), n)] << 4)).astype(np.uint8).tobytes()
+
+
+@pytest.mark.skipif(not zstd_ref.available(), reason="libzstd not loadable")
+@pytest.mark.parametrize("level", [1, 3, 19])
+@pytest.mark.parametrize("n", [1, 7, 1000, 70000, 1 << 20])
+def test_zstd_section_libzstd_written(lib, level, n):
+    """L0 on its own: sections written by the real libzstd (Huffman, treeless, FSE sequences, repeats)."""
+    rng = np.random.default_rng(n * 31 + level)
+    data = packed_dna(rng, n)
+    for streaming in (True, False):
+        payload = zstd_ref.compress_magicless(data, level, streaming)
+        assert oracle.zstd_decode(payload, len(data)) == data
+        assert lib.zstd_decompress(payload, len(data)) == data
+
+
+@pytest.mark.skipif(not zstd_ref.available(), reason="libzstd not loadable")
+def test_zstd_text_sections(lib):
+    rng = np.random.default_rng(5)
+    q = rng.choice(np.frombuffer(b"#8CGGGGGGGG<AFFJJ", dtype=np.uint8), 400000).tobytes()
+    ids = b"".join(b"@SRR1377138.%d some read\0" % i for i in range(20000))
+    rep = packed_dna(rng, 4000) * 50 + bytes(5000) + b"\x11" * 300000 + rng.integers(0, 256, 200000, dtype=np.uint8).tobytes()
+    for data in (q, ids, rep):
+        for level, kw in ((1, {}), (3, {}), (3, {"flush_every": 97}), (9, {"flush_every": 4001}), (19, {"checksum": True})):
+            payload = zstd_ref.compress_magicless(data, level, True, **kw)
+            assert lib.zstd_decompress(payload, len(data)) == data
+
+
+@pytest.mark.skipif(not zstd_ref.available(), reason="libzstd not loadable")
+def test_zstd_corrupt_is_an_error_not_a_fault(lib):
+    from nafcodec_amd import NafError
+    rng = np.random.default_rng(11)
+    data = packed_dna(rng, 200000)
+    payload = bytearray(zstd_ref.compress_magicless(data, 3, True))
+    for cut in (1, 2, 5, len(payload) // 2, len(payload) - 1):
+        with pytest.raises(NafError):
+            lib.zstd_decompress(bytes(payload[:cut]), len(data))
+    for k in range(24):
+        p = bytearray(payload)
+        p[int(rng.integers(0, len(p)))] ^= 1 << int(rng.integers(0, 8))
+        try:
+            out = lib.zstd_decompress(bytes(p), len(data))
+        except NafError:
+            continue
+        # a flip may land in bits no decoder reads; if it decodes, it must agree with the oracle
+        assert out == oracle.zstd_decode(bytes(p), len(data))
+
+
+@pytest.mark.parametrize("n_bases,mask,iupac", [(1000, False, 0), (300001, True, 0), (3000001, True, 5),
+                                                (1500000, False, 200), (40_000_001, True, 0)])
+def test_synthetic_archive(lib, n_bases, mask, iupac):
+    """Synthetic config-2/4 style archives: bulk device decode, checksum-of-checksums against the
+    writer's expected value, and (small sizes) per-record equality with the oracle."""
+    import nafcodec_amd
+    arc = lib.synth(n_bases, seed=n_bases, with_mask=mask, iupac_permille=iupac)
+    try:
+        blob = ctypes.string_at(arc.bytes, arc.n)
+        dec = nafcodec_amd.Decoder(io.BytesIO(blob))
+        res = dec.decode_all_device()
+        assert (res.n_bases, res.n_records) == (arc.n_bases, arc.n_records)
+        assert dec.hash_device(res.d_sequence, res.n_bases) == arc.seq_hash
+        assert dec.hash_device(res.d_record_end, 8 * res.n_records) == arc.offsets_hash
+        if n_bases <= 3_000_001:
+            same_records(list(nafcodec_amd.Decoder(io.BytesIO(blob))), list(oracle.Decoder(blob)))
+    finally:
+        lib.c.nafgpu_synth_free(ctypes.byref(arc))

@@ -43,7 +43,7 @@ struct HufLane {
 
 #define HUF_STEP(ACC, SHIFT, LEN_EXPR)                                                        \
     {                                                                                         \
-        const uint32_t peek = static_cast<uint32_t>(((static_cast<uint64_t>(L.hi) << 32) | L.lo) >> (32u - L.c)); \
+        const uint32_t peek = __builtin_amdgcn_alignbit(L.hi, L.lo, 32u - L.c); /* c = 32 -> shift 0 -> lo */ \
         const uint32_t e = tbl[peek >> sh];                                                   \
         const uint32_t len = (LEN_EXPR);                                                      \
         L.c += len;                                                                           \
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         const uint32_t hb = 31u - static_cast<uint32_t>(__clz(static_cast<int>(lastb | 1u)));
         bits_total = (st.src_len - 1u) * 8u + hb;
         const uintptr_t a = reinterpret_cast<uintptr_t>(lastp);
-        ctop = reinterpret_cast<const uint8_t *>(a & ~static_cast<uintptr_t>(15));
+        ctop = lastp - (a & 15);                                 // stays a global-memory pointer (no flat loads)
         L.rp = 3u - static_cast<uint32_t>((a >> 2) & 3u);
         L.c = (3u - static_cast<uint32_t>(a & 3u)) * 8u + (8u - hb);
         c0 = L.c;
@@ -116,7 +116,8 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         L.hi = ring[L.rp];
         L.lo = ring[L.rp + 1];
         L.nw = ring[L.rp + 2];
-        s_dst[lane] = reinterpret_cast<uint64_t>((st.flags & 1) ? lit + st.dst : out + blk_base[st.blk] + st.dst);
+        // destination as an offset; bit 63 selects the literal buffer
+        s_dst[lane] = (st.flags & 1) ? (st.dst | (1ull << 63)) : blk_base[st.blk] + st.dst;
     } else {
         s_dst[lane] = 0;
     }
@@ -175,7 +176,8 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
                 const uint32_t valid = rn - base < 64u ? rn - base : 64u;
                 if (col < valid) {
                     const uint4 v = *reinterpret_cast<const uint4 *>(s_out + row * kRowWords + (col >> 2));
-                    uint8_t *d = reinterpret_cast<uint8_t *>(s_dst[row]) + base + col;
+                    const uint64_t doff = s_dst[row];
+                    uint8_t *d = ((doff >> 63) ? lit : out) + (doff & ~(1ull << 63)) + base + col;
                     if (col + 16 <= valid) {
                         if ((reinterpret_cast<uintptr_t>(d) & 15) == 0) {
                             *reinterpret_cast<uint4 *>(d) = v;

@@ -64,6 +64,10 @@ inline T atomicAdd(T *p, T v) {
     *p = old + v;
     return old;
 }
+// v_alignbit_b32: ({hi, lo} >> (shift & 31)) truncated to 32 bits
+inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t shift) {
+    return static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | lo) >> (shift & 31));
+}
 // v_perm_b32: byte select from {hi (bytes 4-7), lo (bytes 0-3)}
 inline uint32_t __builtin_amdgcn_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
     const uint64_t src = (static_cast<uint64_t>(hi) << 32) | lo;

@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- NAF decode throughput on MI355X (BASELINE.json metric: decoded Gbases/s).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--bases B]
+
+One "step" = one pass of the hot path over one synthetic archive already resident in HBM:
+per-block Huffman literal decode of the sequence section, record-length scan, 4-bit -> IUPAC
+unpack, (mask).  Workload at N=1 = BASELINE.json configs[1]: a synthetic 10 GB DNA-only
+.naf (Length + Sequence sections, ~40e9 bases, zstd-level-1 shape: 128 KiB Huffman-literal
+blocks).  For N>1 every rank decodes its own 10 GB shard of the N x 10 GB archive (weak
+scaling, block-range sharding) and the ranks exchange {bases, packed bytes, records, carry}
+with one RCCL all-gather per step to place their records in the global offset table.
+
+Prints ONE JSON line on rank 0 (see the field list in the task contract) with two extra
+objects: "roofline" for the dominant kernel (k_huf_decode) and "cpu_baseline" (the CPU oracle
+timed on a bounded sample of the same workload, one host thread like the reference).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+DEFAULT_BASES = 40_000_000_000  # ~10 GB archive at ~0.25 B/base
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--bases", type=float, default=float(os.environ.get("NAF_BENCH_BASES", DEFAULT_BASES)),
+                    help="nucleotides per GPU (default 40e9 = the 10 GB archive of configs[1])")
+    ap.add_argument("--mask", action="store_true", help="configs[3]: add a Mask section")
+    ap.add_argument("--cpu-sample-bases", type=float, default=0,
+                    help="size of the CPU-baseline sample (0 = auto, about 15 s of CPU work)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-verify", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(lib, n_bases_target, mask):
+    """The oracle (kind "port": CPU restatement of the reference pipeline, one thread) timed on a
+    bounded sample of the same workload.  Returns the cpu_baseline JSON object."""
+    from oracle import oracle
+    # calibrate on a small sample, then size the real one for ~15 s of single-thread work
+    probe_bases = 8_000_000
+    arc = lib.synth(probe_bases, seed=0x4E4146, with_mask=mask)
+    blob = ctypes.string_at(arc.bytes, arc.n)
+    lib.c.nafgpu_synth_free(ctypes.byref(arc))
+    t0 = time.perf_counter()
+    n = sum(len(r.sequence) for r in oracle.Decoder(blob, raw=True))
+    rate = n / (time.perf_counter() - t0)
+    sample = int(n_bases_target) if n_bases_target else int(min(max(rate * 15.0, probe_bases), 4e9))
+    arc = lib.synth(sample, seed=0x4E4146, with_mask=mask)
+    blob = ctypes.string_at(arc.bytes, arc.n)
+    lib.c.nafgpu_synth_free(ctypes.byref(arc))
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        n = sum(len(r.sequence) for r in oracle.Decoder(blob, raw=True))
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": round(n / best / 1e9, 4), "unit": "Gbases/s", "cores": 1, "kind": "port",
+            "sample": "%d bases (%.1f MB archive) of the same synthetic workload, CPU oracle "
+                      "(oracle/*.c: scalar zstd + reader.rs restatement), best of 2, host has %d cores"
+                      % (n, len(blob) / 1e6, os.cpu_count() or 0)}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    from nafcodec_amd import _ffi
+    lib = _ffi.default()                       # raises if libnafgpu.so is missing: no CPU fallback
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+    device = local_rank
+
+    n_bases = int(args.bases)
+    t0 = time.perf_counter()
+    arc = lib.synth(n_bases, seed=0x4E4146 + rank, with_mask=args.mask)
+    t_gen = time.perf_counter() - t0
+
+    opts = _ffi.Opts()
+    lib.c.nafgpu_opts_default(ctypes.byref(opts))
+    opts.device = device
+    h, err = ctypes.c_void_p(), _ffi.Error()
+    rc = lib.c.nafgpu_open_bytes(ctypes.cast(arc.bytes, ctypes.c_char_p), arc.n, ctypes.byref(opts),
+                                 ctypes.byref(h), ctypes.byref(err))
+    if rc != 0:
+        raise RuntimeError("open failed: %s" % err.message.decode())
+    t0 = time.perf_counter()
+    rc = lib.c.nafgpu_upload(h)                # host plan + H2D: compressed bytes resident in HBM
+    if rc != 0:
+        lib.c.nafgpu_last_error(h, ctypes.byref(err))
+        raise RuntimeError("upload failed: %s" % err.message.decode())
+    t_upload = time.perf_counter() - t0
+
+    res = _ffi.DeviceResult()
+    gather_in = gather_out = None
+    if world > 1:
+        gather_in = torch.zeros(4, dtype=torch.int64, device="cuda")
+        gather_out = torch.zeros(4 * world, dtype=torch.int64, device="cuda")
+
+    def step():
+        rc = lib.c.nafgpu_decode_all_device(h, ctypes.byref(res))
+        if rc != 0:
+            lib.c.nafgpu_last_error(h, ctypes.byref(err))
+            raise RuntimeError("decode failed: %s" % err.message.decode())
+        if world > 1:
+            # the one exchange step of the sharded path: per-rank counts -> global record/base offsets
+            gather_in.copy_(torch.tensor([res.n_bases, res.packed_bytes, res.n_records, res.n_bases & 1],
+                                         dtype=torch.int64), non_blocking=False)
+            dist.all_gather_into_tensor(gather_out, gather_in)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        lib.c.nafgpu_device_synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    huf_ms, unpack_ms, other_ms, total_ms = [], [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        huf_ms.append(res.ms_huf)
+        unpack_ms.append(res.ms_unpack)
+        other_ms.append(res.ms_other + res.ms_seq_lz)
+        total_ms.append(res.ms_total)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        g = gather_out.view(world, 4).cpu()
+        total_bases = int(g[:, 0].sum())
+        base_offset = int(g[:rank, 0].sum())        # where this shard's first base lands globally
+        assert base_offset >= 0
+    else:
+        total_bases = int(res.n_bases)
+
+    ok = True
+    if not args.no_verify:                          # bit-exactness at full size: checksum of checksums
+        out = ctypes.c_uint64()
+        lib.c.nafgpu_hash64_device(h, res.d_sequence, res.n_bases, ctypes.byref(out))
+        ok = out.value == arc.seq_hash and res.n_bases == arc.n_bases and res.n_records == arc.n_records
+        lib.c.nafgpu_hash64_device(h, res.d_record_end, 8 * res.n_records, ctypes.byref(out))
+        ok = ok and out.value == arc.offsets_hash
+        if not ok:
+            raise RuntimeError("rank %d: decoded bases / offsets differ from the writer's checksums" % rank)
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = total_bases * args.steps / elapsed / 1e9
+        k1 = sum(huf_ms) / len(huf_ms) / max(res.n_huf_launches, 1)      # ms per k_huf_decode launch
+        # algorithmic bytes of ONE k_huf_decode launch: compressed sequence bytes in + packed bytes out
+        k1_bytes = res.seq_compressed_bytes + res.packed_bytes
+        achieved = k1_bytes / (k1 * 1e-3) / 1e9 if k1 > 0 else 0.0
+        # whole path, SURVEY 8(d): compressed in + 1 ASCII byte per base out + 4 B per record
+        path_bytes = res.seq_compressed_bytes + res.n_bases + 4 * res.n_records
+        dev_ms = sum(total_ms) / len(total_ms)
+        line = {
+            "metric": "decoded Gbases/s (+ GB/s off HBM) at 1/2/4/8 MI355X vs CPU ref",
+            "value": round(value, 3), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "synthetic %.1f GB DNA-only .naf per GPU (seq+len%s), %d bases, %d records, "
+                                   "%d zstd blocks / %d Huffman streams, zstd-level-1 shape (L1), bit-exact check %s"
+                                   % (arc.n / 1e9, "+mask" if args.mask else "", res.n_bases, res.n_records,
+                                      res.n_zstd_blocks, res.n_huf_streams,
+                                      "passed" if (ok and not args.no_verify) else "skipped"),
+                       "sharding": "block ranges, one 10 GB shard per GPU" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "k_huf_decode", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "ms_per_launch": round(k1, 3),
+                         "algorithmic_bytes_per_launch": int(k1_bytes)},
+            "path": {"device_ms_per_step": round(dev_ms, 3),
+                     "algorithmic_GBps": round(path_bytes / (dev_ms * 1e-3) / 1e9, 1) if dev_ms else None,
+                     "frac_of_hbm_peak": round(path_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dev_ms else None,
+                     "ms_huf": round(sum(huf_ms) / len(huf_ms), 3), "ms_unpack": round(sum(unpack_ms) / len(unpack_ms), 3),
+                     "ms_other": round(sum(other_ms) / len(other_ms), 3),
+                     "host_plan_ms": round(res.ms_host_plan, 1), "h2d_ms": round(res.ms_h2d, 1),
+                     "synth_s": round(t_gen, 1), "upload_s": round(t_upload, 2)},
+        }
+        if not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(lib, args.cpu_sample_bases, args.mask)
+        print(json.dumps(line), flush=True)
+
+    lib.c.nafgpu_close(h)
+    lib.c.nafgpu_synth_free(ctypes.byref(arc))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

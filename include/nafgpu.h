@@ -178,6 +178,12 @@ typedef struct {
 } nafgpu_device_result;
 
 int nafgpu_decode_all_device(nafgpu_decoder *dec, nafgpu_device_result *out);
+/* Host front end only: frame walk, table build, upload of the archive and task lists to HBM.
+ * Idempotent; decode_all_device / next call it implicitly.  Lets a caller separate "compressed
+ * bytes resident in HBM" from the decode itself. */
+int nafgpu_upload(nafgpu_decoder *dec);
+/* hipDeviceSynchronize on `device` (-1 = current) */
+int nafgpu_device_synchronize(int device);
 
 /* ---- L0 replacement on its own: one NAF section payload ------------------------------
  * Replaces zstd::stream::read::Decoder + include_magicbytes(false) (decoder/mod.rs:221-223)

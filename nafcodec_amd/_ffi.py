@@ -76,6 +76,7 @@ EXPORTS = [
     "nafgpu_get_header", "nafgpu_remaining", "nafgpu_next", "nafgpu_close", "nafgpu_last_error",
     "nafgpu_decode_all_device", "nafgpu_zstd_decompress", "nafgpu_synth_write", "nafgpu_synth_free",
     "nafgpu_hash64_host", "nafgpu_hash64_device", "nafgpu_abi_version", "nafgpu_device_info",
+    "nafgpu_upload", "nafgpu_device_synchronize",
 ]
 
 
@@ -104,6 +105,8 @@ class Library:
         L.nafgpu_last_error.argtypes = [c_void_p, POINTER(Error)]
         L.nafgpu_last_error.restype = None
         L.nafgpu_decode_all_device.argtypes = [c_void_p, POINTER(DeviceResult)]
+        L.nafgpu_upload.argtypes = [c_void_p]
+        L.nafgpu_device_synchronize.argtypes = [c_int]
         L.nafgpu_zstd_decompress.argtypes = [c_char_p, c_size_t, c_void_p, c_size_t, POINTER(c_size_t), c_int,
                                              POINTER(Error)]
         L.nafgpu_synth_write.argtypes = [POINTER(SynthSpec), POINTER(SynthArchive)]

@@ -124,22 +124,14 @@ struct nafgpu_decoder {
 
 namespace {
 
+Failure ensure_uploaded(nafgpu_decoder *d);
+
 Failure ensure_decoded(nafgpu_decoder *d) {
     if (!d->fatal.ok()) return d->fatal;
     if (d->decoded) return Failure();
-    if (!d->device_ready) {
-        Failure f = d->job.init(d->opts.device);
-        if (!f.ok()) return d->fatal = f;
-        ArchiveOptions ao;
-        const bool want[kNumSections] = {d->opts.id != 0, d->opts.comment != 0, true, d->opts.mask != 0,
-                                         d->opts.sequence != 0, d->opts.quality != 0};
-        for (int s = 0; s < kNumSections; s++) ao.want[s] = want[s];
-        ao.spec_mask = d->opts.spec_mask != 0;
-        f = d->job.upload(d->bytes, d->n_bytes, d->header, d->sec, ao);
-        if (!f.ok()) return d->fatal = f;
-        d->device_ready = true;
-    }
-    Failure f = d->job.decode();
+    Failure f = ensure_uploaded(d);
+    if (!f.ok()) return f;
+    f = d->job.decode();
     if (!f.ok()) return d->fatal = f;
     // small sections come back to the host whole; sequence / quality through sliding windows
     auto fetch = [&](int s, std::vector<uint8_t> *dst) -> Failure {
@@ -162,6 +154,23 @@ Failure ensure_decoded(nafgpu_decoder *d) {
     const uint64_t total = d->sec[kSequence].present ? d->sec[kSequence].original_size : 0;
     d->mask_covered = d->job.mask_sum() >= total ? UINT64_MAX : d->job.mask_sum();
     d->decoded = true;
+    return Failure();
+}
+
+Failure ensure_uploaded(nafgpu_decoder *d) {
+    if (!d->fatal.ok()) return d->fatal;
+    if (!d->device_ready) {
+        Failure f = d->job.init(d->opts.device);
+        if (!f.ok()) return d->fatal = f;
+        ArchiveOptions ao;
+        const bool want[kNumSections] = {d->opts.id != 0, d->opts.comment != 0, true, d->opts.mask != 0,
+                                         d->opts.sequence != 0, d->opts.quality != 0};
+        for (int s = 0; s < kNumSections; s++) ao.want[s] = want[s];
+        ao.spec_mask = d->opts.spec_mask != 0;
+        f = d->job.upload(d->bytes, d->n_bytes, d->header, d->sec, ao);
+        if (!f.ok()) return d->fatal = f;
+        d->device_ready = true;
+    }
     return Failure();
 }
 
@@ -419,6 +428,17 @@ int nafgpu_decode_all_device(nafgpu_decoder *d, nafgpu_device_result *out) {
     out->ms_host_plan = j.host_plan_ms();
     out->ms_h2d = j.h2d_ms();
     return NAFGPU_OK;
+}
+
+int nafgpu_upload(nafgpu_decoder *d) {
+    if (!d) return NAFGPU_E_INVALID_ARG;
+    Failure f = ensure_uploaded(d);
+    return f.ok() ? NAFGPU_OK : fail(d, f);
+}
+
+int nafgpu_device_synchronize(int device) {
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) return NAFGPU_E_DEVICE;
+    return hipDeviceSynchronize() == hipSuccess ? NAFGPU_OK : NAFGPU_E_DEVICE;
 }
 
 int nafgpu_hash64_device(const nafgpu_decoder *d, const void *d_ptr, uint64_t n, uint64_t *out) {

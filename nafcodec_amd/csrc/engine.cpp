@@ -115,8 +115,9 @@ StageTimes StageTimer::collect() {
 
 // ------------------------------------------------------------------ SectionJob
 Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expect_size, const uint8_t *d_payload,
-                            hipStream_t stream) {
+                            hipStream_t stream, uint32_t ascii_t_char) {
     ready_ = false;
+    t_char_ = ascii_t_char;
     plan_ = ZPlan();
     const double t0 = now_ms();
     bool truncated = false;
@@ -133,16 +134,19 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
     n_seq_blocks_ = plan_.seq_blocks.size();
     if (plan_.seq_blocks.empty() && plan_.known_out != expect_size)
         return Failure::io(NAFGPU_IO_INVALID_DATA, "zstd: decoded size differs from the size recorded in the archive");
-    max_tbl_entries_ = 0;
-    for (const HufTask &t : plan_.tasks) {
+    max_tbl_direct_ = max_tbl_lit_ = 0;
+    n_direct_tasks_ = plan_.n_direct_tasks;
+    for (size_t i = 0; i < plan_.tasks.size(); i++) {
+        const HufTask &t = plan_.tasks[i];
         uint32_t e = 0;
         for (uint32_t k = 0; k < t.n_copies; k++) {
             const HufTblCopy &c = plan_.tbl_copies[t.first_copy + k];
             e = std::max(e, c.lds_off + c.n_entries);
         }
-        max_tbl_entries_ = std::max(max_tbl_entries_, e);
+        uint32_t &m = i < n_direct_tasks_ ? max_tbl_direct_ : max_tbl_lit_;
+        m = std::max(m, e);
     }
-    bool ok = d_out_.alloc(static_cast<size_t>(expect_size) + 64) && d_status_.alloc(64) &&
+    bool ok = d_out_.alloc(static_cast<size_t>(out_bytes()) + 64) && d_status_.alloc(64) &&
               d_blk_size_.upload(plan_.blk_size.data(), n_blocks_ * sizeof(uint32_t), stream) &&
               d_blk_base_.alloc((n_blocks_ + 1) * sizeof(uint64_t)) && d_scan_tmp_.alloc(scan_tmp_bytes(n_blocks_)) &&
               d_streams_.upload(plan_.streams.data(), n_streams_ * sizeof(HufStream), stream) &&
@@ -180,20 +184,29 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer) {
     if (timer) timer->begin(stream, StageTimer::kOther);
     launch_scan_blocks(stream, d_blk_size_.as<uint32_t>(), n_blocks_, d_blk_base_.as<uint64_t>(), d_scan_tmp_.bytes(),
                        expect_, status);
+    const bool ascii = t_char_ != 0;
     launch_copy_fill(stream, d_src_, d_copies_.as<CopyTask>(), static_cast<uint32_t>(n_copies_),
-                     d_blk_base_.as<uint64_t>(), d_out_.bytes(), d_lit_.bytes(), status);
+                     d_blk_base_.as<uint64_t>(), d_out_.bytes(), d_lit_.bytes(), ascii, t_char_, status);
     if (timer) timer->end(stream);
-    if (n_tasks_) {
+    if (n_direct_tasks_) {                                   // streams of literal-only blocks: straight to the output
         if (timer) timer->begin(stream, StageTimer::kHuf);
-        launch_huf_decode(stream, d_src_, d_tasks_.as<HufTask>(), static_cast<uint32_t>(n_tasks_),
-                          d_tbl_copies_.as<HufTblCopy>(), d_streams_.as<HufStream>(), d_pool_.as<uint16_t>(),
-                          d_blk_base_.as<uint64_t>(), d_out_.bytes(), d_lit_.bytes(), max_tbl_entries_, status);
+        launch_huf_decode(stream, d_src_, d_tasks_.as<HufTask>(), n_direct_tasks_, d_tbl_copies_.as<HufTblCopy>(),
+                          d_streams_.as<HufStream>(), d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), d_out_.bytes(),
+                          d_lit_.bytes(), max_tbl_direct_, ascii, t_char_, status);
+        if (timer) timer->end(stream);
+    }
+    if (n_tasks_ > n_direct_tasks_) {                        // streams of blocks with sequences: to the literal buffer
+        if (timer) timer->begin(stream, StageTimer::kHuf);
+        launch_huf_decode(stream, d_src_, d_tasks_.as<HufTask>() + n_direct_tasks_,
+                          static_cast<uint32_t>(n_tasks_ - n_direct_tasks_), d_tbl_copies_.as<HufTblCopy>(),
+                          d_streams_.as<HufStream>(), d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), d_out_.bytes(),
+                          d_lit_.bytes(), max_tbl_lit_, false, t_char_, status);
         if (timer) timer->end(stream);
     }
     if (n_seq_blocks_) {
         if (timer) timer->begin(stream, StageTimer::kSeqLz);
         launch_lz_execute(stream, d_seq_blocks_.as<SeqBlock>(), static_cast<uint32_t>(n_seq_blocks_), d_seqs_.as<Seq>(),
-                          d_lit_.bytes(), d_blk_base_.as<uint64_t>(), d_out_.bytes(), status);
+                          d_lit_.bytes(), d_blk_base_.as<uint64_t>(), d_out_.bytes(), ascii, t_char_, status);
         if (timer) timer->end(stream);
     }
 }
@@ -259,8 +272,9 @@ Failure ArchiveJob::upload(const uint8_t *bytes, size_t n, const nafgpu_header &
         }
         uint64_t expect = sec[s].original_size;
         if (s == kSequence && is_nuc_) expect = (expect + 1) / 2;     // nucleotides -> packed bytes
+        const uint32_t t_char = (s == kSequence && is_nuc_) ? (h.sequence_type == 1 ? 'U' : 'T') : 0;
         fail_[s] = job_[s].prepare(bytes + sec[s].offset, static_cast<size_t>(sec[s].compressed_size), expect,
-                                   d_archive_.bytes() + kSrcFrontPad + sec[s].offset, stream_);
+                                   d_archive_.bytes() + kSrcFrontPad + sec[s].offset, stream_, t_char);
         plan_ms_ += job_[s].host_plan_ms();
         if (fail_[s].status == NAFGPU_E_DEVICE) return fail_[s];
         if (fail_[s].ok()) compressed_ += sec[s].compressed_size;
@@ -277,7 +291,6 @@ Failure ArchiveJob::upload(const uint8_t *bytes, size_t n, const nafgpu_header &
         ok = ok && d_mask_ends_.alloc((mask_cap_ + 1) * sizeof(uint64_t));
     }
     ok = ok && d_scan_tmp_.alloc(scan_tmp_bytes(std::max(rec_cap_, mask_cap_)));
-    if (job_[kSequence].ready() && is_nuc_) ok = ok && d_ascii_.alloc(static_cast<size_t>(2 * job_[kSequence].size()) + 64);
     if (!ok) return Failure::make(NAFGPU_E_DEVICE, "out of device memory");
     return Failure();
 }
@@ -297,17 +310,13 @@ Failure ArchiveJob::decode() {
                              d_scan_tmp_.bytes(), &totals[0], status);
         timer_.end(stream_);
     }
-    if (job_[kSequence].ready() && is_nuc_) {                      // SequenceReader, reader.rs:121-172
-        timer_.begin(stream_, StageTimer::kUnpack);
-        launch_unpack4(stream_, job_[kSequence].out(), job_[kSequence].size(), d_ascii_.bytes(),
-                       2 * job_[kSequence].size(), h_.sequence_type == 1 ? 'U' : 'T', status);
-        timer_.end(stream_);
-    }
+    // (nucleotide sequence sections come out of their SectionJob already expanded to ASCII:
+    //  SequenceReader::read_nucleotide, reader.rs:121-172, is fused into the zstd kernels)
     if (job_[kMask].ready() && job_[kSequence].ready() && job_[kLengths].ready()) {   // mod.rs:386-388, 402-441
         timer_.begin(stream_, StageTimer::kOther);
         launch_scan_runs_u8(stream_, job_[kMask].out(), mask_cap_, d_mask_ends_.as<uint64_t>(), mask_cap_,
                             d_scan_tmp_.bytes(), &totals[1], status);
-        uint8_t *seq = is_nuc_ ? d_ascii_.bytes() : job_[kSequence].out_mut();
+        uint8_t *seq = job_[kSequence].out_mut();
         const uint64_t n_seq = is_nuc_ ? mask_total_bases_ : std::min<uint64_t>(mask_total_bases_, job_[kSequence].size());
         launch_mask_apply(stream_, seq, std::min<uint64_t>(n_seq, n_sequence_bytes()), d_mask_ends_.as<uint64_t>(),
                           &totals[1], d_rec_ends_.as<uint64_t>(), &totals[0], mask_cap_, opt_.spec_mask ? 1 : 0, status);
@@ -332,12 +341,12 @@ Failure ArchiveJob::decode() {
 
 const uint8_t *ArchiveJob::d_sequence() const {
     if (!job_[kSequence].ready()) return nullptr;
-    return is_nuc_ ? d_ascii_.bytes() : job_[kSequence].out();
+    return job_[kSequence].out();
 }
 
 uint64_t ArchiveJob::n_sequence_bytes() const {
     if (!job_[kSequence].ready()) return 0;
-    return is_nuc_ ? 2 * job_[kSequence].size() : job_[kSequence].size();
+    return job_[kSequence].out_bytes();
 }
 
 Failure ArchiveJob::copy_to_host(void *dst, const void *d_src, size_t n) {

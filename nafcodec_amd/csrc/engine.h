@@ -78,8 +78,11 @@ class SectionJob {
 public:
     // Walks the payload on the host (zplan), allocates HBM, uploads the task lists.
     // d_payload points at the same bytes in device memory (>= 256 B readable in front, 64 behind).
+    // ascii_t_char != 0: nucleotide sequence section -- every byte bound for the section output is
+    // expanded to its two IUPAC characters on the way ('T' / 'U' for code 1); out() then holds
+    // 2 * size() ASCII bytes and the packed form never exists in HBM.
     Failure prepare(const uint8_t *host_payload, size_t n, uint64_t expect_size, const uint8_t *d_payload,
-                    hipStream_t stream);
+                    hipStream_t stream, uint32_t ascii_t_char = 0);
     // Enqueues the decode kernels.  Results: out() holds size() bytes once the stream is done.
     void run(hipStream_t stream, StageTimer *timer);
     // After synchronisation: device status -> Failure
@@ -87,7 +90,9 @@ public:
 
     const uint8_t *out() const { return d_out_.bytes(); }
     uint8_t *out_mut() const { return d_out_.bytes(); }
-    uint64_t size() const { return expect_; }
+    uint64_t size() const { return expect_; }                       // decoded zstd bytes
+    uint64_t out_bytes() const { return expect_ * (t_char_ ? 2 : 1); }   // bytes behind out()
+    bool ascii() const { return t_char_ != 0; }
     bool ready() const { return ready_; }
     const ZPlan &plan() const { return plan_; }
     uint64_t n_blocks() const { return n_blocks_; }
@@ -97,7 +102,7 @@ public:
 private:
     ZPlan plan_;
     uint64_t expect_ = 0, n_blocks_ = 0, n_streams_ = 0, n_tasks_ = 0, n_copies_ = 0, n_seq_blocks_ = 0;
-    uint32_t max_tbl_entries_ = 0;
+    uint32_t max_tbl_direct_ = 0, max_tbl_lit_ = 0, n_direct_tasks_ = 0, t_char_ = 0;
     const uint8_t *d_src_ = nullptr;
     float plan_ms_ = 0;
     bool ready_ = false;
@@ -153,7 +158,7 @@ private:
     DevBuf d_archive_;
     SectionJob job_[kNumSections];
     Failure fail_[kNumSections];
-    DevBuf d_ascii_, d_rec_ends_, d_mask_ends_, d_scan_tmp_, d_totals_, d_status_, d_hash_;
+    DevBuf d_rec_ends_, d_mask_ends_, d_scan_tmp_, d_totals_, d_status_, d_hash_;
     uint64_t rec_cap_ = 0, mask_cap_ = 0, mask_total_bases_ = 0;
     ScanTotals rec_totals_{0, 0}, mask_totals_{0, 0};
     float plan_ms_ = 0, h2d_ms_ = 0;

@@ -32,19 +32,23 @@ void launch_scan_runs_u8(hipStream_t stream, const uint8_t *bytes, uint64_t n_by
                          void *tile_tmp, ScanTotals *totals, uint32_t *status);
 
 // raw / RLE blocks and literal sections
+// ascii = true (nucleotide sequence sections): bytes bound for `out` are expanded to two IUPAC
+// characters each on the way (t_char = 'T' DNA / 'U' RNA); bytes bound for `lit` stay packed.
 void launch_copy_fill(hipStream_t stream, const uint8_t *src, const CopyTask *tasks, uint32_t n_tasks,
-                      const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t *status);
+                      const uint64_t *blk_base, uint8_t *out, uint8_t *lit, bool ascii, uint32_t t_char,
+                      uint32_t *status);
 
 // K1: Huffman literal streams, one lane per stream, one wave per task.
 // max_tbl_entries = largest staged-table footprint over the tasks (sizes the dynamic LDS).
 void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *tasks, uint32_t n_tasks,
                        const HufTblCopy *copies, const HufStream *streams, const uint16_t *pool,
-                       const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t max_tbl_entries,
-                       uint32_t *status);
+                       const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t max_tbl_entries, bool ascii,
+                       uint32_t t_char, uint32_t *status);
 
 // K4: LZ77 sequence execution (literal scatter + ordered match copy)
 void launch_lz_execute(hipStream_t stream, const SeqBlock *blocks, uint32_t n_blocks, const Seq *seqs,
-                       const uint8_t *lit, const uint64_t *blk_base, uint8_t *out, uint32_t *status);
+                       const uint8_t *lit, const uint64_t *blk_base, uint8_t *out, bool ascii, uint32_t t_char,
+                       uint32_t *status);
 
 // K5: 4-bit -> IUPAC ASCII; t_char = 'T' (DNA) or 'U' (RNA)
 void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed, uint8_t *ascii, uint64_t n_bases,

@@ -12,6 +12,8 @@
 // Reference counterparts are cited per kernel.  Format: RFC 8878 / SURVEY.md Appendix B.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "hash64.h"
 #include "kernels.h"
 #include "plan.h"
@@ -30,8 +32,13 @@ __device__ inline void flag_error(uint32_t *status, uint32_t code, uint32_t deta
 // One wave per task, one lane per stream.  Each lane walks its backward
 // bitstream with a 64-bit window {hi, lo} plus one look-ahead word; words come from a per-lane
 // 16-word ring in LDS that the lane refills with 16-byte aligned global loads (one chunk in
-// flight).  Symbols are packed four to a dword, staged as 64-byte rows in LDS and flushed
-// cooperatively so that every global store instruction writes whole 64-byte segments.
+// flight).  Decoded bytes are staged as 64-byte rows in LDS and flushed cooperatively so that
+// every global store instruction writes whole 64-byte segments.
+//
+// ASCII = true is the fused DNA/RNA form: the 4-bit -> IUPAC expansion of
+// SequenceReader::read_nucleotide / decode (reader.rs:121-172) is folded into the Huffman
+// table while it is staged in LDS -- an entry holds the symbol's TWO output characters -- so
+// the kernel writes final ASCII bases and the packed intermediate never touches HBM.
 constexpr int kRowWords = 20;        // 80-byte padded LDS rows (64 used): conflict-free b128 access
 constexpr int kRingMask = 15;
 
@@ -41,28 +48,46 @@ struct HufLane {
     uint32_t rp;           // ring index of hi
 };
 
-#define HUF_STEP(ACC, SHIFT, LEN_EXPR)                                                        \
-    {                                                                                         \
-        const uint32_t peek = __builtin_amdgcn_alignbit(L.hi, L.lo, 32u - L.c); /* c = 32 -> shift 0 -> lo */ \
-        const uint32_t e = tbl[peek >> sh];                                                   \
-        const uint32_t len = (LEN_EXPR);                                                      \
-        L.c += len;                                                                           \
-        ACC |= (e & 0xFFu) << (SHIFT);                                                        \
-        const bool adv = L.c > 32u;                                                           \
-        L.hi = adv ? L.lo : L.hi;                                                             \
-        L.lo = adv ? L.nw : L.lo;                                                             \
-        L.c = adv ? L.c - 32u : L.c;                                                          \
-        L.rp += adv ? 1u : 0u;                                                                \
-        L.nw = ring[(L.rp + 2u) & kRingMask];                                                 \
-    }
+// "-TGKCYSBAWRDMHVN"[nib], with index 1 = t_char ('T' for DNA, 'U' for RNA)  (reader.rs:152-172)
+__device__ inline uint32_t nib_char(uint32_t nib, uint32_t t_char) {
+    const uint64_t lo = 0x425359434B47002Dull | (static_cast<uint64_t>(t_char) << 8);   // - T G K C Y S B
+    const uint64_t hi = 0x4E56484D44525741ull;                                          // A W R D M H V N
+    return static_cast<uint32_t>(((nib & 8u) ? hi : lo) >> (8u * (nib & 7u))) & 0xFFu;
+}
+// both characters of one packed byte: low nibble first (reader.rs:131-136)
+__device__ inline uint32_t byte_chars(uint32_t b, uint32_t t_char) {
+    return nib_char(b & 15u, t_char) | (nib_char(b >> 4, t_char) << 8);
+}
 
+// one symbol: table look-up on the next max_bits bits, then advance the window
+template <bool ASCII>
+__device__ inline uint32_t huf_step(HufLane &L, const void *tbl, uint32_t sh, const uint32_t *ring, bool live) {
+    const uint32_t peek = __builtin_amdgcn_alignbit(L.hi, L.lo, 32u - L.c);   // c = 32 -> shift 0 -> lo
+    const uint32_t idx = peek >> sh;
+    const uint32_t e = ASCII ? static_cast<const uint32_t *>(tbl)[idx] : static_cast<const uint16_t *>(tbl)[idx];
+    const uint32_t len = ASCII ? e >> 16 : e >> 8;
+    L.c += live ? len : 0u;
+    const bool adv = L.c > 32u;
+    L.hi = adv ? L.lo : L.hi;
+    L.lo = adv ? L.nw : L.lo;
+    L.c = adv ? L.c - 32u : L.c;
+    L.rp += adv ? 1u : 0u;
+    L.nw = ring[(L.rp + 2u) & kRingMask];
+    return e;
+}
+
+template <bool ASCII>
 __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ src, const HufTask *__restrict__ tasks,
                                                    const HufTblCopy *__restrict__ copies,
                                                    const HufStream *__restrict__ streams,
                                                    const uint16_t *__restrict__ pool,
                                                    const uint64_t *__restrict__ blk_base, uint8_t *out, uint8_t *lit,
-                                                   uint32_t *status) {
-    HIP_DYNAMIC_SHARED(uint16_t, s_tbl)
+                                                   uint32_t t_char, uint32_t *status) {
+    constexpr uint32_t kEntryBytes = ASCII ? 4 : 2;
+    constexpr uint32_t kGroups = ASCII ? 4 : 8;            // groups of 8 symbols per 64-byte row
+    constexpr uint32_t kRound = 8 * kGroups;               // symbols per flush
+    constexpr uint32_t kOutBytes = ASCII ? 2 : 1;          // bytes written per symbol
+    HIP_DYNAMIC_SHARED(uint8_t, s_tbl)
     __shared__ __attribute__((aligned(16))) uint32_t s_ring[64 * kRowWords];
     __shared__ __attribute__((aligned(16))) uint32_t s_out[64 * kRowWords];
     __shared__ uint64_t s_dst[64];
@@ -75,7 +100,13 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
 
     for (uint32_t k = 0; k < task.n_copies; k++) {
         const HufTblCopy cp = copies[task.first_copy + k];
-        for (uint32_t e = lane; e < cp.n_entries; e += 64) s_tbl[cp.lds_off + e] = pool[cp.pool_off + e];
+        for (uint32_t e = lane; e < cp.n_entries; e += 64) {
+            const uint32_t p = pool[cp.pool_off + e];      // len << 8 | symbol
+            if (ASCII)
+                reinterpret_cast<uint32_t *>(s_tbl)[cp.lds_off + e] = ((p >> 8) << 16) | byte_chars(p & 0xFFu, t_char);
+            else
+                reinterpret_cast<uint16_t *>(s_tbl)[cp.lds_off + e] = static_cast<uint16_t>(p);
+        }
     }
     if (lane == 0) s_nmax = 0;
 
@@ -84,7 +115,7 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     if (have) st = streams[task.first_stream + lane];
     const uint32_t n = st.n_syms;
     const uint32_t sh = 32u - st.max_bits;
-    const uint16_t *tbl = s_tbl + st.tbl_lds;
+    const void *tbl = s_tbl + static_cast<size_t>(st.tbl_lds) * kEntryBytes;
     uint32_t *ring = s_ring + lane * kRowWords;
     uint32_t *orow = s_out + lane * kRowWords;
 
@@ -116,8 +147,8 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         L.hi = ring[L.rp];
         L.lo = ring[L.rp + 1];
         L.nw = ring[L.rp + 2];
-        // destination as an offset; bit 63 selects the literal buffer
-        s_dst[lane] = (st.flags & 1) ? (st.dst | (1ull << 63)) : blk_base[st.blk] + st.dst;
+        // destination as a byte offset; bit 63 selects the literal buffer
+        s_dst[lane] = (st.flags & 1) ? (st.dst | (1ull << 63)) : kOutBytes * (blk_base[st.blk] + st.dst);
     } else {
         s_dst[lane] = 0;
     }
@@ -127,10 +158,10 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     __syncthreads();
     const uint32_t nmax = s_nmax;
 
-    for (uint32_t base = 0; base < nmax; base += 64) {
+    for (uint32_t base = 0; base < nmax; base += kRound) {
         if (base < n) {
 #pragma unroll 1
-            for (uint32_t g = 0; g < 8; g++) {
+            for (uint32_t g = 0; g < kGroups; g++) {
                 const uint32_t i0 = base + g * 8;
                 if (i0 >= n) break;
                 // ---- service the input ring: land the chunk in flight, then issue the next one
@@ -142,27 +173,23 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
                     pend = *reinterpret_cast<const uint4 *>(ctop - 16 * static_cast<size_t>(lp));
                     lp++;
                 }
-                uint32_t a0 = 0, a1 = 0;
+                uint32_t e[8];
                 if (i0 + 8 <= n) {
-                    HUF_STEP(a0, 0, e >> 8)
-                    HUF_STEP(a0, 8, e >> 8)
-                    HUF_STEP(a0, 16, e >> 8)
-                    HUF_STEP(a0, 24, e >> 8)
-                    HUF_STEP(a1, 0, e >> 8)
-                    HUF_STEP(a1, 8, e >> 8)
-                    HUF_STEP(a1, 16, e >> 8)
-                    HUF_STEP(a1, 24, e >> 8)
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) e[k] = huf_step<ASCII>(L, tbl, sh, ring, true);
                 } else {                                         // last group of this stream: freeze past n
-                    HUF_STEP(a0, 0, (i0 + 0 < n) ? e >> 8 : 0u)
-                    HUF_STEP(a0, 8, (i0 + 1 < n) ? e >> 8 : 0u)
-                    HUF_STEP(a0, 16, (i0 + 2 < n) ? e >> 8 : 0u)
-                    HUF_STEP(a0, 24, (i0 + 3 < n) ? e >> 8 : 0u)
-                    HUF_STEP(a1, 0, (i0 + 4 < n) ? e >> 8 : 0u)
-                    HUF_STEP(a1, 8, (i0 + 5 < n) ? e >> 8 : 0u)
-                    HUF_STEP(a1, 16, (i0 + 6 < n) ? e >> 8 : 0u)
-                    HUF_STEP(a1, 24, (i0 + 7 < n) ? e >> 8 : 0u)
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) e[k] = huf_step<ASCII>(L, tbl, sh, ring, i0 + k < n);
                 }
-                *reinterpret_cast<uint2 *>(orow + 2 * g) = make_uint2(a0, a1);
+                if (ASCII) {
+                    *reinterpret_cast<uint4 *>(orow + 4 * g) =
+                        make_uint4((e[0] & 0xFFFFu) | (e[1] << 16), (e[2] & 0xFFFFu) | (e[3] << 16),
+                                   (e[4] & 0xFFFFu) | (e[5] << 16), (e[6] & 0xFFFFu) | (e[7] << 16));
+                } else {
+                    *reinterpret_cast<uint2 *>(orow + 2 * g) =
+                        make_uint2((e[0] & 0xFFu) | ((e[1] & 0xFFu) << 8) | ((e[2] & 0xFFu) << 16) | (e[3] << 24),
+                                   (e[4] & 0xFFu) | ((e[5] & 0xFFu) << 8) | ((e[6] & 0xFFu) << 16) | (e[7] << 24));
+                }
             }
         }
         __syncthreads();
@@ -173,11 +200,11 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
             const uint32_t col = (lane & 3) * 16;
             const uint32_t rn = s_n[row];
             if (rn > base) {
-                const uint32_t valid = rn - base < 64u ? rn - base : 64u;
+                const uint32_t valid = (rn - base < kRound ? rn - base : kRound) * kOutBytes;   // bytes
                 if (col < valid) {
                     const uint4 v = *reinterpret_cast<const uint4 *>(s_out + row * kRowWords + (col >> 2));
                     const uint64_t doff = s_dst[row];
-                    uint8_t *d = ((doff >> 63) ? lit : out) + (doff & ~(1ull << 63)) + base + col;
+                    uint8_t *d = ((doff >> 63) ? lit : out) + (doff & ~(1ull << 63)) + static_cast<uint64_t>(base) * kOutBytes + col;
                     if (col + 16 <= valid) {
                         if ((reinterpret_cast<uintptr_t>(d) & 15) == 0) {
                             *reinterpret_cast<uint4 *>(d) = v;
@@ -431,18 +458,22 @@ __global__ void k_scan_finish_blocks(uint64_t *blk_base, uint64_t n, const ScanT
 // ======================================================================================
 // Raw / RLE blocks and literal sections
 // ======================================================================================
+template <bool ASCII>
 __global__ __launch_bounds__(256) void k_copy_fill(const uint8_t *__restrict__ src, const CopyTask *__restrict__ tasks,
                                                    const uint64_t *__restrict__ blk_base, uint8_t *out, uint8_t *lit,
-                                                   const uint32_t *status) {
+                                                   uint32_t t_char, const uint32_t *status) {
     if (status[0] != 0) return;
     const CopyTask t = tasks[blockIdx.x];
-    uint8_t *d = (t.flags & 1) ? lit + t.dst : out + blk_base[t.blk] + t.dst;
-    if (t.flags & 2) {
-        const uint8_t v = static_cast<uint8_t>(t.src_off);
-        for (uint32_t i = threadIdx.x; i < t.len; i += blockDim.x) d[i] = v;
+    const bool fill = (t.flags & 2) != 0;
+    const uint8_t fv = static_cast<uint8_t>(t.src_off);
+    const uint8_t *s = src + (fill ? 0 : t.src_off);
+    if (ASCII && !(t.flags & 1)) {                       // nucleotide section: expand while copying
+        uint16_t *d = reinterpret_cast<uint16_t *>(out) + blk_base[t.blk] + t.dst;
+        for (uint32_t i = threadIdx.x; i < t.len; i += blockDim.x)
+            d[i] = static_cast<uint16_t>(byte_chars(fill ? fv : s[i], t_char));
     } else {
-        const uint8_t *s = src + t.src_off;
-        for (uint32_t i = threadIdx.x; i < t.len; i += blockDim.x) d[i] = s[i];
+        uint8_t *d = (t.flags & 1) ? lit + t.dst : out + blk_base[t.blk] + t.dst;
+        for (uint32_t i = threadIdx.x; i < t.len; i += blockDim.x) d[i] = fill ? fv : s[i];
     }
 }
 
@@ -453,10 +484,16 @@ __global__ __launch_bounds__(256) void k_copy_fill(const uint8_t *__restrict__ s
 // cross-block dependency (repeat offsets, window matches) is satisfied by construction.
 // Literal-only blocks were already written by K1.  Inside a batch of 256 sequences the
 // literal copies run in parallel and the matches in order (a match may read the previous one).
+// ASCII = true: the output is the expanded base stream (two characters per packed byte), so a
+// match of `ml` packed bytes at distance `off` copies ml 16-bit elements at distance off, and
+// literals are expanded while they are scattered.  The ASCII buffer itself is the LZ window.
+template <bool ASCII>
 __global__ __launch_bounds__(256) void k_lz_execute(const SeqBlock *__restrict__ blocks, uint32_t n_blocks,
                                                     const Seq *__restrict__ seqs, const uint8_t *__restrict__ lit,
-                                                    const uint64_t *__restrict__ blk_base, uint8_t *out,
-                                                    uint32_t *status) {
+                                                    const uint64_t *__restrict__ blk_base, uint8_t *out_bytes,
+                                                    uint32_t t_char, uint32_t *status) {
+    using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
+    Elem *out = reinterpret_cast<Elem *>(out_bytes);
     __shared__ uint32_t s_ll[256], s_ml[256], s_off[256], s_lpos[256];
     __shared__ uint64_t s_opos[256];
     __shared__ uint64_t s_rep[3];
@@ -538,18 +575,18 @@ __global__ __launch_bounds__(256) void k_lz_execute(const SeqBlock *__restrict__
             }
             __syncthreads();
             if (tid < cnt) {                             // literal runs: independent of each other
-                uint8_t *d = out + s_opos[tid];
+                Elem *d = out + s_opos[tid];
                 const uint8_t *s = blit + s_lpos[tid];
                 const uint32_t ll = s_ll[tid];
-                for (uint32_t k = 0; k < ll; k++) d[k] = s[k];
+                for (uint32_t k = 0; k < ll; k++) d[k] = ASCII ? static_cast<Elem>(byte_chars(s[k], t_char)) : static_cast<Elem>(s[k]);
             }
             __syncthreads();
             for (uint32_t i = 0; i < cnt; i++) {         // matches: in order
                 const uint32_t mlf = s_ml[i];
                 if (!(mlf & 0x80000000u)) {
                     const uint32_t ml = mlf, off = s_off[i];
-                    uint8_t *d = out + s_opos[i] + s_ll[i];
-                    const uint8_t *s = d - off;
+                    Elem *d = out + s_opos[i] + s_ll[i];
+                    const Elem *s = d - off;
                     if (off >= ml) {
                         for (uint32_t k = tid; k < ml; k += 256) d[k] = s[k];
                     } else {
@@ -561,8 +598,9 @@ __global__ __launch_bounds__(256) void k_lz_execute(const SeqBlock *__restrict__
         }
         {                                                // literals after the last sequence
             const uint32_t l = s_cur_l;
-            uint8_t *d = out + s_cur_o;
-            for (uint32_t k = tid; k < sb.lit_size - l; k += 256) d[k] = blit[l + k];
+            Elem *d = out + s_cur_o;
+            for (uint32_t k = tid; k < sb.lit_size - l; k += 256)
+                d[k] = ASCII ? static_cast<Elem>(byte_chars(blit[l + k], t_char)) : static_cast<Elem>(blit[l + k]);
         }
         __syncthreads();
     }
@@ -771,25 +809,41 @@ void launch_scan_runs_u8(hipStream_t stream, const uint8_t *bytes, uint64_t n_by
 }
 
 void launch_copy_fill(hipStream_t stream, const uint8_t *src, const CopyTask *tasks, uint32_t n_tasks,
-                      const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t *status) {
+                      const uint64_t *blk_base, uint8_t *out, uint8_t *lit, bool ascii, uint32_t t_char,
+                      uint32_t *status) {
     if (!n_tasks) return;
-    hipLaunchKernelGGL(k_copy_fill, dim3(n_tasks), dim3(256), 0, stream, src, tasks, blk_base, out, lit, status);
+    if (ascii)
+        hipLaunchKernelGGL(k_copy_fill<true>, dim3(n_tasks), dim3(256), 0, stream, src, tasks, blk_base, out, lit, t_char,
+                           status);
+    else
+        hipLaunchKernelGGL(k_copy_fill<false>, dim3(n_tasks), dim3(256), 0, stream, src, tasks, blk_base, out, lit, t_char,
+                           status);
 }
 
 void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *tasks, uint32_t n_tasks,
                        const HufTblCopy *copies, const HufStream *streams, const uint16_t *pool,
-                       const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t max_tbl_entries,
-                       uint32_t *status) {
+                       const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t max_tbl_entries, bool ascii,
+                       uint32_t t_char, uint32_t *status) {
     if (!n_tasks) return;
-    const uint32_t lds = ((max_tbl_entries * 2u) + 15u) & ~15u;
-    hipLaunchKernelGGL(k_huf_decode, dim3(n_tasks), dim3(64), lds, stream, src, tasks, copies, streams, pool, blk_base,
-                       out, lit, status);
+    const uint32_t lds = ((max_tbl_entries * (ascii ? 4u : 2u)) + 15u) & ~15u;
+    if (ascii)
+        hipLaunchKernelGGL(k_huf_decode<true>, dim3(n_tasks), dim3(64), lds, stream, src, tasks, copies, streams, pool,
+                           blk_base, out, lit, t_char, status);
+    else
+        hipLaunchKernelGGL(k_huf_decode<false>, dim3(n_tasks), dim3(64), lds, stream, src, tasks, copies, streams, pool,
+                           blk_base, out, lit, t_char, status);
 }
 
 void launch_lz_execute(hipStream_t stream, const SeqBlock *blocks, uint32_t n_blocks, const Seq *seqs,
-                       const uint8_t *lit, const uint64_t *blk_base, uint8_t *out, uint32_t *status) {
+                       const uint8_t *lit, const uint64_t *blk_base, uint8_t *out, bool ascii, uint32_t t_char,
+                       uint32_t *status) {
     if (!n_blocks) return;
-    hipLaunchKernelGGL(k_lz_execute, dim3(1), dim3(256), 0, stream, blocks, n_blocks, seqs, lit, blk_base, out, status);
+    if (ascii)
+        hipLaunchKernelGGL(k_lz_execute<true>, dim3(1), dim3(256), 0, stream, blocks, n_blocks, seqs, lit, blk_base, out,
+                           t_char, status);
+    else
+        hipLaunchKernelGGL(k_lz_execute<false>, dim3(1), dim3(256), 0, stream, blocks, n_blocks, seqs, lit, blk_base, out,
+                           t_char, status);
 }
 
 void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed, uint8_t *ascii, uint64_t n_bases,

@@ -632,7 +632,24 @@ struct Walker {
     }
 
     // Greedy packing of streams into wave tasks: <= 64 lanes, decode tables <= kHufLdsEntries.
+    // Streams that write the section output directly come first, those that feed the literal
+    // buffer of a block with sequences second: the two groups are launched separately (the
+    // first one may expand 4-bit codes to ASCII on the fly, the second never does).
     void pack_tasks() {
+        {   // stable partition by destination
+            std::vector<HufStream> ordered;
+            std::vector<HufRef> ordered_tbl;
+            ordered.reserve(plan->streams.size());
+            ordered_tbl.reserve(plan->streams.size());
+            for (int pass = 0; pass < 2; pass++)
+                for (size_t s = 0; s < plan->streams.size(); s++)
+                    if ((plan->streams[s].flags & 1) == pass) {
+                        ordered.push_back(plan->streams[s]);
+                        ordered_tbl.push_back(stream_tbl[s]);
+                    }
+            plan->streams.swap(ordered);
+            stream_tbl.swap(ordered_tbl);
+        }
         struct Slot {
             uint32_t pool_off, lds_off;
         };
@@ -648,7 +665,13 @@ struct Walker {
             slots.clear();
             lds_used = 0;
         };
+        size_t first_lit = 0;
+        while (first_lit < plan->streams.size() && !(plan->streams[first_lit].flags & 1)) first_lit++;
         for (size_t s = 0; s < plan->streams.size(); s++) {
+            if (s == first_lit) {                           // group boundary: never share a task
+                close();
+                plan->n_direct_tasks = static_cast<uint32_t>(plan->tasks.size());
+            }
             const HufRef &t = stream_tbl[s];
             const uint32_t entries = 1u << t.max_bits;
             auto find = [&]() -> int {
@@ -672,6 +695,7 @@ struct Walker {
             if (cur.n_streams == kHufWave) close();
         }
         close();
+        if (first_lit == plan->streams.size()) plan->n_direct_tasks = static_cast<uint32_t>(plan->tasks.size());
     }
 };
 

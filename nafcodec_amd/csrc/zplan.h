@@ -22,7 +22,8 @@ struct ZPlan {
                                          // (k_seq_decode adds the match bytes on the device)
     // Huffman literals
     std::vector<HufStream> streams;
-    std::vector<HufTask> tasks;
+    std::vector<HufTask> tasks;          // the first n_direct_tasks write the section output, the rest the literal buffer
+    uint32_t n_direct_tasks = 0;
     std::vector<HufTblCopy> tbl_copies;
     std::vector<uint16_t> huf_pool;      // decode tables, (len << 8 | symbol)
     // raw / RLE

@@ -111,10 +111,10 @@ def main():
     t_upload = time.perf_counter() - t0
 
     res = _ffi.DeviceResult()
-    gather_in = gather_out = None
+    scratch = placement = None
     if world > 1:
-        gather_in = torch.zeros(4, dtype=torch.int64, device="cuda")
-        gather_out = torch.zeros(4 * world, dtype=torch.int64, device="cuda")
+        from nafcodec_amd.sharding import gather_placement
+        scratch = (torch.zeros(4, dtype=torch.int64, device="cuda"), torch.zeros(4 * world, dtype=torch.int64, device="cuda"))
 
     def step():
         rc = lib.c.nafgpu_decode_all_device(h, ctypes.byref(res))
@@ -122,10 +122,11 @@ def main():
             lib.c.nafgpu_last_error(h, ctypes.byref(err))
             raise RuntimeError("decode failed: %s" % err.message.decode())
         if world > 1:
-            # the one exchange step of the sharded path: per-rank counts -> global record/base offsets
-            gather_in.copy_(torch.tensor([res.n_bases, res.packed_bytes, res.n_records, res.n_bases & 1],
-                                         dtype=torch.int64), non_blocking=False)
-            dist.all_gather_into_tensor(gather_out, gather_in)
+            # the one exchange step of the sharded path (RCCL all-gather of 32 B per rank):
+            # per-rank counts -> global base / record offsets of this shard
+            nonlocal placement
+            placement = gather_placement(dist, torch, res.n_bases, res.packed_bytes, res.n_records,
+                                         res.n_bases & 1, "cuda", scratch)
 
     def sync():
         if world > 1:
@@ -150,10 +151,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        g = gather_out.view(world, 4).cpu()
-        total_bases = int(g[:, 0].sum())
-        base_offset = int(g[:rank, 0].sum())        # where this shard's first base lands globally
-        assert base_offset >= 0
+        total_bases = placement.total_bases
     else:
         total_bases = int(res.n_bases)
 

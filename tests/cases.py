@@ -1,0 +1,148 @@
+"""Archive cases shared by the CPU-harness tests (tests/test_emu_parity.py) and the GPU parity
+tests (tests/test_gpu_parity.py).  Every case is (name, archive bytes, decoder options); the
+expected result is whatever the CPU oracle produces for the same bytes and options.
+
+Covers the reference-test gaps listed in SURVEY.md section 4: masked runs reaching / crossing record
+ends, runs of exactly 255*k, lengths >= 2^32-1, many-block frames, truncated streams,
+zero-length records, RNA, title section."""
+import numpy as np
+
+import naf_writer as nw
+
+
+def rand_dna(rng, n, alphabet="ACGT", iupac=0.0):
+    s = rng.choice(list(alphabet), n)
+    if iupac and n:
+        k = rng.random(n) < iupac
+        s[k] = rng.choice(list("NRYKMSWBDHV-"), int(k.sum()))
+    return "".join(s)
+
+
+def make_records(rng, lengths, alphabet="ACGT", iupac=0.0, quality=False):
+    recs = []
+    for i, n in enumerate(lengths):
+        r = {"id": "rec%d" % i, "comment": "" if i % 3 == 0 else "comment number %d é" % i,
+             "sequence": rand_dna(rng, n, alphabet, iupac)}
+        if quality:
+            r["quality"] = "".join(rng.choice(list("#8CGGGGGG<AFFJJ"), n))
+        recs.append(r)
+    return recs
+
+
+def build_cases(scale=1):
+    """scale=1: sizes the CPU harness decodes in seconds; larger scales for the GPU."""
+    rng = np.random.default_rng(0x4E4146)
+    cases = []
+
+    def add(name, blob, **opts):
+        cases.append((name, blob, opts))
+
+    lens = [0, 1, 2, 151, 151, 0, 17, 21, 1000, 4097, 70001 * scale, 3, 0, 999]
+    for level in (1, 3, 19):
+        recs = make_records(rng, lens, iupac=0.01)
+        add("dna_l%d" % level, nw.write_naf(recs, level=level))
+    add("dna_l3_big", nw.write_naf(make_records(rng, [300000 * scale, 151, 500001 * scale]), level=3))
+    add("dna_repeats_l1", nw.write_naf([{"id": "r", "sequence": rand_dna(rng, 5000) * (40 * scale)}], level=1))
+    add("dna_homopolymer", nw.write_naf([{"id": "a", "sequence": "A" * (400001 * scale)},
+                                         {"id": "n", "sequence": "N" * 70000}], level=3))
+    add("rna_l3", nw.write_naf(make_records(rng, [33, 0, 100001, 7], alphabet="ACGU"), sequence_type="rna", level=3))
+    add("protein_l3", nw.write_naf(make_records(rng, [488, 477, 0, 30001], alphabet="ACDEFGHIKLMNPQRSTVWY"),
+                                   sequence_type="protein", level=3))
+    add("text_quality", nw.write_naf(make_records(rng, [301] * 40 + [95, 0, 7], iupac=0.02, quality=True),
+                                     quality=True, level=3, line_length=301))
+    add("fastq_flush_per_record", nw.write_naf(make_records(rng, [151] * 300, quality=True), quality=True, level=3,
+                                               zstd_kwargs={"flush_every": 151}))
+    add("title_and_extended", nw.write_naf(make_records(rng, [10, 20, 30]), title="a title ✓", extended=True))
+    add("v2_dna", nw.write_naf(make_records(rng, [100, 101]), version=2))
+    add("no_ids_no_comments", nw.write_naf(make_records(rng, [5, 6, 7]), ids=False, comments=False))
+    add("lengths_only_big", nw.write_naf([{"id": "x"}], sequence=False, comments=False,
+                                         raw_sections={"lengths": nw.length_words([0xFFFFFFFF + 5, 7, 0xFFFFFFFF * 2])},
+                                         number_of_sequences=3))
+    add("more_records_than_lengths", nw.write_naf(make_records(rng, [4, 5]), number_of_sequences=4))
+    add("fewer_records_than_lengths", nw.write_naf(make_records(rng, [4, 5, 6]), number_of_sequences=2))
+    add("checksum_frames", nw.write_naf(make_records(rng, [50000, 3]), level=3, zstd_kwargs={"checksum": True}))
+
+    # ---- mask ------------------------------------------------------------------------------
+    recs = make_records(rng, [1550, 1800, 0, 700, 255, 510, 1000])
+    total = sum(len(r["sequence"]) for r in recs)
+    inside = [657, 19, 635, 39, 725, 96, 99, 13]                     # masked.naf-like, runs inside records
+    inside.append(total - sum(inside))
+    add("mask_inside_records", nw.write_naf(recs, mask_runs=inside))
+    crossing = [1500, 100, 1700, 50, 0, 0, 700, 255, 255, 510, 100]  # runs reaching / crossing record ends
+    crossing.append(total - sum(crossing))
+    add("mask_crossing_record_ends", nw.write_naf(recs, mask_runs=crossing))                 # App. D-1 quirk
+    add("mask_crossing_spec", nw.write_naf(recs, mask_runs=crossing), spec_mask=True)
+    add("mask_exact_255k", nw.write_naf(recs, mask_runs=[255, 255, 510, 765, 0, 1020, total - 2805]))
+    add("mask_all_masked_from_0", nw.write_naf(recs, mask_runs=[0, total]))
+    add("mask_short_stream", nw.write_naf(recs, mask_runs=[1000, 500]))                      # runs end early: error
+    add("mask_overshoot", nw.write_naf(recs, mask_runs=[total - 10, 500]))
+    add("mask_off", nw.write_naf(recs, mask_runs=inside), mask=False)
+    add("mask_no_sequence", nw.write_naf(recs, mask_runs=inside), sequence=False)
+    add("mask_on_protein", nw.write_naf(make_records(rng, [100, 200], alphabet="ACDEFGHIKLMNPQRSTVWY"),
+                                        sequence_type="protein", mask_runs=[50, 30, 40, 100, 80]))
+    long_run = make_records(rng, [70000 * scale + 3, 40000])
+    lt = sum(len(r["sequence"]) for r in long_run)
+    add("mask_run_gt_65535", nw.write_naf(long_run, mask_runs=[10, 66000, lt - 66010]))
+
+    # ---- field selection ---------------------------------------------------------------------
+    fq = nw.write_naf(make_records(rng, [151] * 9, quality=True), quality=True, mask_runs=[100, 20, 151 * 9 - 120])
+    for off in ("id", "comment", "sequence", "quality", "mask"):
+        add("fastq_no_" + off, fq, **{off: False})
+
+    # ---- malformed ---------------------------------------------------------------------------
+    good = nw.write_naf(make_records(rng, [3000, 2000]), level=3)
+    add("truncated_tail", good[:-7])
+    add("truncated_mid", good[:len(good) // 2])
+    add("truncated_header", good[:6])
+    add("bad_magic", b"\x01\xF9\xED" + good[3:])
+    add("bad_version", good[:3] + b"\x07" + good[4:])
+    add("bad_separator", good[:5] + b"\x07" + good[6:])
+    flip = bytearray(good)
+    flip[len(flip) - 40] ^= 0x10
+    add("bitflip_sequence", bytes(flip))
+    add("empty", b"")
+    add("lengths_exceed_sequence", nw.write_naf(make_records(rng, [10, 20]),
+                                                raw_sections={"lengths": nw.length_words([10, 25])}))
+    return cases
+
+
+FIELDS = ("id", "comment", "sequence", "quality", "length")
+
+
+def run_oracle(blob, opts):
+    """-> (records, error) where error is None or a normalised kind string"""
+    from oracle import oracle
+    kinds = {oracle.E_IO_EOF: "io:eof", oracle.E_IO_INVALID: "io:invalid", oracle.E_NOM: "nom", oracle.E_PANIC: "panic"}
+    recs = []
+    try:
+        d = oracle.Decoder(blob, **opts)
+        for r in d:
+            recs.append(tuple(getattr(r, f) for f in FIELDS))
+    except oracle.OracleError as e:
+        return recs, kinds.get(e.kind, "other")
+    except UnicodeDecodeError:
+        return recs, "panic"
+    return recs, None
+
+
+def run_product(blob, opts, lib=None):
+    import io
+    from nafcodec_amd import _ffi
+    from nafcodec_amd.decoder import Decoder
+    recs = []
+    kw = dict(opts)
+    if lib is not None:
+        kw["_lib"] = lib
+    try:
+        d = Decoder(io.BytesIO(blob), **kw)
+        for r in d:
+            recs.append(tuple(getattr(r, f) for f in FIELDS))
+    except EOFError:
+        return recs, "io:eof"
+    except ValueError:
+        return recs, "nom"
+    except _ffi.NafError as e:
+        return recs, {_ffi.E_PANIC: "panic", _ffi.E_IO: "io:invalid"}.get(e.status, "other:%d" % e.status)
+    except OSError:
+        return recs, "io:invalid"
+    return recs, None

@@ -1,0 +1,95 @@
+"""CPU-harness tests: the SAME host + device sources as libnafgpu.so, compiled with g++ against
+tests/emu/hip/hip_runtime.h (one fiber per work-item, switched at __syncthreads()) and compared
+with the CPU oracle case by case.  This is test infrastructure for logic and memory-safety
+(AddressSanitizer / UBSan are not available on the GPU pool); the parity tests proper are the
+`-m gpu` ones, which run the hipcc build on an MI355X."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import cases
+import zstd_ref
+from conftest import ROOT, golden_bytes
+
+EMU_DIR = os.path.join(ROOT, "tests", "emu", "_build")
+CSRC = os.path.join(ROOT, "nafcodec_amd", "csrc")
+
+pytestmark = pytest.mark.skipif(not zstd_ref.available(), reason="libzstd not loadable (cases are written with it)")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.check_call(["make", "-s", "-C", CSRC, "emu"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    from nafcodec_amd import _ffi
+    return _ffi.Library(os.path.join(EMU_DIR, "libnafgpu_emu.so"))
+
+
+@pytest.fixture(scope="module")
+def all_cases():
+    return cases.build_cases(scale=1)
+
+
+def test_cases_match_oracle(emu, all_cases):
+    bad = []
+    for name, blob, opts in all_cases:
+        if cases.run_product(blob, opts, emu) != cases.run_oracle(blob, opts):
+            bad.append(name)
+    assert not bad
+
+
+@pytest.mark.parametrize("name", ["LuxC", "masked", "phix", "CP040672", "NZ_AAEN01000029"])
+def test_fixtures_match_oracle(emu, name):
+    blob = golden_bytes(name + ".naf")
+    assert cases.run_product(blob, {}, emu) == cases.run_oracle(blob, {})
+
+
+def test_synthetic_writer_roundtrip(emu):
+    """nafgpu_synth_write output: valid for libzstd, decodes to the writer's own checksums."""
+    import ctypes
+    import io
+    from nafcodec_amd.decoder import Decoder
+    from oracle import oracle
+    for n, mask, iupac in [(1000, False, 0), (300001, True, 0), (1500000, True, 7)]:
+        arc = emu.synth(n, seed=n, with_mask=mask, iupac_permille=iupac)
+        try:
+            blob = ctypes.string_at(arc.bytes, arc.n)
+            d = oracle.Decoder(blob)
+            data, orig, comp, off = d.section(4)
+            assert zstd_ref.decompress_magicless(blob[off:off + comp], len(data) + 8) == data
+            want = cases.run_oracle(blob, {})
+            seq = "".join(r[2] for r in want[0]).encode()
+            assert emu.c.nafgpu_hash64_host(seq, len(seq)) == arc.seq_hash
+            dec = Decoder(io.BytesIO(blob), _lib=emu)
+            res = dec.decode_all_device()
+            assert (res.n_bases, res.n_records) == (arc.n_bases, arc.n_records)
+            assert dec.hash_device(res.d_sequence, res.n_bases) == arc.seq_hash
+            assert dec.hash_device(res.d_record_end, 8 * res.n_records) == arc.offsets_hash
+            assert cases.run_product(blob, {}, emu) == want
+        finally:
+            emu.c.nafgpu_synth_free(ctypes.byref(arc))
+
+
+def test_under_address_sanitizer():
+    """A subset of the cases with every kernel running under ASan + UBSan."""
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not os.path.exists(asan):
+        pytest.skip("libasan not available")
+    subprocess.check_call(["make", "-s", "-C", CSRC, "emu-asan"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    script = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import cases
+from conftest import golden_bytes
+from nafcodec_amd import _ffi
+lib = _ffi.Library(%r)
+todo = [c for c in cases.build_cases(1) if not c[0].endswith("_big")]
+todo += [(n, golden_bytes(n + ".naf"), {}) for n in ("phix", "masked", "CP040672")]
+bad = [n for n, blob, opts in todo if cases.run_product(blob, opts, lib) != cases.run_oracle(blob, opts)]
+print("BAD", bad)
+sys.exit(1 if bad else 0)
+""" % (ROOT, os.path.join(ROOT, "tests"), os.path.join(EMU_DIR, "libnafgpu_emu_asan.so"))
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")
+    p = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]

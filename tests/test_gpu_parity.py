@@ -134,3 +134,14 @@ def test_synthetic_archive(lib, n_bases, mask, iupac):
             same_records(list(nafcodec_amd.Decoder(io.BytesIO(blob))), list(oracle.Decoder(blob)))
     finally:
         lib.c.nafgpu_synth_free(ctypes.byref(arc))
+
+
+def test_shared_cases_match_oracle(lib):
+    """tests/cases.py at 4x the CPU-harness sizes: levels 1/3/19, RNA, protein, FASTQ, per-record
+    flush, every mask shape incl. the record-end rule, field selection, malformed archives."""
+    import cases
+    bad = []
+    for name, blob, opts in cases.build_cases(scale=4):
+        if cases.run_product(blob, opts) != cases.run_oracle(blob, opts):
+            bad.append(name)
+    assert not bad

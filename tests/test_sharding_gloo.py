@@ -1,0 +1,44 @@
+"""The N>1 exchange step (nafcodec_amd/sharding.py) on CPU: two gloo ranks, no GPU."""
+import os
+import socket
+import subprocess
+import sys
+
+from conftest import ROOT
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from nafcodec_amd.sharding import gather_placement
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+table = [(1000003, 500002, 17, 1), (2000000, 1000000, 5, 0), (7, 4, 1, 1)][:w]
+for _ in range(3):
+    p = gather_placement(dist, torch, *table[r], device="cpu")
+assert p.base_offset == sum(t[0] for t in table[:r]) and p.packed_offset == sum(t[1] for t in table[:r])
+assert p.record_offset == sum(t[2] for t in table[:r])
+assert (p.total_bases, p.total_packed, p.total_records) == tuple(sum(t[k] for t in table) for k in range(3))
+assert p.carries == [t[3] for t in table] and (p.rank, p.world) == (r, w)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", r, "ok")
+"""
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_offset_gather_two_and_three_ranks(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    for n in (2, 3):
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+                            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
+                           capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, OMP_NUM_THREADS="1"))
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        assert p.stdout.count("ok") == n

@@ -1,0 +1,152 @@
+// nafcodec.hpp -- header-only C++17 mirror of the reference's public decode API on top of the
+// C-ABI (include/nafgpu.h).  Same names, defaults and error behaviour as
+// nafcodec/src/decoder/mod.rs (DecoderBuilder :53-257, Decoder :285-461), data.rs (Record :29-40,
+// Header :198-237, Flag(s) :80-189, SequenceType :56-73, FormatVersion :46-50) and error.rs.
+#pragma once
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+
+#include "nafgpu.h"
+
+namespace nafcodec {
+
+enum class FormatVersion : uint8_t { V1 = 1, V2 = 2 };
+enum class SequenceType : uint8_t { Dna = 0, Rna = 1, Protein = 2, Text = 3 };
+inline bool is_nucleotide(SequenceType t) { return t == SequenceType::Dna || t == SequenceType::Rna; }
+
+enum class Flag : uint8_t { Quality = 0x1, Sequence = 0x2, Mask = 0x4, Length = 0x8, Comment = 0x10, Id = 0x20, Title = 0x40, Extended = 0x80 };
+struct Flags {
+    uint8_t bits = 0;
+    bool test(Flag f) const { return (bits & static_cast<uint8_t>(f)) != 0; }
+    void set(Flag f) { bits |= static_cast<uint8_t>(f); }
+    void unset(Flag f) { bits &= static_cast<uint8_t>(~static_cast<uint8_t>(f)); }
+    uint8_t as_byte() const { return bits; }
+};
+inline Flags operator|(Flag a, Flag b) { return Flags{static_cast<uint8_t>(static_cast<uint8_t>(a) | static_cast<uint8_t>(b))}; }
+inline Flags operator|(Flags a, Flag b) { return Flags{static_cast<uint8_t>(a.bits | static_cast<uint8_t>(b))}; }
+
+// error.rs:4-11 -- Io / Nom / Utf8 (+ the C-ABI's Panic and Device kinds)
+struct Error : std::runtime_error {
+    nafgpu_error raw;
+    explicit Error(const nafgpu_error &e) : std::runtime_error(e.message), raw(e) {}
+    bool is_io() const { return raw.status == NAFGPU_E_IO; }
+    bool is_unexpected_eof() const { return is_io() && raw.io_kind == NAFGPU_IO_UNEXPECTED_EOF; }
+    bool is_nom() const { return raw.status == NAFGPU_E_NOM; }
+};
+
+struct Record {   // data.rs:29-40: five public Option fields, owned strings (Record<'static>)
+    std::optional<std::string> id, comment, sequence, quality;
+    std::optional<uint64_t> length;
+};
+
+class Header {    // data.rs:198-237
+public:
+    explicit Header(const nafgpu_header &h) : h_(h) {}
+    Flags flags() const { return Flags{h_.flags}; }
+    uint64_t line_length() const { return h_.line_length; }
+    char name_separator() const { return static_cast<char>(h_.name_separator); }
+    uint64_t number_of_sequences() const { return h_.number_of_sequences; }
+    SequenceType sequence_type() const { return static_cast<SequenceType>(h_.sequence_type); }
+    FormatVersion format_version() const { return static_cast<FormatVersion>(h_.format_version); }
+
+private:
+    nafgpu_header h_;
+};
+
+class Decoder {   // mod.rs:285-461
+public:
+    Decoder(Decoder &&o) noexcept : d_(std::exchange(o.d_, nullptr)) {}
+    Decoder &operator=(Decoder &&o) noexcept {
+        if (this != &o) {
+            nafgpu_close(d_);
+            d_ = std::exchange(o.d_, nullptr);
+        }
+        return *this;
+    }
+    Decoder(const Decoder &) = delete;
+    ~Decoder() { nafgpu_close(d_); }
+
+    static Decoder from_path(const std::string &path);   // mod.rs:304-306
+    Header header() const {
+        nafgpu_header h;
+        nafgpu_get_header(d_, &h);
+        return Header(h);
+    }
+    SequenceType sequence_type() const { return header().sequence_type(); }
+    size_t len() const { return static_cast<size_t>(nafgpu_remaining(d_)); }   // ExactSizeIterator
+
+    // Iterator::next: nullopt at the end; throws Error (the iterator stays usable, mod.rs:391)
+    std::optional<Record> next() {
+        nafgpu_record r;
+        int rc = nafgpu_next(d_, &r);
+        if (rc == NAFGPU_END) return std::nullopt;
+        if (rc != NAFGPU_OK) {
+            nafgpu_error e;
+            nafgpu_last_error(d_, &e);
+            throw Error(e);
+        }
+        auto own = [](const nafgpu_field &f) -> std::optional<std::string> {
+            if (!f.present) return std::nullopt;
+            return std::string(reinterpret_cast<const char *>(f.ptr), static_cast<size_t>(f.len));
+        };
+        Record out;
+        out.id = own(r.id);
+        out.comment = own(r.comment);
+        out.sequence = own(r.sequence);
+        out.quality = own(r.quality);
+        if (r.has_length) out.length = r.length;
+        return out;
+    }
+    nafgpu_decoder *raw() const { return d_; }
+
+private:
+    friend class DecoderBuilder;
+    explicit Decoder(nafgpu_decoder *d) : d_(d) {}
+    nafgpu_decoder *d_ = nullptr;
+};
+
+class DecoderBuilder {   // mod.rs:53-257
+public:
+    DecoderBuilder() { nafgpu_opts_default(&o_); }                                  // mod.rs:67-76
+    static DecoderBuilder from_flags(Flags f) {                                     // mod.rs:93-101
+        DecoderBuilder b;
+        nafgpu_opts_from_flags(&b.o_, f.as_byte());
+        return b;
+    }
+    DecoderBuilder &buffer_size(size_t n) { o_.buffer_size = n; return *this; }      // mod.rs:110
+    DecoderBuilder &id(bool v) { o_.id = v; return *this; }
+    DecoderBuilder &comment(bool v) { o_.comment = v; return *this; }
+    DecoderBuilder &sequence(bool v) { o_.sequence = v; return *this; }
+    DecoderBuilder &quality(bool v) { o_.quality = v; return *this; }
+    DecoderBuilder &mask(bool v) { o_.mask = v; return *this; }
+    DecoderBuilder &device(int ordinal) { o_.device = ordinal; return *this; }       // MI355X-specific knob
+
+    Decoder with_bytes(const uint8_t *p, size_t n) const {                           // mod.rs:151-156
+        nafgpu_decoder *d = nullptr;
+        nafgpu_error e;
+        if (nafgpu_open_bytes(p, n, &o_, &d, &e) != NAFGPU_OK) throw Error(e);
+        return Decoder(d);
+    }
+    Decoder with_path(const std::string &path) const {                               // mod.rs:159-166
+        nafgpu_decoder *d = nullptr;
+        nafgpu_error e;
+        if (nafgpu_open_path(path.c_str(), &o_, &d, &e) != NAFGPU_OK) throw Error(e);
+        return Decoder(d);
+    }
+    Decoder with_reader(nafgpu_read_fn read, nafgpu_seek_fn seek, void *ctx) const {  // mod.rs:169-256
+        nafgpu_decoder *d = nullptr;
+        nafgpu_error e;
+        if (nafgpu_open_io(read, seek, ctx, &o_, &d, &e) != NAFGPU_OK) throw Error(e);
+        return Decoder(d);
+    }
+
+private:
+    nafgpu_opts o_;
+};
+
+inline Decoder Decoder::from_path(const std::string &path) { return DecoderBuilder().with_path(path); }
+
+}  // namespace nafcodec

@@ -29,24 +29,40 @@ __device__ inline void flag_error(uint32_t *status, uint32_t code, uint32_t deta
 // ======================================================================================
 // K1  Huffman literal streams
 // ======================================================================================
-// One wave per task, one lane per stream.  Each lane walks its backward
-// bitstream with a 64-bit window {hi, lo} plus one look-ahead word; words come from a per-lane
-// 16-word ring in LDS that the lane refills with 16-byte aligned global loads (one chunk in
-// flight).  Decoded bytes are staged as 64-byte rows in LDS and flushed cooperatively so that
-// every global store instruction writes whole 64-byte segments.
-//
-// ASCII = true is the fused DNA/RNA form: the 4-bit -> IUPAC expansion of
-// SequenceReader::read_nucleotide / decode (reader.rs:121-172) is folded into the Huffman
-// table while it is staged in LDS -- an entry holds the symbol's TWO output characters -- so
-// the kernel writes final ASCII bases and the packed intermediate never touches HBM.
-constexpr int kRowWords = 20;        // 80-byte padded LDS rows (64 used): conflict-free b128 access
-constexpr int kRingMask = 15;
+// One wave per task, one lane per stream.  The kernel is bound by the latency of
+// the per-symbol dependency chain (window -> table look-up -> advance), so everything here is
+// about doing more per look-up and keeping the chain short:
+//   * two-symbol table: while a task's Huffman tables are staged into LDS they are widened to
+//     W = max(max_bits, 8) index bits and every entry is extended with the symbol that FOLLOWS
+//     when both codes fit in W bits (zstd's own "X2" idea).  DNA codes are ~4 bits, so almost every
+//     look-up yields two packed bytes = four bases.
+//   * bit window: {hi, lo, nw} are three consecutive 32-bit words of the backward stream and
+//     c in [1,32] the consumed bits of hi; peek = v_alignbit_b32(hi, lo, 32 - c).
+//   * input ring: 16 words per lane in LDS, stored transposed (word x of lane l at x*64 + l: any
+//     mix of positions is bank-conflict free), refilled by the lane itself with 16-byte aligned
+//     global loads, one chunk in flight, serviced every 8 look-ups.  Invariant (look-ups consume
+//     <= 11 bits, so <= 3 words per service period): >= 6 staged words ahead after each service.
+//   * output: lanes progress at different speeds (1 or 2 symbols per look-up), so each lane
+//     appends packed bytes to its own 64-byte ring in LDS whose position is congruent to the
+//     destination offset mod 32.  After every 16 look-ups the wave flushes one 32-byte unit per
+//     ready row cooperatively: 4 lanes per row, each expands 8 packed bytes to 16 IUPAC characters
+//     (v_perm_b32 LUT; reader.rs:121-172) and stores one aligned dwordx4 -- 64 contiguous bytes per
+//     row per store instruction.  The 4-bit intermediate never reaches HBM (ASCII = true); text
+//     sections (ASCII = false) store the bytes as they are.
+constexpr uint32_t kRingWords = 16;
+constexpr uint32_t kOutRing = 64;        // packed bytes per lane
+constexpr uint32_t kOutPitch = 72;       // row pitch in bytes (8-byte aligned rows + spill room)
+constexpr uint32_t kUnit = 32;           // packed bytes flushed per row at a time
 
 struct HufLane {
     uint32_t hi, lo, nw;   // bit window: hi = word under the cursor, lo = next, nw = the one after
     uint32_t c;            // bits of hi already consumed, kept in [1, 32]
     uint32_t rp;           // ring index of hi
 };
+
+// table entry: sym1 | sym2 << 8 | len << 16 | len1 << 20 | two << 24
+//   two  = 1 when sym2 is valid;  len = bits consumed when taking everything the entry offers
+//   len1 = bits of sym1 alone (used when only one symbol of the stream is left)
 
 // "-TGKCYSBAWRDMHVN"[nib], with index 1 = t_char ('T' for DNA, 'U' for RNA)  (reader.rs:152-172)
 __device__ inline uint32_t nib_char(uint32_t nib, uint32_t t_char) {
@@ -59,21 +75,36 @@ __device__ inline uint32_t byte_chars(uint32_t b, uint32_t t_char) {
     return nib_char(b & 15u, t_char) | (nib_char(b >> 4, t_char) << 8);
 }
 
-// one symbol: table look-up on the next max_bits bits, then advance the window
-template <bool ASCII>
-__device__ inline uint32_t huf_step(HufLane &L, const void *tbl, uint32_t sh, const uint32_t *ring, bool live) {
-    const uint32_t peek = __builtin_amdgcn_alignbit(L.hi, L.lo, 32u - L.c);   // c = 32 -> shift 0 -> lo
-    const uint32_t idx = peek >> sh;
-    const uint32_t e = ASCII ? static_cast<const uint32_t *>(tbl)[idx] : static_cast<const uint16_t *>(tbl)[idx];
-    const uint32_t len = ASCII ? e >> 16 : e >> 8;
-    L.c += live ? len : 0u;
+// 4 nibbles (one per byte of `nib`) -> 4 characters
+__device__ inline uint32_t lut4(uint32_t nib, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
+    const uint32_t sel = nib & 0x07070707u;
+    const uint32_t lo = __builtin_amdgcn_perm(t1, t0, sel);
+    const uint32_t hi = __builtin_amdgcn_perm(t3, t2, sel);
+    const uint32_t m = ((nib >> 3) & 0x01010101u) * 0xFFu;
+    return (hi & m) | (lo & ~m);
+}
+// 4 packed bytes -> 8 characters (o0 = bases 0..3, o1 = bases 4..7)
+__device__ inline void unpack_dword(uint32_t w, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t *o0,
+                                    uint32_t *o1) {
+    const uint32_t L = lut4(w & 0x0F0F0F0Fu, t0, t1, t2, t3);
+    const uint32_t H = lut4((w >> 4) & 0x0F0F0F0Fu, t0, t1, t2, t3);
+    *o0 = __builtin_amdgcn_perm(H, L, 0x05010400u);   // L0 H0 L1 H1
+    *o1 = __builtin_amdgcn_perm(H, L, 0x07030602u);   // L2 H2 L3 H3
+}
+
+// one table look-up; returns the entry.  take = symbols actually taken (0, 1 or 2).
+__device__ inline uint32_t huf_lookup(HufLane &L, const uint32_t *tbl, uint32_t sh, const uint32_t *ring_lane,
+                                      uint32_t len) {
+    L.c += len;
     const bool adv = L.c > 32u;
     L.hi = adv ? L.lo : L.hi;
     L.lo = adv ? L.nw : L.lo;
     L.c = adv ? L.c - 32u : L.c;
     L.rp += adv ? 1u : 0u;
-    L.nw = ring[(L.rp + 2u) & kRingMask];
-    return e;
+    L.nw = ring_lane[((L.rp + 2u) & (kRingWords - 1)) * 64u];
+    (void)tbl;
+    (void)sh;
+    return 0;
 }
 
 template <bool ASCII>
@@ -83,41 +114,42 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
                                                    const uint16_t *__restrict__ pool,
                                                    const uint64_t *__restrict__ blk_base, uint8_t *out, uint8_t *lit,
                                                    uint32_t t_char, uint32_t *status) {
-    constexpr uint32_t kEntryBytes = ASCII ? 4 : 2;
-    constexpr uint32_t kGroups = ASCII ? 4 : 8;            // groups of 8 symbols per 64-byte row
-    constexpr uint32_t kRound = 8 * kGroups;               // symbols per flush
-    constexpr uint32_t kOutBytes = ASCII ? 2 : 1;          // bytes written per symbol
-    HIP_DYNAMIC_SHARED(uint8_t, s_tbl)
-    __shared__ __attribute__((aligned(16))) uint32_t s_ring[64 * kRowWords];
-    __shared__ __attribute__((aligned(16))) uint32_t s_out[64 * kRowWords];
-    __shared__ uint64_t s_dst[64];
-    __shared__ uint32_t s_n[64];
-    __shared__ uint32_t s_nmax;
+    HIP_DYNAMIC_SHARED(uint32_t, s_tbl)
+    __shared__ uint32_t s_ring[kRingWords * 64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[64 * kOutPitch];
+    __shared__ uint64_t s_dst[64];     // destination of ring coordinate 0 (packed-byte offset; bit 63: literal buffer)
+    __shared__ uint32_t s_h[64];       // first valid ring coordinate of the row (bytes before it belong to another stream)
+    __shared__ uint32_t s_q[64];       // ring coordinate of the row's next write
+    __shared__ uint32_t s_fl[64];      // ring coordinate up to which the row has been flushed (multiple of kUnit)
 
     if (status[0] != 0) return;
     const uint32_t lane = threadIdx.x;
     const HufTask task = tasks[blockIdx.x];
 
+    // ---- stage the task's tables, widened to two symbols per entry
     for (uint32_t k = 0; k < task.n_copies; k++) {
         const HufTblCopy cp = copies[task.first_copy + k];
-        for (uint32_t e = lane; e < cp.n_entries; e += 64) {
-            const uint32_t p = pool[cp.pool_off + e];      // len << 8 | symbol
-            if (ASCII)
-                reinterpret_cast<uint32_t *>(s_tbl)[cp.lds_off + e] = ((p >> 8) << 16) | byte_chars(p & 0xFFu, t_char);
-            else
-                reinterpret_cast<uint16_t *>(s_tbl)[cp.lds_off + e] = static_cast<uint16_t>(p);
+        const uint32_t mb = cp.bits & 0xFFu, W = cp.bits >> 8;
+        const uint16_t *x1 = pool + cp.pool_off;           // 2^mb entries of len << 8 | sym
+        for (uint32_t i = lane; i < cp.n_entries; i += 64) {
+            const uint32_t v = i << (32u - W);             // the W index bits, left-aligned
+            const uint32_t e1 = x1[v >> (32u - mb)];
+            const uint32_t l1 = e1 >> 8;
+            const uint32_t e2 = x1[(v << l1) >> (32u - mb)];
+            const uint32_t l2 = e2 >> 8;
+            const uint32_t two = l1 + l2 <= W ? 1u : 0u;
+            s_tbl[cp.lds_off + i] = (e1 & 0xFFu) | ((e2 & 0xFFu) << 8) | ((two ? l1 + l2 : l1) << 16) | (l1 << 20) | (two << 24);
         }
     }
-    if (lane == 0) s_nmax = 0;
 
     const bool have = lane < task.n_streams;
     HufStream st{};
     if (have) st = streams[task.first_stream + lane];
     const uint32_t n = st.n_syms;
-    const uint32_t sh = 32u - st.max_bits;
-    const void *tbl = s_tbl + static_cast<size_t>(st.tbl_lds) * kEntryBytes;
-    uint32_t *ring = s_ring + lane * kRowWords;
-    uint32_t *orow = s_out + lane * kRowWords;
+    const uint32_t sh = 32u - st.max_bits;                 // max_bits holds W here
+    const uint32_t *tbl = s_tbl + st.tbl_lds;
+    uint32_t *ring = s_ring + lane;                        // word x at ring[x * 64]
+    uint8_t *orow = s_out + lane * kOutPitch;
 
     HufLane L{0, 0, 0, 1, 0};
     const uint8_t *ctop = nullptr;       // 16-byte chunk holding the stream's last byte
@@ -125,6 +157,7 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     uint4 pend = make_uint4(0, 0, 0, 0);
     uint32_t c0 = 1, rp0 = 0, bits_total = 0;
     bool bad = false;
+    uint32_t cur = 0, n_end = 0, fl = 0;                   // ring coordinates: next write, end of stream, flushed
     if (have) {
         const uint8_t *lastp = src + st.src_end - 1;
         const uint32_t lastb = *lastp;
@@ -139,86 +172,134 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         rp0 = L.rp;
         for (uint32_t j = 0; j < 3; j++) {
             const uint4 v = *reinterpret_cast<const uint4 *>(ctop - 16 * j);
-            *reinterpret_cast<uint4 *>(ring + 4 * j) = make_uint4(v.w, v.z, v.y, v.x);
+            ring[(4 * j + 0) * 64] = v.w;
+            ring[(4 * j + 1) * 64] = v.z;
+            ring[(4 * j + 2) * 64] = v.y;
+            ring[(4 * j + 3) * 64] = v.x;
         }
         wp = 3;
         pend = *reinterpret_cast<const uint4 *>(ctop - 48);
         lp = 4;
-        L.hi = ring[L.rp];
-        L.lo = ring[L.rp + 1];
-        L.nw = ring[L.rp + 2];
-        // destination as a byte offset; bit 63 selects the literal buffer
-        s_dst[lane] = (st.flags & 1) ? (st.dst | (1ull << 63)) : kOutBytes * (blk_base[st.blk] + st.dst);
+        L.hi = ring[L.rp * 64];
+        L.lo = ring[(L.rp + 1) * 64];
+        L.nw = ring[(L.rp + 2) * 64];
+        const uint64_t dstart = (st.flags & 1) ? st.dst : blk_base[st.blk] + st.dst;   // packed-byte offset
+        cur = static_cast<uint32_t>(dstart & (kUnit - 1));
+        n_end = cur + n;
+        s_dst[lane] = (dstart - cur) | ((st.flags & 1) ? (1ull << 63) : 0ull);
+        s_h[lane] = cur;
     } else {
         s_dst[lane] = 0;
+        s_h[lane] = 0;
     }
-    s_n[lane] = n;
-    __syncthreads();
-    atomicMax(&s_nmax, n);
-    __syncthreads();
-    const uint32_t nmax = s_nmax;
 
-    for (uint32_t base = 0; base < nmax; base += kRound) {
-        if (base < n) {
-#pragma unroll 1
-            for (uint32_t g = 0; g < kGroups; g++) {
-                const uint32_t i0 = base + g * 8;
-                if (i0 >= n) break;
-                // ---- service the input ring: land the chunk in flight, then issue the next one
-                if (lp > wp) {
-                    *reinterpret_cast<uint4 *>(ring + ((4 * wp) & kRingMask)) = make_uint4(pend.w, pend.z, pend.y, pend.x);
-                    wp++;
-                }
-                if (4 * lp + 3 < L.rp + 16) {
-                    pend = *reinterpret_cast<const uint4 *>(ctop - 16 * static_cast<size_t>(lp));
-                    lp++;
-                }
-                uint32_t e[8];
-                if (i0 + 8 <= n) {
-#pragma unroll
-                    for (uint32_t k = 0; k < 8; k++) e[k] = huf_step<ASCII>(L, tbl, sh, ring, true);
-                } else {                                         // last group of this stream: freeze past n
-#pragma unroll
-                    for (uint32_t k = 0; k < 8; k++) e[k] = huf_step<ASCII>(L, tbl, sh, ring, i0 + k < n);
-                }
-                if (ASCII) {
-                    *reinterpret_cast<uint4 *>(orow + 4 * g) =
-                        make_uint4((e[0] & 0xFFFFu) | (e[1] << 16), (e[2] & 0xFFFFu) | (e[3] << 16),
-                                   (e[4] & 0xFFFFu) | (e[5] << 16), (e[6] & 0xFFFFu) | (e[7] << 16));
-                } else {
-                    *reinterpret_cast<uint2 *>(orow + 2 * g) =
-                        make_uint2((e[0] & 0xFFu) | ((e[1] & 0xFFu) << 8) | ((e[2] & 0xFFu) << 16) | (e[3] << 24),
-                                   (e[4] & 0xFFu) | ((e[5] & 0xFFu) << 8) | ((e[6] & 0xFFu) << 16) | (e[7] << 24));
-                }
-            }
-        }
-        __syncthreads();
-        // ---- cooperative flush: lane j stores 16 bytes of row (j/4 + 16k); 4 lanes cover a 64-byte row
+    __syncthreads();                                       // tables and row metadata are staged
+
+    // "-TGKCYSBAWRDMHVN" as four LUT dwords (index 1 = T or U)
+    const uint32_t t0 = 0x4B47002Du | (t_char << 8), t1 = 0x42535943u, t2 = 0x44525741u, t3 = 0x4E56484Du;
+
+    // flush one unit (<= 32 packed bytes) of every ready row; final = also partial units
+    auto flush = [&](bool final) {
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++) {
             const uint32_t row = (lane >> 2) + 16 * k;
-            const uint32_t col = (lane & 3) * 16;
-            const uint32_t rn = s_n[row];
-            if (rn > base) {
-                const uint32_t valid = (rn - base < kRound ? rn - base : kRound) * kOutBytes;   // bytes
-                if (col < valid) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(s_out + row * kRowWords + (col >> 2));
+            const uint32_t qd = lane & 3;
+            const uint32_t rfl = s_fl[row], rq = s_q[row];
+            const uint32_t avail = rq - rfl;
+            if (avail >= kUnit || (final && avail > 0)) {
+                const uint32_t lo_x = rfl + 8 * qd, hi_x = lo_x + 8;
+                const uint32_t rh = s_h[row];
+                const uint32_t v_lo = lo_x > rh ? lo_x : rh, v_hi = hi_x < rq ? hi_x : rq;
+                if (v_lo < v_hi) {
+                    const uint2 w = *reinterpret_cast<const uint2 *>(s_out + row * kOutPitch + (lo_x & (kOutRing - 1)));
                     const uint64_t doff = s_dst[row];
-                    uint8_t *d = ((doff >> 63) ? lit : out) + (doff & ~(1ull << 63)) + static_cast<uint64_t>(base) * kOutBytes + col;
-                    if (col + 16 <= valid) {
-                        if ((reinterpret_cast<uintptr_t>(d) & 15) == 0) {
-                            *reinterpret_cast<uint4 *>(d) = v;
+                    const uint64_t pos = (doff & ~(1ull << 63)) + lo_x;          // packed-byte offset of this quarter
+                    uint8_t *base = (doff >> 63) ? lit : out;
+                    const bool full = v_lo == lo_x && v_hi == hi_x;
+                    if (ASCII) {
+                        uint4 a;
+                        unpack_dword(w.x, t0, t1, t2, t3, &a.x, &a.y);
+                        unpack_dword(w.y, t0, t1, t2, t3, &a.z, &a.w);
+                        if (full) {
+                            *reinterpret_cast<uint4 *>(base + 2 * pos) = a;
                         } else {
-                            __builtin_memcpy(d, &v, 16);
+                            const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+                            for (uint32_t x = v_lo; x < v_hi; x++) {
+                                const uint32_t b = 2 * (x - lo_x);
+                                reinterpret_cast<uint16_t *>(base)[pos + (x - lo_x)] =
+                                    static_cast<uint16_t>(aw[b >> 2] >> (8 * (b & 3)));
+                            }
                         }
+                    } else if (full) {
+                        *reinterpret_cast<uint2 *>(base + pos) = w;
                     } else {
-                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                        for (uint32_t b = 0; b < valid - col; b++) d[b] = static_cast<uint8_t>(w[b >> 2] >> (8 * (b & 3)));
+                        const uint32_t ww[2] = {w.x, w.y};
+                        for (uint32_t x = v_lo; x < v_hi; x++) {
+                            const uint32_t b = x - lo_x;
+                            base[pos + b] = static_cast<uint8_t>(ww[b >> 2] >> (8 * (b & 3)));
+                        }
                     }
                 }
             }
         }
+    };
+
+    int any = 1;
+    while (any) {
+        if (cur < n_end) {
+#pragma unroll 1
+            for (uint32_t g = 0; g < 2; g++) {
+                if (cur >= n_end) break;
+                // ---- service the input ring: land the chunk in flight, then issue the next one
+                if (lp > wp) {
+                    const uint32_t x0 = (4 * wp) & (kRingWords - 1);
+                    ring[(x0 + 0) * 64] = pend.w;
+                    ring[(x0 + 1) * 64] = pend.z;
+                    ring[(x0 + 2) * 64] = pend.y;
+                    ring[(x0 + 3) * 64] = pend.x;
+                    wp++;
+                }
+                if (4 * lp + 3 < L.rp + kRingWords) {
+                    pend = *reinterpret_cast<const uint4 *>(ctop - 16 * static_cast<size_t>(lp));
+                    lp++;
+                }
+                if (cur + 16 <= n_end) {                   // 8 look-ups cannot overrun the stream
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) {
+                        const uint32_t e = tbl[__builtin_amdgcn_alignbit(L.hi, L.lo, 32u - L.c) >> sh];
+                        orow[cur & (kOutRing - 1)] = static_cast<uint8_t>(e);
+                        orow[(cur + 1) & (kOutRing - 1)] = static_cast<uint8_t>(e >> 8);
+                        cur += 1u + ((e >> 24) & 1u);
+                        huf_lookup(L, tbl, sh, ring, (e >> 16) & 15u);
+                    }
+                } else {                                   // tail of the stream: never take more than is left
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) {
+                        const uint32_t e = tbl[__builtin_amdgcn_alignbit(L.hi, L.lo, 32u - L.c) >> sh];
+                        const uint32_t left = n_end - cur;
+                        const bool two = ((e >> 24) & 1u) && left >= 2;
+                        orow[cur & (kOutRing - 1)] = static_cast<uint8_t>(e);
+                        orow[(cur + 1) & (kOutRing - 1)] = static_cast<uint8_t>(e >> 8);
+                        cur += left == 0 ? 0u : (two ? 2u : 1u);
+                        huf_lookup(L, tbl, sh, ring, left == 0 ? 0u : (two ? (e >> 16) & 15u : (e >> 20) & 15u));
+                    }
+                }
+            }
+        }
+        s_q[lane] = cur;
+        s_fl[lane] = fl;
         __syncthreads();
+        flush(false);
+        any = __syncthreads_or(cur < n_end ? 1 : 0);
+        if (cur - fl >= kUnit) fl += kUnit;                // what the flush above wrote for this lane's row
+    }
+    for (uint32_t t = 0; t < 2; t++) {                     // at most 63 bytes are left in a row
+        s_q[lane] = cur;
+        s_fl[lane] = fl;
+        __syncthreads();
+        flush(true);
+        __syncthreads();
+        fl = cur - fl > kUnit ? fl + kUnit : cur;
     }
     if (have) {
         const uint32_t consumed = 32u * (L.rp - rp0) + L.c - c0;
@@ -612,22 +693,6 @@ __global__ __launch_bounds__(256) void k_lz_execute(const SeqBlock *__restrict__
 // Byte b of the packed stream yields LUT[b & 15] then LUT[b >> 4]; records are contiguous in
 // nibble space, so record k is bases [end[k-1], end[k]) of this one flat array -- the odd-nibble
 // `cache` of reader.rs:92-94,138-143 is just an odd offset here.
-__device__ inline uint32_t lut4(uint32_t nib, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
-    const uint32_t sel = nib & 0x07070707u;
-    const uint32_t lo = __builtin_amdgcn_perm(t1, t0, sel);
-    const uint32_t hi = __builtin_amdgcn_perm(t3, t2, sel);
-    const uint32_t m = ((nib >> 3) & 0x01010101u) * 0xFFu;
-    return (hi & m) | (lo & ~m);
-}
-
-__device__ inline void unpack_dword(uint32_t w, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t *o0,
-                                    uint32_t *o1) {
-    const uint32_t L = lut4(w & 0x0F0F0F0Fu, t0, t1, t2, t3);
-    const uint32_t H = lut4((w >> 4) & 0x0F0F0F0Fu, t0, t1, t2, t3);
-    *o0 = __builtin_amdgcn_perm(H, L, 0x05010400u);   // L0 H0 L1 H1
-    *o1 = __builtin_amdgcn_perm(H, L, 0x07030602u);   // L2 H2 L3 H3
-}
-
 __global__ __launch_bounds__(256) void k_unpack4(const uint8_t *__restrict__ packed, uint64_t n_packed,
                                                  uint8_t *__restrict__ ascii, uint64_t n_bases, uint32_t t_char,
                                                  const uint32_t *status) {
@@ -825,7 +890,7 @@ void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *ta
                        const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t max_tbl_entries, bool ascii,
                        uint32_t t_char, uint32_t *status) {
     if (!n_tasks) return;
-    const uint32_t lds = ((max_tbl_entries * (ascii ? 4u : 2u)) + 15u) & ~15u;
+    const uint32_t lds = ((max_tbl_entries * 4u) + 15u) & ~15u;
     if (ascii)
         hipLaunchKernelGGL(k_huf_decode<true>, dim3(n_tasks), dim3(64), lds, stream, src, tasks, copies, streams, pool,
                            blk_base, out, lit, t_char, status);

@@ -8,7 +8,9 @@ namespace nafgpu {
 
 constexpr uint32_t kBlockMax = 128u << 10;   // zstd Block_Maximum_Size
 constexpr int kHufWave = 64;                 // one Huffman stream per lane, one wave per workgroup
-constexpr uint32_t kHufLdsEntries = 4096;    // u16 decode-table entries a wave task may stage in LDS
+constexpr uint32_t kHufLdsEntries = 4096;    // 4-byte decode-table entries a wave task may stage in LDS
+// index width of the staged two-symbol table for a tree with `max_bits`-bit codes
+constexpr uint32_t huf_index_bits(uint32_t max_bits) { return max_bits < 8 ? 8 : max_bits; }
 constexpr uint32_t kSrcFrontPad = 256;       // bytes readable in front of any device source buffer
 constexpr uint32_t kSrcBackPad = 64;
 
@@ -20,13 +22,16 @@ struct alignas(16) HufStream {
     uint32_t n_syms;     // symbols to regenerate
     uint32_t blk;        // zstd block index (for blk_base[])
     uint16_t tbl_lds;    // first entry of this stream's table inside the task's LDS table area
-    uint8_t max_bits;    // table is 2^max_bits entries of (len << 8 | symbol)
+    uint8_t max_bits;    // index width W of the staged table (>= the tree's max_bits, see huf_index_bits)
     uint8_t flags;       // bit0: write to the literal buffer (block has sequences)
 };
 static_assert(sizeof(HufStream) == 32, "HufStream layout");
 
-struct HufTblCopy {      // stage pool[pool_off .. +n_entries) at LDS entry lds_off
-    uint32_t pool_off, lds_off, n_entries, pad;
+struct HufTblCopy {      // build the two-symbol table of pool[pool_off ..) at LDS entry lds_off
+    uint32_t pool_off;   // 2^max_bits single-symbol entries (len << 8 | sym) in the pool
+    uint32_t lds_off;    // first staged entry (4-byte entries)
+    uint32_t n_entries;  // 2^W staged entries
+    uint32_t bits;       // max_bits | W << 8
 };
 
 struct HufTask {         // one workgroup of k_huf_decode: <= 64 streams, tables <= kHufLdsEntries

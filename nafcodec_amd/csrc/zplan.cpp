@@ -673,7 +673,8 @@ struct Walker {
                 plan->n_direct_tasks = static_cast<uint32_t>(plan->tasks.size());
             }
             const HufRef &t = stream_tbl[s];
-            const uint32_t entries = 1u << t.max_bits;
+            const uint32_t W = huf_index_bits(t.max_bits);
+            const uint32_t entries = 1u << W;
             auto find = [&]() -> int {
                 for (size_t k = 0; k < slots.size(); k++)
                     if (slots[k].pool_off == t.pool_off) return static_cast<int>(k);
@@ -685,12 +686,13 @@ struct Walker {
             }
             if (k < 0) {
                 slots.push_back(Slot{t.pool_off, lds_used});
-                plan->tbl_copies.push_back(HufTblCopy{t.pool_off, lds_used, entries, 0});
+                plan->tbl_copies.push_back(HufTblCopy{t.pool_off, lds_used, entries, t.max_bits | (W << 8)});
                 cur.n_copies++;
                 lds_used += entries;
                 k = static_cast<int>(slots.size()) - 1;
             }
             plan->streams[s].tbl_lds = static_cast<uint16_t>(slots[size_t(k)].lds_off);
+            plan->streams[s].max_bits = static_cast<uint8_t>(W);
             cur.n_streams++;
             if (cur.n_streams == kHufWave) close();
         }

@@ -43,6 +43,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &bo
 }  // namespace hipemu
 
 inline void __syncthreads() { hipemu::sync_threads(); }
+int __syncthreads_or(int pred);
 
 // ---- device intrinsics used by kernels.hip ------------------------------------------------
 inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz(static_cast<unsigned>(v)); }

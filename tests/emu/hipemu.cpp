@@ -128,6 +128,22 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &bo
 }
 }  // namespace hipemu
 
+// block-wide OR: accumulate, barrier, read, barrier (all work-items of the block must call it)
+static int g_or_acc = 0, g_or_out = 0, g_or_count = 0;
+int __syncthreads_or(int pred) {
+    const int nthreads = static_cast<int>(blockDim.x * blockDim.y * blockDim.z);
+    g_or_acc |= pred != 0;
+    if (++g_or_count == nthreads) {
+        g_or_out = g_or_acc;
+        g_or_acc = 0;
+        g_or_count = 0;
+    }
+    hipemu::sync_threads();
+    const int r = g_or_out;
+    hipemu::sync_threads();
+    return r;
+}
+
 // ---- runtime API ---------------------------------------------------------------------------
 struct hipemuEvent {
     std::chrono::steady_clock::time_point t;

@@ -12,7 +12,10 @@
 // Reference counterparts are cited per kernel.  Format: RFC 8878 / SURVEY.md Appendix B.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
+
+#include <nafgpu_vmem.h>
 
 #include "hash64.h"
 #include "kernels.h"
@@ -29,40 +32,52 @@ __device__ inline void flag_error(uint32_t *status, uint32_t code, uint32_t deta
 // ======================================================================================
 // K1  Huffman literal streams
 // ======================================================================================
-// One wave per task, one lane per stream.  The kernel is bound by the latency of
-// the per-symbol dependency chain (window -> table look-up -> advance), so everything here is
-// about doing more per look-up and keeping the chain short:
-//   * two-symbol table: while a task's Huffman tables are staged into LDS they are widened to
-//     W = max(max_bits, 8) index bits and every entry is extended with the symbol that FOLLOWS
-//     when both codes fit in W bits (zstd's own "X2" idea).  DNA codes are ~4 bits, so almost every
-//     look-up yields two packed bytes = four bases.
-//   * bit window: {hi, lo, nw} are three consecutive 32-bit words of the backward stream and
-//     c in [1,32] the consumed bits of hi; peek = v_alignbit_b32(hi, lo, 32 - c).
+// One wave per task, one lane per stream.  Measured on MI355X the kernel is bound
+// by VALU issue and by the length of the per-look-up dependency chain, so the design minimises
+// vector instructions per decoded byte:
+//   * two-symbol table with the OUTPUT baked in: while a task's Huffman tables are staged into
+//     LDS they are widened to W = max(max_bits, 8) index bits; a 64-bit entry holds the bytes to
+//     emit for the next one or two symbols (for DNA/RNA: the 2 x 2 IUPAC characters of the two
+//     packed bytes -- SequenceReader::read_nucleotide/decode, reader.rs:121-172, costs nothing per
+//     symbol and the 4-bit intermediate never reaches HBM), the bits consumed and the bytes produced.
+//     DNA codes are ~4 bits, so almost every look-up yields four bases.
+//   * bit window: {hi, lo, nw} are three consecutive 32-bit words of the backward stream,
+//     s = 32 - (bits of hi consumed) in [0, 31]; peek = v_alignbit_b32(hi, lo, s); consuming len
+//     bits is s -= len, a borrow meaning "advance one word", s &= 31.
 //   * input ring: 16 words per lane in LDS, stored transposed (word x of lane l at x*64 + l: any
 //     mix of positions is bank-conflict free), refilled by the lane itself with 16-byte aligned
-//     global loads, one chunk in flight, serviced every 8 look-ups.  Invariant (look-ups consume
-//     <= 11 bits, so <= 3 words per service period): >= 6 staged words ahead after each service.
-//   * output: lanes progress at different speeds (1 or 2 symbols per look-up), so each lane
-//     appends packed bytes to its own 64-byte ring in LDS whose position is congruent to the
-//     destination offset mod 32.  After every 16 look-ups the wave flushes one 32-byte unit per
-//     ready row cooperatively: 4 lanes per row, each expands 8 packed bytes to 16 IUPAC characters
-//     (v_perm_b32 LUT; reader.rs:121-172) and stores one aligned dwordx4 -- 64 contiguous bytes per
-//     row per store instruction.  The 4-bit intermediate never reaches HBM (ASCII = true); text
-//     sections (ASCII = false) store the bytes as they are.
+//     global loads, one 32-byte pair in flight, serviced once per round of 16 look-ups.  Invariant
+//     (a look-up consumes <= 11 bits, so a round <= 6 words, + 2 words of look-ahead): >= 9
+//     staged words past the cursor after each service.
+//   * output: each lane appends to its own 128-byte row in LDS whose byte 0 is 64-byte aligned
+//     in the destination; look-ups store with constant offsets from a running write address (no
+//     wrap arithmetic).  Once per round the wave copies one complete 64-byte unit per ready row
+//     to HBM cooperatively -- 4 lanes per row, one aligned dwordx4 each, so a store instruction
+//     writes 16 whole 64-byte segments -- and the row's owner moves its leftover (< 64 B) down.
+//   * a round is [request next input pair] -> [flush previous round's output] -> [16 look-ups] ->
+//     [land the pair].  The VM counter retires loads and stores in issue order, so the loads and
+//     stores go through gfx950/nafgpu_vmem.h with a fixed count per round and the landing waits
+//     `vmcnt(4)`: the loads are back, the round's stores stay in flight.
 constexpr uint32_t kRingWords = 16;
-constexpr uint32_t kOutRing = 64;        // packed bytes per lane
-constexpr uint32_t kOutPitch = 72;       // row pitch in bytes (8-byte aligned rows + spill room)
-constexpr uint32_t kUnit = 32;           // packed bytes flushed per row at a time
+constexpr uint32_t kOutPitch = 136;      // row pitch in bytes: 128 used, 8-byte aligned rows, 2-way banks at worst
+constexpr uint32_t kUnit = 64;           // output bytes flushed per row at a time
 
-struct HufLane {
-    uint32_t hi, lo, nw;   // bit window: hi = word under the cursor, lo = next, nw = the one after
-    uint32_t c;            // bits of hi already consumed, kept in [1, 32]
-    uint32_t rp;           // ring index of hi
-};
+// Ordering point for LDS traffic inside a ONE-WAVE workgroup.  LDS instructions of a wave execute in
+// issue order, so no s_waitcnt / s_barrier is needed -- only the compiler must not move LDS accesses
+// across this point.  Unlike __syncthreads() this does not wait for outstanding global stores
+// (vmcnt), which is what lets the flush stores stay in flight behind the next look-ups.
+__device__ inline void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
-// table entry: sym1 | sym2 << 8 | len << 16 | len1 << 20 | two << 24
-//   two  = 1 when sym2 is valid;  len = bits consumed when taking everything the entry offers
-//   len1 = bits of sym1 alone (used when only one symbol of the stream is left)
+// table entry (uint2):
+//   .x  bytes to emit: first symbol in the low half, second symbol in the high half
+//       (ASCII: two characters per symbol; plain: one byte per symbol, in bits 0-7 and 16-23)
+//   .y  bits  0-7  bits consumed when everything the entry offers is taken
+//       bits  8-15 output bytes produced then
+//       bits 16-23 bits consumed by the first symbol alone (stream tail)
+//       bit  24    entry holds two symbols
 
 // "-TGKCYSBAWRDMHVN"[nib], with index 1 = t_char ('T' for DNA, 'U' for RNA)  (reader.rs:152-172)
 __device__ inline uint32_t nib_char(uint32_t nib, uint32_t t_char) {
@@ -75,36 +90,21 @@ __device__ inline uint32_t byte_chars(uint32_t b, uint32_t t_char) {
     return nib_char(b & 15u, t_char) | (nib_char(b >> 4, t_char) << 8);
 }
 
-// 4 nibbles (one per byte of `nib`) -> 4 characters
-__device__ inline uint32_t lut4(uint32_t nib, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
-    const uint32_t sel = nib & 0x07070707u;
-    const uint32_t lo = __builtin_amdgcn_perm(t1, t0, sel);
-    const uint32_t hi = __builtin_amdgcn_perm(t3, t2, sel);
-    const uint32_t m = ((nib >> 3) & 0x01010101u) * 0xFFu;
-    return (hi & m) | (lo & ~m);
-}
-// 4 packed bytes -> 8 characters (o0 = bases 0..3, o1 = bases 4..7)
-__device__ inline void unpack_dword(uint32_t w, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t *o0,
-                                    uint32_t *o1) {
-    const uint32_t L = lut4(w & 0x0F0F0F0Fu, t0, t1, t2, t3);
-    const uint32_t H = lut4((w >> 4) & 0x0F0F0F0Fu, t0, t1, t2, t3);
-    *o0 = __builtin_amdgcn_perm(H, L, 0x05010400u);   // L0 H0 L1 H1
-    *o1 = __builtin_amdgcn_perm(H, L, 0x07030602u);   // L2 H2 L3 H3
-}
+struct HufLane {
+    uint32_t hi, lo, nw;   // bit window: hi = word under the cursor, lo = next, nw = the one after
+    uint32_t s;            // 32 - (bits of hi consumed), in [0, 31]
+    uint32_t ra;           // LDS byte offset (inside s_ring) of the look-ahead word: ((rp + 2) & 15) << 8 | lane << 2
+};
 
-// one table look-up; returns the entry.  take = symbols actually taken (0, 1 or 2).
-__device__ inline uint32_t huf_lookup(HufLane &L, const uint32_t *tbl, uint32_t sh, const uint32_t *ring_lane,
-                                      uint32_t len) {
-    L.c += len;
-    const bool adv = L.c > 32u;
+// consume `len` bits: on a borrow shift the window by one word and fetch the next look-ahead
+__device__ inline void huf_advance(HufLane &L, const uint8_t *ring_bytes, uint32_t len) {
+    const uint32_t s2 = L.s - len;
+    const bool adv = static_cast<int32_t>(s2) < 0;
+    L.s = s2 & 31u;
     L.hi = adv ? L.lo : L.hi;
     L.lo = adv ? L.nw : L.lo;
-    L.c = adv ? L.c - 32u : L.c;
-    L.rp += adv ? 1u : 0u;
-    L.nw = ring_lane[((L.rp + 2u) & (kRingWords - 1)) * 64u];
-    (void)tbl;
-    (void)sh;
-    return 0;
+    L.ra = (L.ra + (adv ? 256u : 0u)) & 0xFFFu;
+    L.nw = *reinterpret_cast<const uint32_t *>(ring_bytes + L.ra);
 }
 
 template <bool ASCII>
@@ -113,20 +113,22 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
                                                    const HufStream *__restrict__ streams,
                                                    const uint16_t *__restrict__ pool,
                                                    const uint64_t *__restrict__ blk_base, uint8_t *out, uint8_t *lit,
-                                                   uint32_t t_char, uint32_t *status) {
-    HIP_DYNAMIC_SHARED(uint32_t, s_tbl)
-    __shared__ uint32_t s_ring[kRingWords * 64];
+                                                   uint32_t t_char, uint32_t dbg, uint32_t *status) {
+    constexpr uint32_t kOutB = ASCII ? 2 : 1;              // output bytes per symbol
+    HIP_DYNAMIC_SHARED(uint2, s_tbl)
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kRingWords * 64 * 4];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[64 * kOutPitch];
-    __shared__ uint64_t s_dst[64];     // destination of ring coordinate 0 (packed-byte offset; bit 63: literal buffer)
-    __shared__ uint32_t s_h[64];       // first valid ring coordinate of the row (bytes before it belong to another stream)
-    __shared__ uint32_t s_q[64];       // ring coordinate of the row's next write
-    __shared__ uint32_t s_fl[64];      // ring coordinate up to which the row has been flushed (multiple of kUnit)
+    __shared__ uint64_t s_dst[64];     // destination byte offset of row coordinate 0 (64-byte aligned); bit 63: literal buffer
+    __shared__ uint64_t s_unit[64];    // per round: the row's flush descriptor (see publish)
+    __shared__ uint32_t s_h[64];       // first row coordinate that belongs to this stream
+    __shared__ uint32_t s_q[64];       // row coordinate of the next write
+    __shared__ uint32_t s_fl[64];      // row coordinate of the row's byte 0 (multiple of kUnit)
 
     if (status[0] != 0) return;
     const uint32_t lane = threadIdx.x;
     const HufTask task = tasks[blockIdx.x];
 
-    // ---- stage the task's tables, widened to two symbols per entry
+    // ---- stage the task's tables, widened to two symbols per entry, output bytes baked in
     for (uint32_t k = 0; k < task.n_copies; k++) {
         const HufTblCopy cp = copies[task.first_copy + k];
         const uint32_t mb = cp.bits & 0xFFu, W = cp.bits >> 8;
@@ -138,26 +140,26 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
             const uint32_t e2 = x1[(v << l1) >> (32u - mb)];
             const uint32_t l2 = e2 >> 8;
             const uint32_t two = l1 + l2 <= W ? 1u : 0u;
-            s_tbl[cp.lds_off + i] = (e1 & 0xFFu) | ((e2 & 0xFFu) << 8) | ((two ? l1 + l2 : l1) << 16) | (l1 << 20) | (two << 24);
+            const uint32_t o1 = ASCII ? byte_chars(e1 & 0xFFu, t_char) : (e1 & 0xFFu);
+            const uint32_t o2 = ASCII ? byte_chars(e2 & 0xFFu, t_char) : (e2 & 0xFFu);
+            s_tbl[cp.lds_off + i] = make_uint2(o1 | (o2 << 16), (two ? l1 + l2 : l1) | (((1u + two) * kOutB) << 8) | (l1 << 16) | (two << 24));
         }
     }
 
     const bool have = lane < task.n_streams;
     HufStream st{};
     if (have) st = streams[task.first_stream + lane];
-    const uint32_t n = st.n_syms;
     const uint32_t sh = 32u - st.max_bits;                 // max_bits holds W here
-    const uint32_t *tbl = s_tbl + st.tbl_lds;
-    uint32_t *ring = s_ring + lane;                        // word x at ring[x * 64]
-    uint8_t *orow = s_out + lane * kOutPitch;
+    const uint2 *tbl = s_tbl + st.tbl_lds;
+    uint8_t *const orow = s_out + lane * kOutPitch;
 
-    HufLane L{0, 0, 0, 1, 0};
+    HufLane L{0, 0, 0, 31, 0};
     const uint8_t *ctop = nullptr;       // 16-byte chunk holding the stream's last byte
-    uint32_t wp = 0, lp = 0;             // chunks written to the ring / issued
-    uint4 pend = make_uint4(0, 0, 0, 0);
+    uint32_t wp = 0;                     // 32-byte chunk pairs landed in the ring
     uint32_t c0 = 1, rp0 = 0, bits_total = 0;
     bool bad = false;
-    uint32_t cur = 0, n_end = 0, fl = 0;                   // ring coordinates: next write, end of stream, flushed
+    uint8_t *wa = orow;                  // next write address inside the row
+    uint32_t rbase = 0, end_abs = 0, h = 0;   // row coordinate of orow[0]; end and start of the stream in row coordinates
     if (have) {
         const uint8_t *lastp = src + st.src_end - 1;
         const uint32_t lastb = *lastp;
@@ -166,143 +168,197 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         bits_total = (st.src_len - 1u) * 8u + hb;
         const uintptr_t a = reinterpret_cast<uintptr_t>(lastp);
         ctop = lastp - (a & 15);                                 // stays a global-memory pointer (no flat loads)
-        L.rp = 3u - static_cast<uint32_t>((a >> 2) & 3u);
-        L.c = (3u - static_cast<uint32_t>(a & 3u)) * 8u + (8u - hb);
-        c0 = L.c;
-        rp0 = L.rp;
-        for (uint32_t j = 0; j < 3; j++) {
+        rp0 = 3u - static_cast<uint32_t>((a >> 2) & 3u);
+        c0 = (3u - static_cast<uint32_t>(a & 3u)) * 8u + (8u - hb);   // bits of the top word already "consumed"
+        L.s = 32u - c0;
+        for (uint32_t j = 0; j < 4; j++) {                       // the whole ring: 4 chunks = 2 pairs
             const uint4 v = *reinterpret_cast<const uint4 *>(ctop - 16 * j);
-            ring[(4 * j + 0) * 64] = v.w;
-            ring[(4 * j + 1) * 64] = v.z;
-            ring[(4 * j + 2) * 64] = v.y;
-            ring[(4 * j + 3) * 64] = v.x;
+            uint32_t *r = reinterpret_cast<uint32_t *>(s_ring) + lane;
+            r[(4 * j + 0) * 64] = v.w;
+            r[(4 * j + 1) * 64] = v.z;
+            r[(4 * j + 2) * 64] = v.y;
+            r[(4 * j + 3) * 64] = v.x;
         }
-        wp = 3;
-        pend = *reinterpret_cast<const uint4 *>(ctop - 48);
-        lp = 4;
-        L.hi = ring[L.rp * 64];
-        L.lo = ring[(L.rp + 1) * 64];
-        L.nw = ring[(L.rp + 2) * 64];
-        const uint64_t dstart = (st.flags & 1) ? st.dst : blk_base[st.blk] + st.dst;   // packed-byte offset
-        cur = static_cast<uint32_t>(dstart & (kUnit - 1));
-        n_end = cur + n;
-        s_dst[lane] = (dstart - cur) | ((st.flags & 1) ? (1ull << 63) : 0ull);
-        s_h[lane] = cur;
+        wp = 2;
+        const uint32_t *r = reinterpret_cast<const uint32_t *>(s_ring) + lane;
+        L.hi = r[rp0 * 64];
+        L.lo = r[(rp0 + 1) * 64];
+        L.nw = r[(rp0 + 2) * 64];
+        L.ra = ((rp0 + 2) << 8) | (lane << 2);
+        const uint64_t dstart = ((st.flags & 1) ? st.dst : blk_base[st.blk] + st.dst) * ((st.flags & 1) ? 1 : kOutB);
+        h = static_cast<uint32_t>(dstart & (kUnit - 1));
+        end_abs = h + st.n_syms * ((st.flags & 1) ? 1 : kOutB);
+        wa = orow + h;
+        s_dst[lane] = (dstart - h) | ((st.flags & 1) ? (1ull << 63) : 0ull);
     } else {
         s_dst[lane] = 0;
-        s_h[lane] = 0;
     }
-
+    s_h[lane] = h;
     __syncthreads();                                       // tables and row metadata are staged
 
-    // "-TGKCYSBAWRDMHVN" as four LUT dwords (index 1 = T or U)
-    const uint32_t t0 = 0x4B47002Du | (t_char << 8), t1 = 0x42535943u, t2 = 0x44525741u, t3 = 0x4E56484Du;
-
-    // flush one unit (<= 32 packed bytes) of every ready row; final = also partial units
-    auto flush = [&](bool final) {
+    // ---- flush: one 64-byte unit per ready row, 4 lanes per row.  The row's owner publishes a
+    // descriptor; complete units (the common case) take the branch-light fast path, the first and
+    // last unit of a stream (bytes of a neighbouring stream / not produced yet) the generic one.
+    constexpr uint64_t kFlagLit = 1ull << 63, kFlagReady = 1ull << 62, kFlagFull = 1ull << 61;
+    constexpr uint64_t kPosMask = kFlagFull - 1;
+    const uint32_t qd = lane & 3;
+    const uint32_t frow0 = lane >> 2;                      // this lane serves rows frow0 + 16 k
+    auto publish = [&](bool final) {
+        const uint32_t avail = static_cast<uint32_t>(wa - orow);
+        const bool ready = have && (avail >= kUnit || (final && avail > 0));
+        const bool full = rbase >= h && avail >= kUnit;
+        const uint64_t d = s_dst[lane];
+        s_unit[lane] = ((d & ~kFlagLit) + rbase) | (d & kFlagLit) | (ready ? kFlagReady : 0) | (ready && full ? kFlagFull : 0);
+        s_q[lane] = rbase + avail;
+        s_fl[lane] = rbase;
+    };
+    uint8_t *const sink = reinterpret_cast<uint8_t *>(status) + 32;   // 16 scratch bytes for lanes with nothing to store
+    // Every call issues >= 4 vector-memory stores per lane slot (rows that are not ready store to the
+    // sink), so that the refill wait below can be the counted `vmcnt(4)` -- see gfx950/nafgpu_vmem.h.
+    auto flush = [&]() {
+        uint64_t u[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) u[k] = s_unit[frow0 + 16 * k];
+        const bool slow = __any((((u[0] & kFlagReady) && !(u[0] & kFlagFull)) || ((u[1] & kFlagReady) && !(u[1] & kFlagFull)) ||
+                                 ((u[2] & kFlagReady) && !(u[2] & kFlagFull)) || ((u[3] & kFlagReady) && !(u[3] & kFlagFull)))
+                                    ? 1 : 0) != 0;
+        if (slow) {
+            // first / last unit of a stream: bytes of a neighbouring stream or not produced yet
+#pragma unroll 1
+            for (uint32_t k = 0; k < 4; k++) {
+                if (!(u[k] & kFlagReady) || (dbg & 1u)) continue;
+                const uint32_t row = frow0 + 16 * k;
+                const uint32_t rfl = s_fl[row], rq = s_q[row], rh = s_h[row];
+                const uint32_t lo_x = rfl + 16 * qd, hi_x = lo_x + 16;
+                const uint32_t v_lo = lo_x > rh ? lo_x : rh, v_hi = hi_x < rq ? hi_x : rq;
+                uint8_t *d = ((u[k] & kFlagLit) ? lit : out) + (u[k] & kPosMask) + 16 * qd;
+                const uint8_t *rowp = s_out + row * kOutPitch + 16 * qd;
+                for (uint32_t x = v_lo; x < v_hi; x++) d[x - lo_x] = rowp[x - lo_x];
+            }
+        }
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++) {
-            const uint32_t row = (lane >> 2) + 16 * k;
-            const uint32_t qd = lane & 3;
-            const uint32_t rfl = s_fl[row], rq = s_q[row];
-            const uint32_t avail = rq - rfl;
-            if (avail >= kUnit || (final && avail > 0)) {
-                const uint32_t lo_x = rfl + 8 * qd, hi_x = lo_x + 8;
-                const uint32_t rh = s_h[row];
-                const uint32_t v_lo = lo_x > rh ? lo_x : rh, v_hi = hi_x < rq ? hi_x : rq;
-                if (v_lo < v_hi) {
-                    const uint2 w = *reinterpret_cast<const uint2 *>(s_out + row * kOutPitch + (lo_x & (kOutRing - 1)));
-                    const uint64_t doff = s_dst[row];
-                    const uint64_t pos = (doff & ~(1ull << 63)) + lo_x;          // packed-byte offset of this quarter
-                    uint8_t *base = (doff >> 63) ? lit : out;
-                    const bool full = v_lo == lo_x && v_hi == hi_x;
-                    if (ASCII) {
-                        uint4 a;
-                        unpack_dword(w.x, t0, t1, t2, t3, &a.x, &a.y);
-                        unpack_dword(w.y, t0, t1, t2, t3, &a.z, &a.w);
-                        if (full) {
-                            *reinterpret_cast<uint4 *>(base + 2 * pos) = a;
-                        } else {
-                            const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
-                            for (uint32_t x = v_lo; x < v_hi; x++) {
-                                const uint32_t b = 2 * (x - lo_x);
-                                reinterpret_cast<uint16_t *>(base)[pos + (x - lo_x)] =
-                                    static_cast<uint16_t>(aw[b >> 2] >> (8 * (b & 3)));
-                            }
-                        }
-                    } else if (full) {
-                        *reinterpret_cast<uint2 *>(base + pos) = w;
-                    } else {
-                        const uint32_t ww[2] = {w.x, w.y};
-                        for (uint32_t x = v_lo; x < v_hi; x++) {
-                            const uint32_t b = x - lo_x;
-                            base[pos + b] = static_cast<uint8_t>(ww[b >> 2] >> (8 * (b & 3)));
-                        }
-                    }
-                }
-            }
+            const uint8_t *rowp = s_out + (frow0 + 16 * k) * kOutPitch + 16 * qd;
+            const uint2 w0 = *reinterpret_cast<const uint2 *>(rowp);
+            const uint2 w1 = *reinterpret_cast<const uint2 *>(rowp + 8);
+            const bool go = !slow && (u[k] & kFlagReady) && !(dbg & 1u);
+            uint8_t *d = go ? ((u[k] & kFlagLit) ? lit : out) + ((u[k] & kPosMask) & ((dbg & 64u) ? 0x1FFFC0ull : ~0ull)) + 16 * qd : sink;
+            vm_u32x4 v;
+            v.x = w0.x;
+            v.y = w0.y;
+            v.z = w1.x;
+            v.w = w1.y;
+            if (dbg & 8u)
+                __builtin_nontemporal_store(v, reinterpret_cast<vm_u32x4 *>(d));   // ablation: streaming stores
+            else
+                vm_store16(d, v);
         }
     };
 
+    // One round = [request the next 32-byte pair] -> [flush what the previous round produced] ->
+    // [16 look-ups] -> [land the pair].  Per round the wave issues exactly 2 VM loads followed by
+    // >= 4 VM stores, so `vmcnt(4)` retires the loads without waiting for the stores.
+    const uint8_t *const lbase = have ? ctop : src;
+    vm_wait<0>();                                          // nothing of the prologue is left in flight
     int any = 1;
     while (any) {
-        if (cur < n_end) {
-#pragma unroll 1
-            for (uint32_t g = 0; g < 2; g++) {
-                if (cur >= n_end) break;
-                // ---- service the input ring: land the chunk in flight, then issue the next one
-                if (lp > wp) {
-                    const uint32_t x0 = (4 * wp) & (kRingWords - 1);
-                    ring[(x0 + 0) * 64] = pend.w;
-                    ring[(x0 + 1) * 64] = pend.z;
-                    ring[(x0 + 2) * 64] = pend.y;
-                    ring[(x0 + 3) * 64] = pend.x;
-                    wp++;
-                }
-                if (4 * lp + 3 < L.rp + kRingWords) {
-                    pend = *reinterpret_cast<const uint4 *>(ctop - 16 * static_cast<size_t>(lp));
-                    lp++;
-                }
-                if (cur + 16 <= n_end) {                   // 8 look-ups cannot overrun the stream
+        const vm_u32x4 p0 = vm_load16(lbase - 32 * static_cast<size_t>(wp));
+        const vm_u32x4 p1 = vm_load16(lbase - 32 * static_cast<size_t>(wp) - 16);
+        publish(false);
+        wave_sync();
+        flush();
+        wave_sync();
+        if (static_cast<uint32_t>(wa - orow) >= kUnit) {   // the flush above took this row's first 64 bytes
+            const uint2 m0 = *reinterpret_cast<const uint2 *>(orow + 64), m1 = *reinterpret_cast<const uint2 *>(orow + 72);
+            const uint2 m2 = *reinterpret_cast<const uint2 *>(orow + 80), m3 = *reinterpret_cast<const uint2 *>(orow + 88);
+            const uint2 m4 = *reinterpret_cast<const uint2 *>(orow + 96), m5 = *reinterpret_cast<const uint2 *>(orow + 104);
+            const uint2 m6 = *reinterpret_cast<const uint2 *>(orow + 112), m7 = *reinterpret_cast<const uint2 *>(orow + 120);
+            *reinterpret_cast<uint2 *>(orow + 0) = m0;
+            *reinterpret_cast<uint2 *>(orow + 8) = m1;
+            *reinterpret_cast<uint2 *>(orow + 16) = m2;
+            *reinterpret_cast<uint2 *>(orow + 24) = m3;
+            *reinterpret_cast<uint2 *>(orow + 32) = m4;
+            *reinterpret_cast<uint2 *>(orow + 40) = m5;
+            *reinterpret_cast<uint2 *>(orow + 48) = m6;
+            *reinterpret_cast<uint2 *>(orow + 56) = m7;
+            wa -= kUnit;
+            rbase += kUnit;
+        }
+        const uint32_t pos = rbase + static_cast<uint32_t>(wa - orow);
+        if (dbg & 4u) {                                    // ablation: no decode, rows fill instantly
+            if (pos < end_abs) wa += (end_abs - pos < kUnit ? end_abs - pos : kUnit);
+        } else if (pos + 32 * kOutB <= end_abs) {          // 16 look-ups cannot overrun the stream
 #pragma unroll
-                    for (uint32_t k = 0; k < 8; k++) {
-                        const uint32_t e = tbl[__builtin_amdgcn_alignbit(L.hi, L.lo, 32u - L.c) >> sh];
-                        orow[cur & (kOutRing - 1)] = static_cast<uint8_t>(e);
-                        orow[(cur + 1) & (kOutRing - 1)] = static_cast<uint8_t>(e >> 8);
-                        cur += 1u + ((e >> 24) & 1u);
-                        huf_lookup(L, tbl, sh, ring, (e >> 16) & 15u);
-                    }
-                } else {                                   // tail of the stream: never take more than is left
-#pragma unroll
-                    for (uint32_t k = 0; k < 8; k++) {
-                        const uint32_t e = tbl[__builtin_amdgcn_alignbit(L.hi, L.lo, 32u - L.c) >> sh];
-                        const uint32_t left = n_end - cur;
-                        const bool two = ((e >> 24) & 1u) && left >= 2;
-                        orow[cur & (kOutRing - 1)] = static_cast<uint8_t>(e);
-                        orow[(cur + 1) & (kOutRing - 1)] = static_cast<uint8_t>(e >> 8);
-                        cur += left == 0 ? 0u : (two ? 2u : 1u);
-                        huf_lookup(L, tbl, sh, ring, left == 0 ? 0u : (two ? (e >> 16) & 15u : (e >> 20) & 15u));
-                    }
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint2 e = tbl[__builtin_amdgcn_alignbit(L.hi, L.lo, L.s) >> sh];
+                if (ASCII) {
+                    reinterpret_cast<uint16_t *>(wa)[0] = static_cast<uint16_t>(e.x);
+                    reinterpret_cast<uint16_t *>(wa)[1] = static_cast<uint16_t>(e.x >> 16);
+                } else {
+                    wa[0] = static_cast<uint8_t>(e.x);
+                    wa[1] = static_cast<uint8_t>(e.x >> 16);
                 }
+                wa += (e.y >> 8) & 0xFFu;
+                huf_advance(L, s_ring, e.y & 0xFFu);
+            }
+        } else if (pos < end_abs) {                        // tail of the stream: never take more than is left
+#pragma unroll 4
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint2 e = tbl[__builtin_amdgcn_alignbit(L.hi, L.lo, L.s) >> sh];
+                const uint32_t left = end_abs - (rbase + static_cast<uint32_t>(wa - orow));   // bytes
+                const bool two = (e.y >> 24) && left >= 2 * kOutB;
+                if (ASCII) {
+                    reinterpret_cast<uint16_t *>(wa)[0] = static_cast<uint16_t>(e.x);
+                    reinterpret_cast<uint16_t *>(wa)[1] = static_cast<uint16_t>(e.x >> 16);
+                } else {
+                    wa[0] = static_cast<uint8_t>(e.x);
+                    wa[1] = static_cast<uint8_t>(e.x >> 16);
+                }
+                wa += left == 0 ? 0u : (two ? 2 * kOutB : kOutB);
+                huf_advance(L, s_ring, left == 0 ? 0u : (two ? e.y & 0xFFu : (e.y >> 16) & 0xFFu));
             }
         }
-        s_q[lane] = cur;
-        s_fl[lane] = fl;
-        __syncthreads();
-        flush(false);
-        any = __syncthreads_or(cur < n_end ? 1 : 0);
-        if (cur - fl >= kUnit) fl += kUnit;                // what the flush above wrote for this lane's row
+        // ---- land the pair requested at the top of the round, if the ring has room for it.
+        // d = words between the oldest ring slot and the cursor; staged past the cursor = 16 - d;
+        // 8 words fit once d >= 8.  A round uses <= 6 words + 2 of look-ahead, and d >= 8 whenever
+        // fewer than 9 are staged, so the cursor never outruns the ring.
+        vm_wait<4>();
+        const uint32_t rp_mod = ((L.ra >> 8) - 2u) & 15u;
+        const uint32_t d = (rp_mod - 8u * wp) & 15u;
+        if (have && d >= 8u && !(dbg & 32u)) {
+            uint32_t *r = reinterpret_cast<uint32_t *>(s_ring) + lane + ((8 * wp) & (kRingWords - 1)) * 64;
+            r[0 * 64] = p0.w;
+            r[1 * 64] = p0.z;
+            r[2 * 64] = p0.y;
+            r[3 * 64] = p0.x;
+            r[4 * 64] = p1.w;
+            r[5 * 64] = p1.z;
+            r[6 * 64] = p1.y;
+            r[7 * 64] = p1.x;
+            wp++;
+        }
+        any = __any(rbase + static_cast<uint32_t>(wa - orow) < end_abs ? 1 : 0);
     }
-    for (uint32_t t = 0; t < 2; t++) {                     // at most 63 bytes are left in a row
-        s_q[lane] = cur;
-        s_fl[lane] = fl;
-        __syncthreads();
-        flush(true);
-        __syncthreads();
-        fl = cur - fl > kUnit ? fl + kUnit : cur;
+    for (uint32_t t = 0; t < 2; t++) {                     // at most 63 + 64 bytes are left in a row
+        publish(true);
+        wave_sync();
+        flush();
+        wave_sync();
+        const uint32_t avail = static_cast<uint32_t>(wa - orow);
+        if (avail > kUnit) {
+            for (uint32_t j = 0; j < 64; j += 8) *reinterpret_cast<uint2 *>(orow + j) = *reinterpret_cast<const uint2 *>(orow + 64 + j);
+            wa -= kUnit;
+            rbase += kUnit;
+        } else {
+            rbase += avail;
+            wa = orow;
+        }
     }
-    if (have) {
-        const uint32_t consumed = 32u * (L.rp - rp0) + L.c - c0;
+    if (have && !(dbg & 36u)) {
+        // words advanced: the ring holds absolute words [8 wp - 16, 8 wp)
+        const uint32_t rp_mod = ((L.ra >> 8) - 2u) & 15u;
+        const uint32_t rp_abs = 8u * wp - 16u + ((rp_mod - 8u * wp) & 15u);
+        const uint32_t consumed = 32u * (rp_abs - rp0) + (32u - L.s) - c0;
         if (bad || consumed != bits_total) flag_error(status, kStHufBadEnd, task.first_stream + lane);
     }
 }
@@ -693,6 +749,22 @@ __global__ __launch_bounds__(256) void k_lz_execute(const SeqBlock *__restrict__
 // Byte b of the packed stream yields LUT[b & 15] then LUT[b >> 4]; records are contiguous in
 // nibble space, so record k is bases [end[k-1], end[k]) of this one flat array -- the odd-nibble
 // `cache` of reader.rs:92-94,138-143 is just an odd offset here.
+__device__ inline uint32_t lut4(uint32_t nib, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
+    const uint32_t sel = nib & 0x07070707u;
+    const uint32_t lo = __builtin_amdgcn_perm(t1, t0, sel);
+    const uint32_t hi = __builtin_amdgcn_perm(t3, t2, sel);
+    const uint32_t m = ((nib >> 3) & 0x01010101u) * 0xFFu;
+    return (hi & m) | (lo & ~m);
+}
+
+__device__ inline void unpack_dword(uint32_t w, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t *o0,
+                                    uint32_t *o1) {
+    const uint32_t L = lut4(w & 0x0F0F0F0Fu, t0, t1, t2, t3);
+    const uint32_t H = lut4((w >> 4) & 0x0F0F0F0Fu, t0, t1, t2, t3);
+    *o0 = __builtin_amdgcn_perm(H, L, 0x05010400u);   // L0 H0 L1 H1
+    *o1 = __builtin_amdgcn_perm(H, L, 0x07030602u);   // L2 H2 L3 H3
+}
+
 __global__ __launch_bounds__(256) void k_unpack4(const uint8_t *__restrict__ packed, uint64_t n_packed,
                                                  uint8_t *__restrict__ ascii, uint64_t n_bases, uint32_t t_char,
                                                  const uint32_t *status) {
@@ -890,13 +962,17 @@ void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *ta
                        const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t max_tbl_entries, bool ascii,
                        uint32_t t_char, uint32_t *status) {
     if (!n_tasks) return;
-    const uint32_t lds = ((max_tbl_entries * 4u) + 15u) & ~15u;
-    if (ascii)
+    const uint32_t lds = ((max_tbl_entries * 8u) + 15u) & ~15u;
+    static const uint32_t dbg = [] {                     // timing ablations only; results are wrong when set
+        const char *e = std::getenv("NAFGPU_K1_DEBUG");
+        return e ? static_cast<uint32_t>(std::atoi(e)) : 0u;
+    }();
+    if (ascii && !(dbg & 2u))
         hipLaunchKernelGGL(k_huf_decode<true>, dim3(n_tasks), dim3(64), lds, stream, src, tasks, copies, streams, pool,
-                           blk_base, out, lit, t_char, status);
+                           blk_base, out, lit, t_char, dbg, status);
     else
         hipLaunchKernelGGL(k_huf_decode<false>, dim3(n_tasks), dim3(64), lds, stream, src, tasks, copies, streams, pool,
-                           blk_base, out, lit, t_char, status);
+                           blk_base, out, lit, t_char, dbg, status);
 }
 
 void launch_lz_execute(hipStream_t stream, const SeqBlock *blocks, uint32_t n_blocks, const Seq *seqs,

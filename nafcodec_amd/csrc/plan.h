@@ -8,7 +8,7 @@ namespace nafgpu {
 
 constexpr uint32_t kBlockMax = 128u << 10;   // zstd Block_Maximum_Size
 constexpr int kHufWave = 64;                 // one Huffman stream per lane, one wave per workgroup
-constexpr uint32_t kHufLdsEntries = 4096;    // 4-byte decode-table entries a wave task may stage in LDS
+constexpr uint32_t kHufLdsEntries = 2048;    // 8-byte decode-table entries a wave task may stage in LDS
 // index width of the staged two-symbol table for a tree with `max_bits`-bit codes
 constexpr uint32_t huf_index_bits(uint32_t max_bits) { return max_bits < 8 ? 8 : max_bits; }
 constexpr uint32_t kSrcFrontPad = 256;       // bytes readable in front of any device source buffer
@@ -29,7 +29,7 @@ static_assert(sizeof(HufStream) == 32, "HufStream layout");
 
 struct HufTblCopy {      // build the two-symbol table of pool[pool_off ..) at LDS entry lds_off
     uint32_t pool_off;   // 2^max_bits single-symbol entries (len << 8 | sym) in the pool
-    uint32_t lds_off;    // first staged entry (4-byte entries)
+    uint32_t lds_off;    // first staged entry (8-byte entries)
     uint32_t n_entries;  // 2^W staged entries
     uint32_t bits;       // max_bits | W << 8
 };

@@ -44,6 +44,10 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &bo
 
 inline void __syncthreads() { hipemu::sync_threads(); }
 int __syncthreads_or(int pred);
+// wave-level primitives: the harness runs one-wave workgroups as a block of fibers
+inline void __builtin_amdgcn_fence(int, const char *) {}
+inline void __builtin_amdgcn_wave_barrier() { hipemu::sync_threads(); }
+inline int __any(int pred) { return __syncthreads_or(pred); }
 
 // ---- device intrinsics used by kernels.hip ------------------------------------------------
 inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz(static_cast<unsigned>(v)); }

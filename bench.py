@@ -72,6 +72,26 @@ def cpu_baseline(lib, n_bases_target, mask):
                       % (n, len(blob) / 1e6, os.cpu_count() or 0)}
 
 
+def committed_traffic(n_bases):
+    """HBM-side bytes per k_huf_decode launch from the committed rocprofv3 PMC passes of this same
+    command (profiles/*_pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, values in bytes;
+    see the note in that file about the gfx950 FETCH_SIZE correction).  None for other workloads."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    if not os.path.isdir(pdir):
+        return None
+    for name in sorted(os.listdir(pdir)):
+        if name.endswith("_pmc_summary.json"):
+            try:
+                with open(os.path.join(pdir, name)) as f:
+                    j = json.load(f)
+            except (OSError, ValueError):
+                continue
+            if "40e9 bases" in j.get("command", "") and n_bases == DEFAULT_BASES:
+                best = int(j["FETCH_SIZE_bytes"] + j["WRITE_SIZE_bytes"])
+    return best
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -81,7 +101,9 @@ def main():
         args.gpus = world
 
     from nafcodec_amd import _ffi
-    lib = _ffi.default()                       # raises if libnafgpu.so is missing: no CPU fallback
+    # raises if libnafgpu.so is missing: no CPU fallback.  NAFGPU_LIB selects another BUILD OF THE SAME
+    # LIBRARY for A/B runs in one process environment (kernel variants); it is not a fallback path.
+    lib = _ffi.Library(os.environ["NAFGPU_LIB"]) if os.environ.get("NAFGPU_LIB") else _ffi.default()
     dist = torch = None
     if world > 1:
         import torch
@@ -189,7 +211,7 @@ def main():
                        "sharding": "block ranges, one 10 GB shard per GPU" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_huf_decode", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "ms_per_launch": round(k1, 3),
+                         "traffic": committed_traffic(n_bases), "ms_per_launch": round(k1, 3),
                          "algorithmic_bytes_per_launch": int(k1_bytes)},
             "path": {"device_ms_per_step": round(dev_ms, 3),
                      "algorithmic_GBps": round(path_bytes / (dev_ms * 1e-3) / 1e9, 1) if dev_ms else None,

@@ -15,8 +15,6 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include <nafgpu_vmem.h>
-
 #include "hash64.h"
 #include "kernels.h"
 #include "plan.h"
@@ -55,9 +53,8 @@ __device__ inline void flag_error(uint32_t *status, uint32_t code, uint32_t deta
 //     to HBM cooperatively -- 4 lanes per row, one aligned dwordx4 each, so a store instruction
 //     writes 16 whole 64-byte segments -- and the row's owner moves its leftover (< 64 B) down.
 //   * a round is [request next input pair] -> [flush previous round's output] -> [16 look-ups] ->
-//     [land the pair].  The VM counter retires loads and stores in issue order, so the loads and
-//     stores go through gfx950/nafgpu_vmem.h with a fixed count per round and the landing waits
-//     `vmcnt(4)`: the loads are back, the round's stores stay in flight.
+//     [land the pair]: the loads are older than the round's stores in the in-order VM counter and
+//     have a whole round to arrive.
 constexpr uint32_t kRingWords = 16;
 constexpr uint32_t kOutPitch = 136;      // row pitch in bytes: 128 used, 8-byte aligned rows, 2-way banks at worst
 constexpr uint32_t kUnit = 64;           // output bytes flushed per row at a time
@@ -212,9 +209,6 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         s_q[lane] = rbase + avail;
         s_fl[lane] = rbase;
     };
-    uint8_t *const sink = reinterpret_cast<uint8_t *>(status) + 32;   // 16 scratch bytes for lanes with nothing to store
-    // Every call issues >= 4 vector-memory stores per lane slot (rows that are not ready store to the
-    // sink), so that the refill wait below can be the counted `vmcnt(4)` -- see gfx950/nafgpu_vmem.h.
     auto flush = [&]() {
         uint64_t u[4];
 #pragma unroll
@@ -222,48 +216,48 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         const bool slow = __any((((u[0] & kFlagReady) && !(u[0] & kFlagFull)) || ((u[1] & kFlagReady) && !(u[1] & kFlagFull)) ||
                                  ((u[2] & kFlagReady) && !(u[2] & kFlagFull)) || ((u[3] & kFlagReady) && !(u[3] & kFlagFull)))
                                     ? 1 : 0) != 0;
-        if (slow) {
-            // first / last unit of a stream: bytes of a neighbouring stream or not produced yet
-#pragma unroll 1
-            for (uint32_t k = 0; k < 4; k++) {
-                if (!(u[k] & kFlagReady) || (dbg & 1u)) continue;
-                const uint32_t row = frow0 + 16 * k;
-                const uint32_t rfl = s_fl[row], rq = s_q[row], rh = s_h[row];
-                const uint32_t lo_x = rfl + 16 * qd, hi_x = lo_x + 16;
-                const uint32_t v_lo = lo_x > rh ? lo_x : rh, v_hi = hi_x < rq ? hi_x : rq;
-                uint8_t *d = ((u[k] & kFlagLit) ? lit : out) + (u[k] & kPosMask) + 16 * qd;
-                const uint8_t *rowp = s_out + row * kOutPitch + 16 * qd;
-                for (uint32_t x = v_lo; x < v_hi; x++) d[x - lo_x] = rowp[x - lo_x];
-            }
-        }
+        if (!slow) {
 #pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                if ((u[k] & kFlagReady) && !(dbg & 1u)) {
+                    const uint8_t *rowp = s_out + (frow0 + 16 * k) * kOutPitch + 16 * qd;
+                    const uint2 w0 = *reinterpret_cast<const uint2 *>(rowp);
+                    const uint2 w1 = *reinterpret_cast<const uint2 *>(rowp + 8);
+                    uint8_t *d = ((u[k] & kFlagLit) ? lit : out) + ((u[k] & kPosMask) & ((dbg & 64u) ? 0x1FFFC0ull : ~0ull)) + 16 * qd;
+                    *reinterpret_cast<uint4 *>(d) = make_uint4(w0.x, w0.y, w1.x, w1.y);
+                }
+            }
+            return;
+        }
+        // first / last unit of a stream: bytes of a neighbouring stream or not produced yet
+#pragma unroll 1
         for (uint32_t k = 0; k < 4; k++) {
-            const uint8_t *rowp = s_out + (frow0 + 16 * k) * kOutPitch + 16 * qd;
-            const uint2 w0 = *reinterpret_cast<const uint2 *>(rowp);
-            const uint2 w1 = *reinterpret_cast<const uint2 *>(rowp + 8);
-            const bool go = !slow && (u[k] & kFlagReady) && !(dbg & 1u);
-            uint8_t *d = go ? ((u[k] & kFlagLit) ? lit : out) + ((u[k] & kPosMask) & ((dbg & 64u) ? 0x1FFFC0ull : ~0ull)) + 16 * qd : sink;
-            vm_u32x4 v;
-            v.x = w0.x;
-            v.y = w0.y;
-            v.z = w1.x;
-            v.w = w1.y;
-            if (dbg & 8u)
-                __builtin_nontemporal_store(v, reinterpret_cast<vm_u32x4 *>(d));   // ablation: streaming stores
-            else
-                vm_store16(d, v);
+            if (!(u[k] & kFlagReady) || (dbg & 1u)) continue;
+            const uint32_t row = frow0 + 16 * k;
+            const uint32_t rfl = s_fl[row], rq = s_q[row], rh = s_h[row];
+            const uint32_t lo_x = rfl + 16 * qd, hi_x = lo_x + 16;
+            const uint32_t v_lo = lo_x > rh ? lo_x : rh, v_hi = hi_x < rq ? hi_x : rq;
+            uint8_t *d = ((u[k] & kFlagLit) ? lit : out) + (u[k] & kPosMask) + 16 * qd;
+            const uint8_t *rowp = s_out + row * kOutPitch + 16 * qd;
+            for (uint32_t x = v_lo; x < v_hi; x++) d[x - lo_x] = rowp[x - lo_x];
         }
     };
 
-    // One round = [request the next 32-byte pair] -> [flush what the previous round produced] ->
-    // [16 look-ups] -> [land the pair].  Per round the wave issues exactly 2 VM loads followed by
-    // >= 4 VM stores, so `vmcnt(4)` retires the loads without waiting for the stores.
+    // One round = [request the next 32-byte input pair unless one is still waiting for room] ->
+    // [flush what the previous round produced] -> [16 look-ups] -> [land the pair if it fits].
+    // Requesting before the flush makes the loads older than the round's stores in the in-order
+    // VM counter; measured alternatives (stores to a sink to make the count fixed, inline-asm
+    // counted waits) were slower or unsafe -- see DESIGN.md section 4.
     const uint8_t *const lbase = have ? ctop : src;
-    vm_wait<0>();                                          // nothing of the prologue is left in flight
+    uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0;
+    bool pending = false;
     int any = 1;
     while (any) {
-        const vm_u32x4 p0 = vm_load16(lbase - 32 * static_cast<size_t>(wp));
-        const vm_u32x4 p1 = vm_load16(lbase - 32 * static_cast<size_t>(wp) - 16);
+        if (!pending && have) {
+            p0 = *reinterpret_cast<const uint4 *>(lbase - 32 * static_cast<size_t>(wp));
+            p1 = *reinterpret_cast<const uint4 *>(lbase - 32 * static_cast<size_t>(wp) - 16);
+            pending = true;
+        }
         publish(false);
         wave_sync();
         flush();
@@ -322,10 +316,9 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         // d = words between the oldest ring slot and the cursor; staged past the cursor = 16 - d;
         // 8 words fit once d >= 8.  A round uses <= 6 words + 2 of look-ahead, and d >= 8 whenever
         // fewer than 9 are staged, so the cursor never outruns the ring.
-        vm_wait<4>();
         const uint32_t rp_mod = ((L.ra >> 8) - 2u) & 15u;
         const uint32_t d = (rp_mod - 8u * wp) & 15u;
-        if (have && d >= 8u && !(dbg & 32u)) {
+        if (pending && d >= 8u && !(dbg & 32u)) {
             uint32_t *r = reinterpret_cast<uint32_t *>(s_ring) + lane + ((8 * wp) & (kRingWords - 1)) * 64;
             r[0 * 64] = p0.w;
             r[1 * 64] = p0.z;
@@ -336,6 +329,7 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
             r[6 * 64] = p1.y;
             r[7 * 64] = p1.x;
             wp++;
+            pending = false;
         }
         any = __any(rbase + static_cast<uint32_t>(wa - orow) < end_abs ? 1 : 0);
     }

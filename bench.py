@@ -105,12 +105,17 @@ def main():
     # LIBRARY for A/B runs in one process environment (kernel variants); it is not a fallback path.
     lib = _ffi.Library(os.environ["NAFGPU_LIB"]) if os.environ.get("NAFGPU_LIB") else _ffi.default()
     dist = torch = None
+    tdev = "cpu"
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
-    device = local_rank
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+            tdev = "cuda"
+            dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        else:       # CPU rehearsal of the multi-rank control flow (tests/test_bench_multirank.py)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    device = local_rank if tdev == "cuda" or world == 1 else 0
 
     n_bases = int(args.bases)
     t0 = time.perf_counter()
@@ -136,7 +141,7 @@ def main():
     scratch = placement = None
     if world > 1:
         from nafcodec_amd.sharding import gather_placement
-        scratch = (torch.zeros(4, dtype=torch.int64, device="cuda"), torch.zeros(4 * world, dtype=torch.int64, device="cuda"))
+        scratch = (torch.zeros(4, dtype=torch.int64, device=tdev), torch.zeros(4 * world, dtype=torch.int64, device=tdev))
 
     def step():
         rc = lib.c.nafgpu_decode_all_device(h, ctypes.byref(res))
@@ -148,12 +153,13 @@ def main():
             # per-rank counts -> global base / record offsets of this shard
             nonlocal placement
             placement = gather_placement(dist, torch, res.n_bases, res.packed_bytes, res.n_records,
-                                         res.n_bases & 1, "cuda", scratch)
+                                         res.n_bases & 1, tdev, scratch)
 
     def sync():
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if tdev == "cuda":
+                torch.cuda.synchronize()
         lib.c.nafgpu_device_synchronize(device)
 
     for _ in range(args.warmup):
@@ -170,7 +176,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         total_bases = placement.total_bases
@@ -221,7 +227,7 @@ def main():
                      "host_plan_ms": round(res.ms_host_plan, 1), "h2d_ms": round(res.ms_h2d, 1),
                      "synth_s": round(t_gen, 1), "upload_s": round(t_upload, 2)},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:       # reported baseline, rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(lib, args.cpu_sample_bases, args.mask)
         print(json.dumps(line), flush=True)
 

@@ -37,6 +37,8 @@ def parse_args():
     ap.add_argument("--bases", type=float, default=float(os.environ.get("NAF_BENCH_BASES", DEFAULT_BASES)),
                     help="nucleotides per GPU (default 40e9 = the 10 GB archive of configs[1])")
     ap.add_argument("--mask", action="store_true", help="configs[3]: add a Mask section")
+    ap.add_argument("--iupac", type=int, default=0,
+                    help="per-mille of non-ACGT codes (N, R, Y ...): every block then carries its own deep Huffman tree")
     ap.add_argument("--cpu-sample-bases", type=float, default=0,
                     help="size of the CPU-baseline sample (0 = auto, about 15 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -119,7 +121,7 @@ def main():
 
     n_bases = int(args.bases)
     t0 = time.perf_counter()
-    arc = lib.synth(n_bases, seed=0x4E4146 + rank, with_mask=args.mask)
+    arc = lib.synth(n_bases, seed=0x4E4146 + rank, with_mask=args.mask, iupac_permille=args.iupac)
     t_gen = time.perf_counter() - t0
 
     opts = _ffi.Opts()
@@ -209,9 +211,10 @@ def main():
             "value": round(value, 3), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "synthetic %.1f GB DNA-only .naf per GPU (seq+len%s), %d bases, %d records, "
+            "config": {"workload": "synthetic %.1f GB DNA-only .naf per GPU (seq+len%s%s), %d bases, %d records, "
                                    "%d zstd blocks / %d Huffman streams, zstd-level-1 shape (L1), bit-exact check %s"
-                                   % (arc.n / 1e9, "+mask" if args.mask else "", res.n_bases, res.n_records,
+                                   % (arc.n / 1e9, "+mask" if args.mask else "", ", %d permille IUPAC" % args.iupac if args.iupac else "",
+                                      res.n_bases, res.n_records,
                                       res.n_zstd_blocks, res.n_huf_streams,
                                       "passed" if (ok and not args.no_verify) else "skipped"),
                        "sharding": "block ranges, one 10 GB shard per GPU" if world > 1 else "single GPU"},

@@ -125,21 +125,39 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     const uint32_t lane = threadIdx.x;
     const HufTask task = tasks[blockIdx.x];
 
-    // ---- stage the task's tables, widened to two symbols per entry, output bytes baked in
+    // ---- stage the task's tables: 2^W two-symbol entries with the output bytes baked in; W-bit
+    // prefixes whose first code is longer than W bits point to a 2^(max_bits - W) entry sub-table
     for (uint32_t k = 0; k < task.n_copies; k++) {
         const HufTblCopy cp = copies[task.first_copy + k];
         const uint32_t mb = cp.bits & 0xFFu, W = cp.bits >> 8;
         const uint16_t *x1 = pool + cp.pool_off;           // 2^mb entries of len << 8 | sym
-        for (uint32_t i = lane; i < cp.n_entries; i += 64) {
+        uint2 *t = s_tbl + cp.lds_off;
+        const uint32_t mbx = mb > W ? mb : W;              // bits that index x1 (zero-extended if mb < W)
+        uint32_t n_esc = 0;
+        for (uint32_t i = lane; i < (1u << W); i += 64) {
             const uint32_t v = i << (32u - W);             // the W index bits, left-aligned
             const uint32_t e1 = x1[v >> (32u - mb)];
             const uint32_t l1 = e1 >> 8;
-            const uint32_t e2 = x1[(v << l1) >> (32u - mb)];
-            const uint32_t l2 = e2 >> 8;
-            const uint32_t two = l1 + l2 <= W ? 1u : 0u;
-            const uint32_t o1 = ASCII ? byte_chars(e1 & 0xFFu, t_char) : (e1 & 0xFFu);
-            const uint32_t o2 = ASCII ? byte_chars(e2 & 0xFFu, t_char) : (e2 & 0xFFu);
-            s_tbl[cp.lds_off + i] = make_uint2(o1 | (o2 << 16), (two ? l1 + l2 : l1) | (((1u + two) * kOutB) << 8) | (l1 << 16) | (two << 24));
+            const bool esc = l1 > W;
+            const unsigned long long m = __ballot(esc ? 1 : 0);
+            const uint32_t rank = n_esc + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+            n_esc += static_cast<uint32_t>(__popcll(m));
+            if (!esc) {
+                const uint32_t e2 = x1[(v << l1) >> (32u - mb)];
+                const uint32_t l2 = e2 >> 8;
+                const uint32_t two = l1 + l2 <= W ? 1u : 0u;
+                const uint32_t o1 = ASCII ? byte_chars(e1 & 0xFFu, t_char) : (e1 & 0xFFu);
+                const uint32_t o2 = ASCII ? byte_chars(e2 & 0xFFu, t_char) : (e2 & 0xFFu);
+                t[i] = make_uint2(o1 | (o2 << 16), (two ? l1 + l2 : l1) | (((1u + two) * kOutB) << 8) | (l1 << 16) | (two << 24));
+            } else {
+                const uint32_t sub = (1u << W) + (rank << (mbx - W));
+                t[i] = make_uint2(sub, 1u << 25);
+                for (uint32_t j = 0; j < (1u << (mbx - W)); j++) {
+                    const uint32_t es = x1[(i << (mbx - W)) | j];
+                    const uint32_t o = ASCII ? byte_chars(es & 0xFFu, t_char) : (es & 0xFFu);
+                    t[sub + j] = make_uint2(o, (es >> 8) | (kOutB << 8) | ((es >> 8) << 16));
+                }
+            }
         }
     }
 
@@ -147,10 +165,19 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     HufStream st{};
     if (have) st = streams[task.first_stream + lane];
     const uint32_t sh = 32u - st.max_bits;                 // max_bits holds W here
+    const uint32_t esc_bits = st.flags >> 4;               // tree max_bits - W
+    const uint32_t sh2 = sh - esc_bits, esc_mask = (1u << esc_bits) - 1u;
     const uint2 *tbl = s_tbl + st.tbl_lds;
     uint8_t *const orow = s_out + lane * kOutPitch;
 
     HufLane L{0, 0, 0, 31, 0};
+    // one table look-up on the next bits of the stream; rare long codes take a second, sub-table look-up
+    auto lookup = [&]() -> uint2 {
+        const uint32_t peek = __builtin_amdgcn_alignbit(L.hi, L.lo, L.s);
+        uint2 e = tbl[peek >> sh];
+        if (e.y & (1u << 25)) e = tbl[e.x + ((peek >> sh2) & esc_mask)];
+        return e;
+    };
     const uint8_t *ctop = nullptr;       // 16-byte chunk holding the stream's last byte
     uint32_t wp = 0;                     // 32-byte chunk pairs landed in the ring
     uint32_t c0 = 1, rp0 = 0, bits_total = 0;
@@ -284,7 +311,7 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         } else if (pos + 32 * kOutB <= end_abs) {          // 16 look-ups cannot overrun the stream
 #pragma unroll
             for (uint32_t k = 0; k < 16; k++) {
-                const uint2 e = tbl[__builtin_amdgcn_alignbit(L.hi, L.lo, L.s) >> sh];
+                const uint2 e = lookup();
                 if (ASCII) {
                     reinterpret_cast<uint16_t *>(wa)[0] = static_cast<uint16_t>(e.x);
                     reinterpret_cast<uint16_t *>(wa)[1] = static_cast<uint16_t>(e.x >> 16);
@@ -298,9 +325,9 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         } else if (pos < end_abs) {                        // tail of the stream: never take more than is left
 #pragma unroll 4
             for (uint32_t k = 0; k < 16; k++) {
-                const uint2 e = tbl[__builtin_amdgcn_alignbit(L.hi, L.lo, L.s) >> sh];
+                const uint2 e = lookup();
                 const uint32_t left = end_abs - (rbase + static_cast<uint32_t>(wa - orow));   // bytes
-                const bool two = (e.y >> 24) && left >= 2 * kOutB;
+                const bool two = ((e.y >> 24) & 1u) && left >= 2 * kOutB;
                 if (ASCII) {
                     reinterpret_cast<uint16_t *>(wa)[0] = static_cast<uint16_t>(e.x);
                     reinterpret_cast<uint16_t *>(wa)[1] = static_cast<uint16_t>(e.x >> 16);

@@ -9,8 +9,6 @@ namespace nafgpu {
 constexpr uint32_t kBlockMax = 128u << 10;   // zstd Block_Maximum_Size
 constexpr int kHufWave = 64;                 // one Huffman stream per lane, one wave per workgroup
 constexpr uint32_t kHufLdsEntries = 2048;    // 8-byte decode-table entries a wave task may stage in LDS
-// index width of the staged two-symbol table for a tree with `max_bits`-bit codes
-constexpr uint32_t huf_index_bits(uint32_t max_bits) { return max_bits < 8 ? 8 : max_bits; }
 constexpr uint32_t kSrcFrontPad = 256;       // bytes readable in front of any device source buffer
 constexpr uint32_t kSrcBackPad = 64;
 
@@ -22,15 +20,15 @@ struct alignas(16) HufStream {
     uint32_t n_syms;     // symbols to regenerate
     uint32_t blk;        // zstd block index (for blk_base[])
     uint16_t tbl_lds;    // first entry of this stream's table inside the task's LDS table area
-    uint8_t max_bits;    // index width W of the staged table (>= the tree's max_bits, see huf_index_bits)
-    uint8_t flags;       // bit0: write to the literal buffer (block has sequences)
+    uint8_t max_bits;    // index width W of the staged table (6..8, chosen per task by the host)
+    uint8_t flags;       // bit0: write to the literal buffer (block has sequences); bits 4-7: tree max_bits - W (0 = no escapes)
 };
 static_assert(sizeof(HufStream) == 32, "HufStream layout");
 
 struct HufTblCopy {      // build the two-symbol table of pool[pool_off ..) at LDS entry lds_off
     uint32_t pool_off;   // 2^max_bits single-symbol entries (len << 8 | sym) in the pool
     uint32_t lds_off;    // first staged entry (8-byte entries)
-    uint32_t n_entries;  // 2^W staged entries
+    uint32_t n_entries;  // 2^W main entries + one 2^(max_bits - W) sub-table per escaping prefix
     uint32_t bits;       // max_bits | W << 8
 };
 

@@ -650,54 +650,72 @@ struct Walker {
             plan->streams.swap(ordered);
             stream_tbl.swap(ordered_tbl);
         }
-        struct Slot {
-            uint32_t pool_off, lds_off;
+        // Every table of a task is staged with the same index width W (8, 7 or 6 bits): 2^W
+        // two-symbol entries plus, for codes longer than W bits, one 2^(max_bits - W) entry
+        // sub-table per escaping W-bit prefix.  The widest W whose tables fit kHufLdsEntries wins,
+        // so archives where every block brings its own (possibly 11-bit) tree still fill 64 lanes.
+        auto staged_entries = [&](const HufRef &t, uint32_t W) -> uint32_t {
+            if (t.max_bits <= W) return 1u << W;
+            const uint16_t *x1 = plan->huf_pool.data() + t.pool_off;
+            uint32_t esc = 0;
+            for (uint32_t p = 0; p < (1u << W); p++)
+                if ((x1[p << (t.max_bits - W)] >> 8) > W) esc++;
+            return (1u << W) + (esc << (t.max_bits - W));
         };
-        std::vector<Slot> slots;
-        HufTask cur{0, 0, 0, 0};
-        uint32_t lds_used = 0;
-        auto close = [&]() {
-            if (cur.n_streams) plan->tasks.push_back(cur);
-            cur.first_stream += cur.n_streams;
-            cur.n_streams = 0;
-            cur.first_copy = static_cast<uint32_t>(plan->tbl_copies.size());
-            cur.n_copies = 0;
-            slots.clear();
-            lds_used = 0;
+        auto pack_group = [&](size_t g0, size_t g1) {
+            size_t s = g0;
+            while (s < g1) {
+                size_t e = std::min(g1, s + kHufWave);
+                uint32_t W = 8;
+                std::vector<HufRef> distinct;
+                for (;;) {
+                    distinct.clear();
+                    for (size_t k = s; k < e; k++) {
+                        bool seen = false;
+                        for (const HufRef &d : distinct) seen = seen || d.pool_off == stream_tbl[k].pool_off;
+                        if (!seen) distinct.push_back(stream_tbl[k]);
+                    }
+                    bool fits = false;
+                    for (W = 8; W >= 6; W--) {
+                        uint32_t total = 0;
+                        for (const HufRef &d : distinct) total += staged_entries(d, W);
+                        if (total <= kHufLdsEntries) {
+                            fits = true;
+                            break;
+                        }
+                    }
+                    if (fits || e == s + 1) break;
+                    e = s + (e - s + 1) / 2;                 // too many distinct deep trees: take fewer streams
+                }
+                if (W < 6) W = 6;
+                HufTask task{static_cast<uint32_t>(s), static_cast<uint32_t>(e - s),
+                             static_cast<uint32_t>(plan->tbl_copies.size()), static_cast<uint32_t>(distinct.size())};
+                uint32_t lds_used = 0;
+                std::vector<uint32_t> lds_of(distinct.size());
+                for (size_t d = 0; d < distinct.size(); d++) {
+                    const uint32_t n = staged_entries(distinct[d], W);
+                    lds_of[d] = lds_used;
+                    plan->tbl_copies.push_back(HufTblCopy{distinct[d].pool_off, lds_used, n, distinct[d].max_bits | (W << 8)});
+                    lds_used += n;
+                }
+                for (size_t k = s; k < e; k++) {
+                    size_t d = 0;
+                    while (distinct[d].pool_off != stream_tbl[k].pool_off) d++;
+                    HufStream &hs = plan->streams[k];
+                    hs.tbl_lds = static_cast<uint16_t>(lds_of[d]);
+                    hs.max_bits = static_cast<uint8_t>(W);
+                    const uint32_t esc_bits = stream_tbl[k].max_bits > W ? stream_tbl[k].max_bits - W : 0;
+                    hs.flags = static_cast<uint8_t>((hs.flags & 0x0F) | (esc_bits << 4));
+                }
+                plan->tasks.push_back(task);
+                s = e;
+            }
         };
         size_t first_lit = 0;
         while (first_lit < plan->streams.size() && !(plan->streams[first_lit].flags & 1)) first_lit++;
-        for (size_t s = 0; s < plan->streams.size(); s++) {
-            if (s == first_lit) {                           // group boundary: never share a task
-                close();
-                plan->n_direct_tasks = static_cast<uint32_t>(plan->tasks.size());
-            }
-            const HufRef &t = stream_tbl[s];
-            const uint32_t W = huf_index_bits(t.max_bits);
-            const uint32_t entries = 1u << W;
-            auto find = [&]() -> int {
-                for (size_t k = 0; k < slots.size(); k++)
-                    if (slots[k].pool_off == t.pool_off) return static_cast<int>(k);
-                return -1;
-            };
-            int k = find();
-            if (k < 0 && lds_used + entries > kHufLdsEntries) {
-                close();                                    // table does not fit beside the others
-            }
-            if (k < 0) {
-                slots.push_back(Slot{t.pool_off, lds_used});
-                plan->tbl_copies.push_back(HufTblCopy{t.pool_off, lds_used, entries, t.max_bits | (W << 8)});
-                cur.n_copies++;
-                lds_used += entries;
-                k = static_cast<int>(slots.size()) - 1;
-            }
-            plan->streams[s].tbl_lds = static_cast<uint16_t>(slots[size_t(k)].lds_off);
-            plan->streams[s].max_bits = static_cast<uint8_t>(W);
-            cur.n_streams++;
-            if (cur.n_streams == kHufWave) close();
-        }
-        close();
-        if (first_lit == plan->streams.size()) plan->n_direct_tasks = static_cast<uint32_t>(plan->tasks.size());
+        pack_group(0, first_lit);
+        plan->n_direct_tasks = static_cast<uint32_t>(plan->tasks.size());
+        pack_group(first_lit, plan->streams.size());
     }
 };
 

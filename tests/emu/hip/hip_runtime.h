@@ -48,6 +48,8 @@ int __syncthreads_or(int pred);
 inline void __builtin_amdgcn_fence(int, const char *) {}
 inline void __builtin_amdgcn_wave_barrier() { hipemu::sync_threads(); }
 inline int __any(int pred) { return __syncthreads_or(pred); }
+unsigned long long __ballot(int pred);
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 
 // ---- device intrinsics used by kernels.hip ------------------------------------------------
 inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz(static_cast<unsigned>(v)); }

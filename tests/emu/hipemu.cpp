@@ -144,6 +144,23 @@ int __syncthreads_or(int pred) {
     return r;
 }
 
+// wave ballot for one-wave (<= 64 work-item) workgroups: bit i = predicate of work-item i
+static unsigned long long g_bal_acc = 0, g_bal_out = 0;
+static int g_bal_count = 0;
+unsigned long long __ballot(int pred) {
+    const int nthreads = static_cast<int>(blockDim.x * blockDim.y * blockDim.z);
+    if (pred) g_bal_acc |= 1ull << (threadIdx.x & 63);
+    if (++g_bal_count == nthreads) {
+        g_bal_out = g_bal_acc;
+        g_bal_acc = 0;
+        g_bal_count = 0;
+    }
+    hipemu::sync_threads();
+    const unsigned long long r = g_bal_out;
+    hipemu::sync_threads();
+    return r;
+}
+
 // ---- runtime API ---------------------------------------------------------------------------
 struct hipemuEvent {
     std::chrono::steady_clock::time_point t;

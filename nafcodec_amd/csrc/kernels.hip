@@ -842,52 +842,70 @@ __device__ inline uint32_t lower4(uint32_t w, uint32_t byte_mask) {
 __global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_bases, const uint64_t *__restrict__ mask_ends,
                                                     const ScanTotals *mask_totals, const uint64_t *__restrict__ rec_ends,
                                                     const ScanTotals *rec_totals, int spec_mask, const uint32_t *status) {
-    if (status[0] != 0) return;
+    // A workgroup takes 256 consecutive masked runs.  Phase 1: one run per thread -- clamp it and
+    // (reference behaviour) find the record that holds its last base with a binary search, 256
+    // searches in flight at once.  Phase 2: each wave lower-cases its 64 runs, all lanes on one run.
+    __shared__ uint64_t s_lo[256], s_hi[256];
+    const uint32_t abort_now = status[0];                  // same word for every thread of the launch
     const uint64_t n_runs = mask_totals->count;
     const uint64_t n_rec = rec_totals->count;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t n_waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
-    for (uint64_t k = 2 * wave + 1; k < n_runs; k += 2 * n_waves) {     // odd runs are the masked ones
-        uint64_t s = mask_ends[k - 1];
-        uint64_t e = mask_ends[k];
-        if (s >= n_bases) break;
-        if (e > n_bases) {                       // MaskReader stops at `total`; the overshoot is never applied
-            if (!spec_mask) continue;
-            e = n_bases;
-        }
-        if (e <= s) continue;
-        if (!spec_mask) {
-            // record holding base e-1: first record whose end is > e-1
-            uint64_t lo = 0, hi = n_rec;
-            while (lo < hi) {
-                const uint64_t mid = (lo + hi) >> 1;
-                if (rec_ends[mid] > e - 1)
-                    hi = mid;
-                else
-                    lo = mid + 1;
+    const uint32_t tid = threadIdx.x;
+    for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * 256; 2 * base + 1 < n_runs && !abort_now;
+         base += static_cast<uint64_t>(gridDim.x) * 256) {
+        const uint64_t k = 2 * (base + tid) + 1;           // odd runs are the masked ones
+        uint64_t s = 0, e = 0;
+        if (k < n_runs) {
+            s = mask_ends[k - 1];
+            e = mask_ends[k];
+            if (s >= n_bases) {
+                s = e = 0;
+            } else if (e > n_bases) {                      // MaskReader stops at `total`: the overshoot is never applied
+                e = spec_mask ? n_bases : s;
             }
-            if (lo >= n_rec) continue;           // beyond the last record
-            const uint64_t rend = rec_ends[lo];
-            const uint64_t rstart = lo ? rec_ends[lo - 1] : 0;
-            if (e >= rend) continue;             // run reaches the record end: stays upper case
-            if (s < rstart) s = rstart;
+            if (e > s && !spec_mask) {
+                uint64_t lo = 0, hi = n_rec;               // first record whose end is > e - 1
+                while (lo < hi) {
+                    const uint64_t mid = (lo + hi) >> 1;
+                    if (rec_ends[mid] > e - 1)
+                        hi = mid;
+                    else
+                        lo = mid + 1;
+                }
+                if (lo >= n_rec) {
+                    e = s;                                 // beyond the last record
+                } else {
+                    const uint64_t rend = rec_ends[lo];
+                    const uint64_t rstart = lo ? rec_ends[lo - 1] : 0;
+                    if (e >= rend)
+                        e = s;                             // run reaches the record end: stays upper case
+                    else if (s < rstart)
+                        s = rstart;
+                }
+            }
         }
-        // lower-case [s, e): aligned dwords, byte masks at both edges
-        const uint64_t w0 = s >> 2, w1 = (e + 3) >> 2;
+        __syncthreads();                                   // previous round's readers are done
+        s_lo[tid] = s;
+        s_hi[tid] = e;
+        __syncthreads();
+        const uint32_t lane = tid & 63, w = tid >> 6;
         uint32_t *words = reinterpret_cast<uint32_t *>(ascii);
-        for (uint64_t w = w0 + lane; w < w1; w += 64) {
-            uint32_t bm = 0xFu;
-            if (w == w0) bm &= 0xFu << (s & 3);
-            if (w == w1 - 1 && (e & 3)) bm &= 0xFu >> (4 - (e & 3));
-            if (bm == 0xFu) {
-                words[w] = lower4(words[w], 0xFu);
-            } else {                              // edge dword: touch only our bytes (neighbours belong to other waves)
-                for (uint32_t b = 0; b < 4; b++)
-                    if ((bm >> b) & 1u) {
-                        const uint8_t c = ascii[4 * w + b];
-                        if (static_cast<uint32_t>(c) - 'A' < 26u) ascii[4 * w + b] = c | 0x20;
-                    }
+        for (uint32_t r = 0; r < 64; r++) {
+            const uint64_t lo = s_lo[w * 64 + r], hi = s_hi[w * 64 + r];
+            if (hi <= lo) continue;
+            const uint64_t w0 = lo >> 2, w1 = (hi + 3) >> 2;
+            for (uint64_t x = w0 + lane; x < w1; x += 64) {
+                uint32_t bm = 0xFu;
+                if (x == w0) bm &= 0xFu << (lo & 3);
+                if (x == w1 - 1 && (hi & 3)) bm &= 0xFu >> (4 - (hi & 3));
+                if (bm == 0xFu) {
+                    words[x] = lower4(words[x], 0xFu);
+                } else {                                   // edge dword: touch only our bytes (neighbours belong to other waves)
+                    for (uint32_t b = 0; b < 4; b++)
+                        if ((bm >> b) & 1u) {
+                            const uint8_t c = ascii[4 * x + b];
+                            if (static_cast<uint32_t>(c) - 'A' < 26u) ascii[4 * x + b] = c | 0x20;
+                        }
+                }
             }
         }
     }
@@ -1023,8 +1041,8 @@ void launch_mask_apply(hipStream_t stream, uint8_t *ascii, uint64_t n_bases, con
                        const ScanTotals *mask_totals, const uint64_t *rec_ends, const ScanTotals *rec_totals,
                        uint64_t max_runs, int spec_mask, uint32_t *status) {
     if (!n_bases || !max_runs) return;
-    uint64_t waves = (max_runs + 1) / 2;
-    uint64_t blocks = (waves + 3) / 4;
+    const uint64_t masked_runs = (max_runs + 1) / 2;
+    uint64_t blocks = (masked_runs + 255) / 256;
     if (blocks > 256u * 8u) blocks = 256u * 8u;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(k_mask_apply, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, ascii, n_bases, mask_ends,

@@ -206,7 +206,8 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer) {
     if (n_seq_blocks_) {
         if (timer) timer->begin(stream, StageTimer::kSeqLz);
         launch_lz_execute(stream, d_seq_blocks_.as<SeqBlock>(), static_cast<uint32_t>(n_seq_blocks_), d_seqs_.as<Seq>(),
-                          d_lit_.bytes(), d_blk_base_.as<uint64_t>(), d_out_.bytes(), ascii, t_char_, status);
+                          d_lit_.bytes(), d_blk_base_.as<uint64_t>(), d_blk_size_.as<uint32_t>(), d_out_.bytes(), ascii,
+                          t_char_, status);
         if (timer) timer->end(stream);
     }
 }

@@ -47,8 +47,8 @@ void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *ta
 
 // K4: LZ77 sequence execution (literal scatter + ordered match copy)
 void launch_lz_execute(hipStream_t stream, const SeqBlock *blocks, uint32_t n_blocks, const Seq *seqs,
-                       const uint8_t *lit, const uint64_t *blk_base, uint8_t *out, bool ascii, uint32_t t_char,
-                       uint32_t *status);
+                       const uint8_t *lit, const uint64_t *blk_base, const uint32_t *blk_size, uint8_t *out, bool ascii,
+                       uint32_t t_char, uint32_t *status);
 
 // K5: 4-bit -> IUPAC ASCII; t_char = 'T' (DNA) or 'U' (RNA)
 void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed, uint8_t *ascii, uint64_t n_bases,

@@ -5,7 +5,7 @@
 //   k_seq_decode   K2  FSE sequence decode (LL / OF / ML)                     lane = block
 //   k_scan_*       K3/K6  tile scans: block bases, record ends, mask run ends
 //   k_copy_fill        Raw / RLE blocks and literal sections
-//   k_lz_execute   K4  literal scatter + ordered match copy
+//   k_lz_literals / k_lz_matches   K4  parallel literal scatter + ordered match copy
 //   k_unpack4      K5  4-bit -> IUPAC ASCII (reader.rs:121-172)
 //   k_mask_apply       soft-mask lower-casing incl. the record-end rule (mod.rs:402-441)
 //   k_hash64           checksum used by full-size parity tests
@@ -436,6 +436,8 @@ __global__ __launch_bounds__(64) void k_seq_decode(const uint8_t *__restrict__ s
             sof = co.next_base + r.read(co.nb);
         }
         if (r.pos < 0) break;
+        s.opos = static_cast<uint32_t>(sum_ll + sum_ml);
+        s.lpos = static_cast<uint32_t>(sum_ll);
         dst[i] = s;
         sum_ll += s.ll;
         sum_ml += s.ml;
@@ -638,65 +640,105 @@ __global__ __launch_bounds__(256) void k_copy_fill(const uint8_t *__restrict__ s
 // ======================================================================================
 // K4  LZ77 execution (App. B "Repeat offsets" + "Execute")
 // ======================================================================================
-// Round-1 shape: ONE workgroup walks the blocks that have sequences in frame order, so every
-// cross-block dependency (repeat offsets, window matches) is satisfied by construction.
-// Literal-only blocks were already written by K1.  Inside a batch of 256 sequences the
-// literal copies run in parallel and the matches in order (a match may read the previous one).
+// Two kernels.  k_lz_literals scatters every literal run to its final position -- no dependencies,
+// one workgroup per block, short runs one per thread, long runs and the block's trailing literals
+// by the whole workgroup.  k_lz_matches then executes the matches: ONE workgroup walks the blocks
+// that have sequences in frame order (repeat-offset history and window matches across blocks are
+// satisfied by construction); inside a batch of 256 sequences, matches whose source lies entirely
+// before the batch's first output byte and that are short run in parallel, one per thread, the
+// others (dependent or long) in order with the whole workgroup on each.
 // ASCII = true: the output is the expanded base stream (two characters per packed byte), so a
 // match of `ml` packed bytes at distance `off` copies ml 16-bit elements at distance off, and
 // literals are expanded while they are scattered.  The ASCII buffer itself is the LZ window.
+constexpr uint32_t kLzShort = 48;        // runs up to this many elements are copied by their own thread
+
 template <bool ASCII>
-__global__ __launch_bounds__(256) void k_lz_execute(const SeqBlock *__restrict__ blocks, uint32_t n_blocks,
-                                                    const Seq *__restrict__ seqs, const uint8_t *__restrict__ lit,
-                                                    const uint64_t *__restrict__ blk_base, uint8_t *out_bytes,
-                                                    uint32_t t_char, uint32_t *status) {
+__global__ __launch_bounds__(256) void k_lz_literals(const SeqBlock *__restrict__ blocks, const Seq *__restrict__ seqs,
+                                                     const uint8_t *__restrict__ lit, const uint64_t *__restrict__ blk_base,
+                                                     const uint32_t *__restrict__ blk_size, uint8_t *out_bytes, uint32_t t_char,
+                                                     const uint32_t *status) {
+    using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
+    __shared__ uint32_t s_long[256];
+    __shared__ uint32_t s_nlong, s_abort;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_abort = status[0];
+    __syncthreads();
+    if (s_abort) return;
+    const SeqBlock sb = blocks[blockIdx.x];
+    Elem *out = reinterpret_cast<Elem *>(out_bytes) + blk_base[sb.blk];
+    const uint8_t *blit = lit + sb.lit_off;
+    const Seq *sq = seqs + sb.seq_first;
+    auto put = [&](Elem *d, uint8_t b) { *d = ASCII ? static_cast<Elem>(byte_chars(b, t_char)) : static_cast<Elem>(b); };
+    for (uint32_t s0 = 0; s0 < sb.n_seq; s0 += 256) {
+        if (tid == 0) s_nlong = 0;
+        __syncthreads();
+        if (s0 + tid < sb.n_seq) {
+            const Seq q = sq[s0 + tid];
+            if (q.ll <= kLzShort) {
+                for (uint32_t k = 0; k < q.ll; k++) put(out + q.opos + k, blit[q.lpos + k]);
+            } else {
+                s_long[atomicAdd(&s_nlong, 1u)] = s0 + tid;
+            }
+        }
+        __syncthreads();
+        const uint32_t nl = s_nlong;
+        for (uint32_t j = 0; j < nl; j++) {
+            const Seq q = sq[s_long[j]];
+            for (uint32_t k = tid; k < q.ll; k += 256) put(out + q.opos + k, blit[q.lpos + k]);
+        }
+        __syncthreads();
+    }
+    // literals after the last sequence run to the end of the block
+    const Seq last = sq[sb.n_seq - 1];
+    const uint32_t lused = last.lpos + last.ll, oend = last.opos + last.ll + last.ml;
+    (void)blk_size;
+    for (uint32_t k = tid; k < sb.lit_size - lused; k += 256) put(out + oend + k, blit[lused + k]);
+}
+
+template <bool ASCII>
+__global__ __launch_bounds__(256) void k_lz_matches(const SeqBlock *__restrict__ blocks, uint32_t n_blocks,
+                                                    const Seq *__restrict__ seqs, const uint64_t *__restrict__ blk_base,
+                                                    uint8_t *out_bytes, uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
-    __shared__ uint32_t s_ll[256], s_ml[256], s_off[256], s_lpos[256];
-    __shared__ uint64_t s_opos[256];
+    __shared__ uint32_t s_ll[256], s_ml[256], s_off[256], s_slow[256];
     __shared__ uint64_t s_rep[3];
-    __shared__ uint64_t s_cur_o;
-    __shared__ uint32_t s_cur_l, s_frame;
+    __shared__ uint32_t s_nslow, s_frame, s_abort;
     const uint32_t tid = threadIdx.x;
     if (tid == 0) {
         s_frame = 0xFFFFFFFFu;
-        s_cur_l = status[0];            // broadcast the abort decision: barriers need uniform control flow
+        s_abort = status[0];            // broadcast the abort decision: barriers need uniform control flow
     }
     __syncthreads();
-    if (s_cur_l != 0) return;
-    __syncthreads();
+    if (s_abort != 0) return;
     for (uint32_t b = 0; b < n_blocks; b++) {
         const SeqBlock sb = blocks[b];
         const uint64_t obase = blk_base[sb.blk];
         const uint64_t fstart = blk_base[sb.frame_first_blk];
-        const uint8_t *blit = lit + sb.lit_off;
-        if (tid == 0) {
-            if (s_frame != sb.frame_first_blk) {        // repeat offsets restart with each frame
-                s_frame = sb.frame_first_blk;
-                s_rep[0] = 1;
-                s_rep[1] = 4;
-                s_rep[2] = 8;
-            }
-            s_cur_o = obase;
-            s_cur_l = 0;
+        if (tid == 0 && s_frame != sb.frame_first_blk) {        // repeat offsets restart with each frame
+            s_frame = sb.frame_first_blk;
+            s_rep[0] = 1;
+            s_rep[1] = 4;
+            s_rep[2] = 8;
         }
-        __syncthreads();
         for (uint32_t s0 = 0; s0 < sb.n_seq; s0 += 256) {
             const uint32_t cnt = sb.n_seq - s0 < 256u ? sb.n_seq - s0 : 256u;
+            Seq q{0, 0, 0, 0, 0};
             if (tid < cnt) {
-                const Seq q = seqs[sb.seq_first + s0 + tid];
+                q = seqs[sb.seq_first + s0 + tid];
                 s_ll[tid] = q.ll;
                 s_ml[tid] = q.ml;
                 s_off[tid] = q.ofv;
             }
+            if (tid == 0) s_nslow = 0;
             __syncthreads();
-            if (tid == 0) {                              // serial: repeat-offset history + positions
-                uint64_t r0 = s_rep[0], r1 = s_rep[1], r2 = s_rep[2];
-                uint64_t o = s_cur_o;
-                uint32_t l = s_cur_l;
+            const uint64_t batch_first = obase + seqs[sb.seq_first + s0].opos;   // first output byte of the batch
+            if (tid == 0) {                              // serial: repeat-offset history
+                uint32_t r0 = static_cast<uint32_t>(s_rep[0]), r1 = static_cast<uint32_t>(s_rep[1]), r2 = static_cast<uint32_t>(s_rep[2]);
+#pragma unroll 8
                 for (uint32_t i = 0; i < cnt; i++) {
                     const uint32_t ll = s_ll[i], ofv = s_off[i];
-                    uint64_t off;
+                    uint32_t off;
                     if (ofv > 3) {
                         off = ofv - 3;
                         r2 = r1;
@@ -713,54 +755,58 @@ __global__ __launch_bounds__(256) void k_lz_execute(const SeqBlock *__restrict__
                             r0 = off;
                         }
                     }
-                    s_opos[i] = o;
-                    s_lpos[i] = l;
-                    o += ll;
-                    l += ll;
-                    if (off == 0 || off > o - fstart) {   // reaches before the frame: corrupt
-                        flag_error(status, kStBadOffset, sb.blk);
-                        s_ml[i] = 0x80000000u | s_ml[i];  // keep the length for positions, skip the copy
-                        off = 1;
-                    }
-                    s_off[i] = static_cast<uint32_t>(off);
-                    o += s_ml[i] & 0x7FFFFFFFu;
+                    s_off[i] = off;
                 }
                 s_rep[0] = r0;
                 s_rep[1] = r1;
                 s_rep[2] = r2;
-                s_cur_o = o;
-                s_cur_l = l;
             }
             __syncthreads();
-            if (tid < cnt) {                             // literal runs: independent of each other
-                Elem *d = out + s_opos[tid];
-                const uint8_t *s = blit + s_lpos[tid];
-                const uint32_t ll = s_ll[tid];
-                for (uint32_t k = 0; k < ll; k++) d[k] = ASCII ? static_cast<Elem>(byte_chars(s[k], t_char)) : static_cast<Elem>(s[k]);
+            if (tid < cnt) {
+                const uint64_t mpos = obase + q.opos + q.ll;     // first byte the match writes
+                const uint32_t off = s_off[tid];
+                if (off == 0 || off > mpos - fstart) {           // reaches before the frame: corrupt
+                    flag_error(status, kStBadOffset, sb.blk);
+                } else if (q.ml) {
+                    const bool independent = mpos - off + q.ml <= batch_first || tid == 0;
+                    if (independent && q.ml <= kLzShort && off >= q.ml) {
+                        Elem *d = out + mpos;
+                        const Elem *s = d - off;
+                        for (uint32_t k = 0; k < q.ml; k++) d[k] = s[k];
+                    } else {
+                        s_slow[atomicAdd(&s_nslow, 1u)] = tid;  // order restored below
+                    }
+                }
             }
             __syncthreads();
-            for (uint32_t i = 0; i < cnt; i++) {         // matches: in order
-                const uint32_t mlf = s_ml[i];
-                if (!(mlf & 0x80000000u)) {
-                    const uint32_t ml = mlf, off = s_off[i];
-                    Elem *d = out + s_opos[i] + s_ll[i];
+            // dependent or long matches: in sequence order, the whole workgroup on each
+            const uint32_t ns = s_nslow;
+            if (ns) {
+                // s_slow was filled in arbitrary order: a rank sort by index (ns <= 256)
+                uint32_t mine = 0xFFFFFFFFu, rank = 0;
+                if (tid < ns) {
+                    mine = s_slow[tid];
+                    for (uint32_t j = 0; j < ns; j++) rank += s_slow[j] < mine ? 1u : 0u;
+                }
+                __syncthreads();
+                if (tid < ns) s_slow[rank] = mine;
+                __syncthreads();
+                for (uint32_t j = 0; j < ns; j++) {
+                    const uint32_t i = s_slow[j];
+                    const Seq qi = seqs[sb.seq_first + s0 + i];
+                    const uint32_t off = s_off[i], ml = qi.ml;
+                    Elem *d = out + obase + qi.opos + qi.ll;
                     const Elem *s = d - off;
                     if (off >= ml) {
                         for (uint32_t k = tid; k < ml; k += 256) d[k] = s[k];
                     } else {
                         for (uint32_t k = tid; k < ml; k += 256) d[k] = s[k % off];   // overlapping: periodic
                     }
+                    __syncthreads();
                 }
-                __syncthreads();
             }
+            __syncthreads();
         }
-        {                                                // literals after the last sequence
-            const uint32_t l = s_cur_l;
-            Elem *d = out + s_cur_o;
-            for (uint32_t k = tid; k < sb.lit_size - l; k += 256)
-                d[k] = ASCII ? static_cast<Elem>(byte_chars(blit[l + k], t_char)) : static_cast<Elem>(blit[l + k]);
-        }
-        __syncthreads();
     }
 }
 
@@ -1001,7 +1047,11 @@ void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *ta
                        const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t max_tbl_entries, bool ascii,
                        uint32_t t_char, uint32_t *status) {
     if (!n_tasks) return;
-    const uint32_t lds = ((max_tbl_entries * 8u) + 15u) & ~15u;
+    static const uint32_t lds_pad = [] {                  // occupancy experiments: extra dynamic LDS per workgroup
+        const char *e = std::getenv("NAFGPU_K1_LDS_PAD");
+        return e ? static_cast<uint32_t>(std::atoi(e)) : 0u;
+    }();
+    const uint32_t lds = (((max_tbl_entries * 8u) + 15u) & ~15u) + lds_pad;
     static const uint32_t dbg = [] {                     // timing ablations only; results are wrong when set
         const char *e = std::getenv("NAFGPU_K1_DEBUG");
         return e ? static_cast<uint32_t>(std::atoi(e)) : 0u;
@@ -1015,15 +1065,18 @@ void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *ta
 }
 
 void launch_lz_execute(hipStream_t stream, const SeqBlock *blocks, uint32_t n_blocks, const Seq *seqs,
-                       const uint8_t *lit, const uint64_t *blk_base, uint8_t *out, bool ascii, uint32_t t_char,
-                       uint32_t *status) {
+                       const uint8_t *lit, const uint64_t *blk_base, const uint32_t *blk_size, uint8_t *out, bool ascii,
+                       uint32_t t_char, uint32_t *status) {
     if (!n_blocks) return;
-    if (ascii)
-        hipLaunchKernelGGL(k_lz_execute<true>, dim3(1), dim3(256), 0, stream, blocks, n_blocks, seqs, lit, blk_base, out,
-                           t_char, status);
-    else
-        hipLaunchKernelGGL(k_lz_execute<false>, dim3(1), dim3(256), 0, stream, blocks, n_blocks, seqs, lit, blk_base, out,
-                           t_char, status);
+    if (ascii) {
+        hipLaunchKernelGGL(k_lz_literals<true>, dim3(n_blocks), dim3(256), 0, stream, blocks, seqs, lit, blk_base, blk_size,
+                           out, t_char, status);
+        hipLaunchKernelGGL(k_lz_matches<true>, dim3(1), dim3(256), 0, stream, blocks, n_blocks, seqs, blk_base, out, status);
+    } else {
+        hipLaunchKernelGGL(k_lz_literals<false>, dim3(n_blocks), dim3(256), 0, stream, blocks, seqs, lit, blk_base, blk_size,
+                           out, t_char, status);
+        hipLaunchKernelGGL(k_lz_matches<false>, dim3(1), dim3(256), 0, stream, blocks, n_blocks, seqs, blk_base, out, status);
+    }
 }
 
 void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed, uint8_t *ascii, uint64_t n_bases,

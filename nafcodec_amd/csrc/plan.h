@@ -70,6 +70,8 @@ static_assert(sizeof(SeqBlock) == 64, "SeqBlock layout");
 
 struct Seq {             // one decoded sequence (offset still in "offset_value" form)
     uint32_t ll, ml, ofv;
+    uint32_t opos;       // output position of its literals, relative to the block's first byte
+    uint32_t lpos;       // position of its literals in the block's literal section
 };
 
 // device status words

@@ -157,7 +157,11 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
               d_seq_blocks_.upload(plan_.seq_blocks.data(), n_seq_blocks_ * sizeof(SeqBlock), stream) &&
               d_cells_.upload(plan_.fse_pool.data(), plan_.fse_pool.size() * sizeof(SeqCell), stream) &&
               d_lit_.alloc(static_cast<size_t>(plan_.lit_bytes) + 64) &&
-              d_seqs_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(Seq) + 16);
+              d_seqs_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(Seq) + 16) &&
+              d_mdst_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(uint64_t) + 16) &&
+              d_flags_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(uint32_t) + 16) &&
+              d_rep_final_.alloc(n_seq_blocks_ * 12 + 16) && d_rep_init_.alloc(n_seq_blocks_ * 12 + 16) &&
+              d_blk_pending_.alloc(n_seq_blocks_ * 4 + 16);
     if (!ok) return Failure::make(NAFGPU_E_DEVICE, "out of device memory while preparing a section");
     // the host vectors were consumed by asynchronous copies: keep them until the stream drains
     if (!hip_ok(hipStreamSynchronize(stream))) return Failure::make(NAFGPU_E_DEVICE, "upload of task lists failed");
@@ -178,7 +182,8 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer) {
         if (timer) timer->begin(stream, StageTimer::kSeqLz);
         // blk_size of blocks with sequences is rewritten in full by k_seq_decode: re-runs are idempotent
         launch_seq_decode(stream, d_src_, d_seq_blocks_.as<SeqBlock>(), static_cast<uint32_t>(n_seq_blocks_),
-                          d_cells_.as<SeqCell>(), d_seqs_.as<Seq>(), d_blk_size_.as<uint32_t>(), status);
+                          d_cells_.as<SeqCell>(), d_seqs_.as<Seq>(), d_blk_size_.as<uint32_t>(), d_rep_final_.as<uint32_t>(),
+                          status);
         if (timer) timer->end(stream);
     }
     if (timer) timer->begin(stream, StageTimer::kOther);
@@ -205,9 +210,22 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer) {
     }
     if (n_seq_blocks_) {
         if (timer) timer->begin(stream, StageTimer::kSeqLz);
-        launch_lz_execute(stream, d_seq_blocks_.as<SeqBlock>(), static_cast<uint32_t>(n_seq_blocks_), d_seqs_.as<Seq>(),
-                          d_lit_.bytes(), d_blk_base_.as<uint64_t>(), d_blk_size_.as<uint32_t>(), d_out_.bytes(), ascii,
-                          t_char_, status);
+        LzArgs la{};
+        la.blocks = d_seq_blocks_.as<SeqBlock>();
+        la.n_blocks = static_cast<uint32_t>(n_seq_blocks_);
+        la.n_sequences = plan_.n_sequences;
+        la.seqs = d_seqs_.as<Seq>();
+        la.lit = d_lit_.bytes();
+        la.blk_base = d_blk_base_.as<uint64_t>();
+        la.rep_final = d_rep_final_.as<uint32_t>();
+        la.rep_init = d_rep_init_.as<uint32_t>();
+        la.mdst = d_mdst_.as<uint64_t>();
+        la.flags = d_flags_.as<uint32_t>();
+        la.blk_pending = d_blk_pending_.as<uint32_t>();
+        la.out = d_out_.bytes();
+        la.t_char = t_char_;
+        la.status = status;
+        launch_lz_execute(stream, la, ascii);
         if (timer) timer->end(stream);
     }
 }

@@ -15,8 +15,9 @@ struct ScanTotals {          // written by the scan kernels
 };
 
 // K2: FSE sequence decode, one lane per block with sequences.  Adds match bytes to blk_size[].
+// rep_final: 3 u32 per block -- the repeat offsets the block ends with (concrete or kRepToken tokens)
 void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *blocks, uint32_t n_blocks,
-                       const SeqCell *cells, Seq *seqs, uint32_t *blk_size, uint32_t *status);
+                       const SeqCell *cells, Seq *seqs, uint32_t *blk_size, uint32_t *rep_final, uint32_t *status);
 
 // K3: exclusive scan of u32 block sizes -> u64 bases (n+1 entries; the last is the total).
 // `tile_tmp` needs scan_tmp_bytes(n) bytes.  Flags status if the total differs from `expect_total`.
@@ -45,10 +46,25 @@ void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *ta
                        const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t max_tbl_entries, bool ascii,
                        uint32_t t_char, uint32_t *status);
 
-// K4: LZ77 sequence execution (literal scatter + ordered match copy)
-void launch_lz_execute(hipStream_t stream, const SeqBlock *blocks, uint32_t n_blocks, const Seq *seqs,
-                       const uint8_t *lit, const uint64_t *blk_base, const uint32_t *blk_size, uint8_t *out, bool ascii,
-                       uint32_t t_char, uint32_t *status);
+// K4: LZ77 sequence execution: repeat-offset chain, parallel literal scatter, multi-pass match
+// resolution over all blocks, ordered fallback
+struct LzArgs {
+    const SeqBlock *blocks;
+    uint32_t n_blocks;
+    uint64_t n_sequences;
+    const Seq *seqs;
+    const uint8_t *lit;
+    const uint64_t *blk_base;
+    const uint32_t *rep_final;   // 3 per block, from k_seq_decode
+    uint32_t *rep_init;          // 3 per block
+    uint64_t *mdst;              // per sequence: output position of its match
+    uint32_t *flags;             // per sequence: pass in which its match was completed (0 = pending)
+    uint32_t *blk_pending;       // per block: matches still pending
+    uint8_t *out;
+    uint32_t t_char;
+    uint32_t *status;
+};
+void launch_lz_execute(hipStream_t stream, const LzArgs &args, bool ascii);
 
 // K5: 4-bit -> IUPAC ASCII; t_char = 'T' (DNA) or 'U' (RNA)
 void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed, uint8_t *ascii, uint64_t n_bases,

@@ -5,7 +5,7 @@
 //   k_seq_decode   K2  FSE sequence decode (LL / OF / ML)                     lane = block
 //   k_scan_*       K3/K6  tile scans: block bases, record ends, mask run ends
 //   k_copy_fill        Raw / RLE blocks and literal sections
-//   k_lz_literals / k_lz_matches   K4  parallel literal scatter + ordered match copy
+//   k_rep_chain / k_lz_literals / k_lz_match_pass / k_lz_matches_ordered   K4
 //   k_unpack4      K5  4-bit -> IUPAC ASCII (reader.rs:121-172)
 //   k_mask_apply       soft-mask lower-casing incl. the record-end rule (mod.rs:402-441)
 //   k_hash64           checksum used by full-size parity tests
@@ -410,9 +410,13 @@ struct BackBits {
     }
 };
 
+__device__ inline uint32_t rep_minus_one(uint32_t r) {      // rep - 1 for a concrete offset or a token
+    return r + ((r & kRepToken) ? 1u : 0xFFFFFFFFu);
+}
+
 __global__ __launch_bounds__(64) void k_seq_decode(const uint8_t *__restrict__ src, const SeqBlock *__restrict__ blocks,
                                                    uint32_t n_blocks, const SeqCell *__restrict__ cells, Seq *seqs,
-                                                   uint32_t *blk_size, uint32_t *status) {
+                                                   uint32_t *blk_size, uint32_t *rep_final, uint32_t *status) {
     if (status[0] != 0) return;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blocks) return;
@@ -424,10 +428,12 @@ __global__ __launch_bounds__(64) void k_seq_decode(const uint8_t *__restrict__ s
     uint32_t sll = r.read(sb.ll_al), sof = r.read(sb.of_al), sml = r.read(sb.ml_al);
     Seq *dst = seqs + sb.seq_first;
     uint64_t sum_ll = 0, sum_ml = 0;
+    uint32_t r0 = kRepToken | (0u << 24), r1 = kRepToken | (1u << 24), r2 = kRepToken | (2u << 24);
+    bool bad_off = false;
     for (uint32_t i = 0; i < sb.n_seq; i++) {
         const SeqCell cl = tll[sll], co = tof[sof], cm = tml[sml];
         Seq s;
-        s.ofv = co.base_value + r.read(co.extra_bits);   // extra bits in the order OF, ML, LL
+        const uint32_t ofv = co.base_value + r.read(co.extra_bits);   // extra bits in the order OF, ML, LL
         s.ml = cm.base_value + r.read(cm.extra_bits);
         s.ll = cl.base_value + r.read(cl.extra_bits);
         if (i + 1 < sb.n_seq) {                          // state updates LL, ML, OF; none after the last
@@ -436,6 +442,25 @@ __global__ __launch_bounds__(64) void k_seq_decode(const uint8_t *__restrict__ s
             sof = co.next_base + r.read(co.nb);
         }
         if (r.pos < 0) break;
+        // repeat-offset history (App. B "Repeat offsets"), on tokens where the value is inherited
+        if (ofv > 3) {
+            s.off = ofv - 3;
+            bad_off = bad_off || (s.off & kRepToken);    // >= 2^31: beyond any legal window
+            r2 = r1;
+            r1 = r0;
+            r0 = s.off;
+        } else {
+            const uint32_t idx = ofv - 1 + (s.ll == 0 ? 1u : 0u);
+            if (idx == 0) {
+                s.off = r0;
+            } else {
+                s.off = idx == 1 ? r1 : (idx == 2 ? r2 : rep_minus_one(r0));
+                bad_off = bad_off || s.off == 0;
+                if (idx > 1) r2 = r1;
+                r1 = r0;
+                r0 = s.off;
+            }
+        }
         s.opos = static_cast<uint32_t>(sum_ll + sum_ml);
         s.lpos = static_cast<uint32_t>(sum_ll);
         dst[i] = s;
@@ -450,6 +475,13 @@ __global__ __launch_bounds__(64) void k_seq_decode(const uint8_t *__restrict__ s
         flag_error(status, kStSeqLiterals, sb.blk);
         return;
     }
+    if (bad_off) {
+        flag_error(status, kStBadOffset, sb.blk);
+        return;
+    }
+    rep_final[3 * b + 0] = r0;
+    rep_final[3 * b + 1] = r1;
+    rep_final[3 * b + 2] = r2;
     if (sb.lit_size + sum_ml > kBlockMax) {
         flag_error(status, kStSizeMismatch, sb.blk);
         return;
@@ -640,22 +672,60 @@ __global__ __launch_bounds__(256) void k_copy_fill(const uint8_t *__restrict__ s
 // ======================================================================================
 // K4  LZ77 execution (App. B "Repeat offsets" + "Execute")
 // ======================================================================================
-// Two kernels.  k_lz_literals scatters every literal run to its final position -- no dependencies,
-// one workgroup per block, short runs one per thread, long runs and the block's trailing literals
-// by the whole workgroup.  k_lz_matches then executes the matches: ONE workgroup walks the blocks
-// that have sequences in frame order (repeat-offset history and window matches across blocks are
-// satisfied by construction); inside a batch of 256 sequences, matches whose source lies entirely
-// before the batch's first output byte and that are short run in parallel, one per thread, the
-// others (dependent or long) in order with the whole workgroup on each.
+//   k_rep_chain      one thread: block b's initial repeat offsets from block b-1's final tokens
+//   k_lz_literals    every literal run to its final position; no dependencies; workgroup per block
+//   k_lz_match_pass  run several times: every pending match whose source bytes are all final
+//                    (literals, or matches completed in an EARLIER pass) is copied; matches are
+//                    independent of block boundaries, so all blocks progress together and the
+//                    number of passes is the depth of the match-on-match dependency chain
+//   k_lz_matches_ordered   whatever is still pending after the fixed number of passes (long chains,
+//                    e.g. tandem repeats): one workgroup, frame order -- always terminates
 // ASCII = true: the output is the expanded base stream (two characters per packed byte), so a
 // match of `ml` packed bytes at distance `off` copies ml 16-bit elements at distance off, and
 // literals are expanded while they are scattered.  The ASCII buffer itself is the LZ window.
 constexpr uint32_t kLzShort = 48;        // runs up to this many elements are copied by their own thread
+constexpr uint32_t kLzPasses = 12;
+
+__device__ inline uint32_t rep_resolve(uint32_t tok, const uint32_t *init, bool *bad) {
+    if (!(tok & kRepToken)) return tok;
+    const uint32_t base = init[(tok >> 24) & 3u], d = tok & 0xFFFFFFu;
+    if (base <= d) {
+        *bad = true;
+        return 1;
+    }
+    return base - d;
+}
+
+__global__ void k_rep_chain(const SeqBlock *__restrict__ blocks, uint32_t n_blocks, const uint32_t *__restrict__ rep_final,
+                            uint32_t *rep_init, uint32_t *status) {
+    if (status[0] != 0 || blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t cur[3] = {1, 4, 8};
+    uint32_t frame = 0xFFFFFFFFu;
+    bool bad = false;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        if (blocks[b].frame_first_blk != frame) {        // repeat offsets restart with each frame
+            frame = blocks[b].frame_first_blk;
+            cur[0] = 1;
+            cur[1] = 4;
+            cur[2] = 8;
+        }
+        rep_init[3 * b + 0] = cur[0];
+        rep_init[3 * b + 1] = cur[1];
+        rep_init[3 * b + 2] = cur[2];
+        const uint32_t n0 = rep_resolve(rep_final[3 * b + 0], cur, &bad);
+        const uint32_t n1 = rep_resolve(rep_final[3 * b + 1], cur, &bad);
+        const uint32_t n2 = rep_resolve(rep_final[3 * b + 2], cur, &bad);
+        cur[0] = n0;
+        cur[1] = n1;
+        cur[2] = n2;
+    }
+    if (bad) flag_error(status, kStBadOffset, 0xFFFFFFFEu);
+}
 
 template <bool ASCII>
 __global__ __launch_bounds__(256) void k_lz_literals(const SeqBlock *__restrict__ blocks, const Seq *__restrict__ seqs,
                                                      const uint8_t *__restrict__ lit, const uint64_t *__restrict__ blk_base,
-                                                     const uint32_t *__restrict__ blk_size, uint8_t *out_bytes, uint32_t t_char,
+                                                     uint64_t *mdst, uint32_t *blk_pending, uint8_t *out_bytes, uint32_t t_char,
                                                      const uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     __shared__ uint32_t s_long[256];
@@ -665,15 +735,18 @@ __global__ __launch_bounds__(256) void k_lz_literals(const SeqBlock *__restrict_
     __syncthreads();
     if (s_abort) return;
     const SeqBlock sb = blocks[blockIdx.x];
-    Elem *out = reinterpret_cast<Elem *>(out_bytes) + blk_base[sb.blk];
+    const uint64_t obase = blk_base[sb.blk];
+    Elem *out = reinterpret_cast<Elem *>(out_bytes) + obase;
     const uint8_t *blit = lit + sb.lit_off;
     const Seq *sq = seqs + sb.seq_first;
+    if (tid == 0) blk_pending[blockIdx.x] = sb.n_seq;
     auto put = [&](Elem *d, uint8_t b) { *d = ASCII ? static_cast<Elem>(byte_chars(b, t_char)) : static_cast<Elem>(b); };
     for (uint32_t s0 = 0; s0 < sb.n_seq; s0 += 256) {
         if (tid == 0) s_nlong = 0;
         __syncthreads();
         if (s0 + tid < sb.n_seq) {
             const Seq q = sq[s0 + tid];
+            mdst[sb.seq_first + s0 + tid] = obase + q.opos + q.ll;   // where the match of this sequence starts
             if (q.ll <= kLzShort) {
                 for (uint32_t k = 0; k < q.ll; k++) put(out + q.opos + k, blit[q.lpos + k]);
             } else {
@@ -691,119 +764,168 @@ __global__ __launch_bounds__(256) void k_lz_literals(const SeqBlock *__restrict_
     // literals after the last sequence run to the end of the block
     const Seq last = sq[sb.n_seq - 1];
     const uint32_t lused = last.lpos + last.ll, oend = last.opos + last.ll + last.ml;
-    (void)blk_size;
     for (uint32_t k = tid; k < sb.lit_size - lused; k += 256) put(out + oend + k, blit[lused + k]);
 }
 
+// Are all output bytes in [lo, hi) final for a reader in pass `pass`?  Bytes that no match writes
+// are literals (final since k_lz_literals / K1); bytes of match g are final once flags[g] holds an
+// earlier pass number.  mdst[] (match start positions) is sorted: sequences are stored in frame order.
+__device__ inline bool lz_range_final(uint64_t lo, uint64_t hi, const uint64_t *mdst, const Seq *seqs, const uint32_t *flags,
+                                      uint64_t g_self, uint32_t pass) {
+    if (hi <= lo) return true;
+    uint64_t a = 0, b = g_self;                          // last g < g_self with mdst[g] <= lo
+    while (a < b) {
+        const uint64_t mid = (a + b) >> 1;
+        if (mdst[mid] <= lo)
+            a = mid + 1;
+        else
+            b = mid;
+    }
+    uint64_t g = a ? a - 1 : 0;
+    for (; g < g_self && mdst[g] < hi; g++) {
+        if (mdst[g] + seqs[g].ml <= lo) continue;        // ends before the range
+        const uint32_t f = flags[g];
+        if (f == 0 || f >= pass) return false;
+    }
+    return true;
+}
+
 template <bool ASCII>
-__global__ __launch_bounds__(256) void k_lz_matches(const SeqBlock *__restrict__ blocks, uint32_t n_blocks,
-                                                    const Seq *__restrict__ seqs, const uint64_t *__restrict__ blk_base,
-                                                    uint8_t *out_bytes, uint32_t *status) {
+__global__ __launch_bounds__(256) void k_lz_match_pass(const SeqBlock *__restrict__ blocks, uint32_t n_blocks,
+                                                       const Seq *__restrict__ seqs, const uint64_t *__restrict__ mdst,
+                                                       uint32_t *flags, uint32_t *blk_pending, const uint32_t *__restrict__ rep_init,
+                                                       const uint64_t *__restrict__ blk_base, uint8_t *out_bytes, uint32_t pass,
+                                                       uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
-    __shared__ uint32_t s_ll[256], s_ml[256], s_off[256], s_slow[256];
-    __shared__ uint64_t s_rep[3];
-    __shared__ uint32_t s_nslow, s_frame, s_abort;
+    __shared__ uint32_t s_long[256];
+    __shared__ uint32_t s_nlong, s_ndone, s_abort, s_pending;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) {
-        s_frame = 0xFFFFFFFFu;
-        s_abort = status[0];            // broadcast the abort decision: barriers need uniform control flow
+    if (tid == 0) s_abort = status[0];
+    __syncthreads();
+    if (s_abort) return;
+    for (uint32_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        if (tid == 0) s_pending = blk_pending[b];
+        __syncthreads();
+        const uint32_t pend = s_pending;
+        __syncthreads();
+        if (pend == 0) continue;
+        const SeqBlock sb = blocks[b];
+        const uint64_t fstart = blk_base[sb.frame_first_blk];
+        const uint32_t init[3] = {rep_init[3 * b], rep_init[3 * b + 1], rep_init[3 * b + 2]};
+        for (uint32_t s0 = 0; s0 < sb.n_seq; s0 += 256) {
+            if (tid == 0) {
+                s_nlong = 0;
+                s_ndone = 0;
+            }
+            __syncthreads();
+            const uint64_t g = sb.seq_first + s0 + tid;
+            if (s0 + tid < sb.n_seq && flags[g] == 0) {
+                const Seq q = seqs[g];
+                bool bad = false;
+                const uint32_t off = rep_resolve(q.off, init, &bad);
+                const uint64_t mpos = mdst[g];
+                if (bad || off > mpos - fstart) {                // reaches before the frame: corrupt
+                    flag_error(status, kStBadOffset, sb.blk);
+                    flags[g] = pass;
+                    atomicAdd(&s_ndone, 1u);
+                } else {
+                    const uint64_t src = mpos - off;
+                    const uint64_t need_hi = src + q.ml < mpos ? src + q.ml : mpos;   // the rest is the match itself
+                    if (lz_range_final(src, need_hi, mdst, seqs, flags, g, pass)) {
+                        if (q.ml <= kLzShort) {
+                            Elem *d = out + mpos;
+                            const Elem *s = out + src;
+                            for (uint32_t k = 0; k < q.ml; k++) d[k] = s[k];   // byte-serial: overlap allowed
+                            flags[g] = pass;
+                            atomicAdd(&s_ndone, 1u);
+                        } else {
+                            s_long[atomicAdd(&s_nlong, 1u)] = s0 + tid;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t nl = s_nlong;
+            for (uint32_t j = 0; j < nl; j++) {                  // long matches: the whole workgroup on each
+                const uint64_t gi = sb.seq_first + s_long[j];
+                const Seq q = seqs[gi];
+                bool bad = false;
+                const uint32_t off = rep_resolve(q.off, init, &bad);
+                Elem *d = out + mdst[gi];
+                const Elem *s = d - off;
+                if (off >= q.ml) {
+                    for (uint32_t k = tid; k < q.ml; k += 256) d[k] = s[k];
+                } else {
+                    for (uint32_t k = tid; k < q.ml; k += 256) d[k] = s[k % off];   // overlapping: periodic
+                }
+                if (tid == 0) flags[gi] = pass;
+            }
+            __syncthreads();
+            if (tid == 0 && (s_ndone + nl)) atomicSub(&blk_pending[b], s_ndone + nl);
+            __syncthreads();
+        }
     }
+}
+
+template <bool ASCII>
+__global__ __launch_bounds__(256) void k_lz_matches_ordered(const SeqBlock *__restrict__ blocks, uint32_t n_blocks,
+                                                            const Seq *__restrict__ seqs, const uint64_t *__restrict__ mdst,
+                                                            const uint32_t *__restrict__ flags, const uint32_t *__restrict__ blk_pending,
+                                                            const uint32_t *__restrict__ rep_init, const uint64_t *__restrict__ blk_base,
+                                                            uint8_t *out_bytes, uint32_t *status) {
+    using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
+    Elem *out = reinterpret_cast<Elem *>(out_bytes);
+    __shared__ uint32_t s_abort, s_pending, s_n;
+    __shared__ uint32_t s_idx[256];
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_abort = status[0];
     __syncthreads();
     if (s_abort != 0) return;
     for (uint32_t b = 0; b < n_blocks; b++) {
+        if (tid == 0) s_pending = blk_pending[b];
+        __syncthreads();
+        const uint32_t pend = s_pending;
+        __syncthreads();
+        if (pend == 0) continue;
         const SeqBlock sb = blocks[b];
-        const uint64_t obase = blk_base[sb.blk];
         const uint64_t fstart = blk_base[sb.frame_first_blk];
-        if (tid == 0 && s_frame != sb.frame_first_blk) {        // repeat offsets restart with each frame
-            s_frame = sb.frame_first_blk;
-            s_rep[0] = 1;
-            s_rep[1] = 4;
-            s_rep[2] = 8;
-        }
+        const uint32_t init[3] = {rep_init[3 * b], rep_init[3 * b + 1], rep_init[3 * b + 2]};
         for (uint32_t s0 = 0; s0 < sb.n_seq; s0 += 256) {
-            const uint32_t cnt = sb.n_seq - s0 < 256u ? sb.n_seq - s0 : 256u;
-            Seq q{0, 0, 0, 0, 0};
-            if (tid < cnt) {
-                q = seqs[sb.seq_first + s0 + tid];
-                s_ll[tid] = q.ll;
-                s_ml[tid] = q.ml;
-                s_off[tid] = q.ofv;
-            }
-            if (tid == 0) s_nslow = 0;
+            // collect the batch's pending matches (flags are read 256 at a time), restore their order
+            if (tid == 0) s_n = 0;
             __syncthreads();
-            const uint64_t batch_first = obase + seqs[sb.seq_first + s0].opos;   // first output byte of the batch
-            if (tid == 0) {                              // serial: repeat-offset history
-                uint32_t r0 = static_cast<uint32_t>(s_rep[0]), r1 = static_cast<uint32_t>(s_rep[1]), r2 = static_cast<uint32_t>(s_rep[2]);
-#pragma unroll 8
-                for (uint32_t i = 0; i < cnt; i++) {
-                    const uint32_t ll = s_ll[i], ofv = s_off[i];
-                    uint32_t off;
-                    if (ofv > 3) {
-                        off = ofv - 3;
-                        r2 = r1;
-                        r1 = r0;
-                        r0 = off;
-                    } else {
-                        const uint32_t idx = ofv - 1 + (ll == 0 ? 1u : 0u);
-                        if (idx == 0) {
-                            off = r0;
-                        } else {
-                            off = idx == 1 ? r1 : (idx == 2 ? r2 : r0 - 1);
-                            if (idx > 1) r2 = r1;
-                            r1 = r0;
-                            r0 = off;
-                        }
-                    }
-                    s_off[i] = off;
-                }
-                s_rep[0] = r0;
-                s_rep[1] = r1;
-                s_rep[2] = r2;
-            }
+            if (s0 + tid < sb.n_seq && flags[sb.seq_first + s0 + tid] == 0) s_idx[atomicAdd(&s_n, 1u)] = s0 + tid;
             __syncthreads();
-            if (tid < cnt) {
-                const uint64_t mpos = obase + q.opos + q.ll;     // first byte the match writes
-                const uint32_t off = s_off[tid];
-                if (off == 0 || off > mpos - fstart) {           // reaches before the frame: corrupt
-                    flag_error(status, kStBadOffset, sb.blk);
-                } else if (q.ml) {
-                    const bool independent = mpos - off + q.ml <= batch_first || tid == 0;
-                    if (independent && q.ml <= kLzShort && off >= q.ml) {
-                        Elem *d = out + mpos;
-                        const Elem *s = d - off;
-                        for (uint32_t k = 0; k < q.ml; k++) d[k] = s[k];
-                    } else {
-                        s_slow[atomicAdd(&s_nslow, 1u)] = tid;  // order restored below
-                    }
-                }
-            }
-            __syncthreads();
-            // dependent or long matches: in sequence order, the whole workgroup on each
-            const uint32_t ns = s_nslow;
-            if (ns) {
-                // s_slow was filled in arbitrary order: a rank sort by index (ns <= 256)
+            const uint32_t n = s_n;
+            if (n > 1) {
                 uint32_t mine = 0xFFFFFFFFu, rank = 0;
-                if (tid < ns) {
-                    mine = s_slow[tid];
-                    for (uint32_t j = 0; j < ns; j++) rank += s_slow[j] < mine ? 1u : 0u;
+                if (tid < n) {
+                    mine = s_idx[tid];
+                    for (uint32_t j = 0; j < n; j++) rank += s_idx[j] < mine ? 1u : 0u;
                 }
                 __syncthreads();
-                if (tid < ns) s_slow[rank] = mine;
+                if (tid < n) s_idx[rank] = mine;
                 __syncthreads();
-                for (uint32_t j = 0; j < ns; j++) {
-                    const uint32_t i = s_slow[j];
-                    const Seq qi = seqs[sb.seq_first + s0 + i];
-                    const uint32_t off = s_off[i], ml = qi.ml;
-                    Elem *d = out + obase + qi.opos + qi.ll;
+            }
+            for (uint32_t j = 0; j < n; j++) {               // strictly in order: every source is final by now
+                const uint64_t g = sb.seq_first + s_idx[j];
+                const Seq q = seqs[g];
+                bool bad = false;
+                const uint32_t off = rep_resolve(q.off, init, &bad);
+                const uint64_t mpos = mdst[g];
+                if (bad || off > mpos - fstart) {
+                    flag_error(status, kStBadOffset, sb.blk);
+                } else {
+                    Elem *d = out + mpos;
                     const Elem *s = d - off;
-                    if (off >= ml) {
-                        for (uint32_t k = tid; k < ml; k += 256) d[k] = s[k];
+                    if (off >= q.ml) {
+                        for (uint32_t k = tid; k < q.ml; k += 256) d[k] = s[k];
                     } else {
-                        for (uint32_t k = tid; k < ml; k += 256) d[k] = s[k % off];   // overlapping: periodic
+                        for (uint32_t k = tid; k < q.ml; k += 256) d[k] = s[k % off];
                     }
-                    __syncthreads();
                 }
+                __syncthreads();
             }
             __syncthreads();
         }
@@ -989,10 +1111,10 @@ __global__ __launch_bounds__(256) void k_hash64(const uint8_t *__restrict__ p, u
 // launchers
 // ======================================================================================
 void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *blocks, uint32_t n_blocks,
-                       const SeqCell *cells, Seq *seqs, uint32_t *blk_size, uint32_t *status) {
+                       const SeqCell *cells, Seq *seqs, uint32_t *blk_size, uint32_t *rep_final, uint32_t *status) {
     if (!n_blocks) return;
     hipLaunchKernelGGL(k_seq_decode, dim3((n_blocks + 63) / 64), dim3(64), 0, stream, src, blocks, n_blocks, cells, seqs,
-                       blk_size, status);
+                       blk_size, rep_final, status);
 }
 
 size_t scan_tmp_bytes(uint64_t n) { return static_cast<size_t>((n + kScanTile - 1) / kScanTile + 1) * sizeof(TileAgg); }
@@ -1064,19 +1186,26 @@ void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *ta
                            blk_base, out, lit, t_char, dbg, status);
 }
 
-void launch_lz_execute(hipStream_t stream, const SeqBlock *blocks, uint32_t n_blocks, const Seq *seqs,
-                       const uint8_t *lit, const uint64_t *blk_base, const uint32_t *blk_size, uint8_t *out, bool ascii,
-                       uint32_t t_char, uint32_t *status) {
-    if (!n_blocks) return;
-    if (ascii) {
-        hipLaunchKernelGGL(k_lz_literals<true>, dim3(n_blocks), dim3(256), 0, stream, blocks, seqs, lit, blk_base, blk_size,
-                           out, t_char, status);
-        hipLaunchKernelGGL(k_lz_matches<true>, dim3(1), dim3(256), 0, stream, blocks, n_blocks, seqs, blk_base, out, status);
-    } else {
-        hipLaunchKernelGGL(k_lz_literals<false>, dim3(n_blocks), dim3(256), 0, stream, blocks, seqs, lit, blk_base, blk_size,
-                           out, t_char, status);
-        hipLaunchKernelGGL(k_lz_matches<false>, dim3(1), dim3(256), 0, stream, blocks, n_blocks, seqs, blk_base, out, status);
-    }
+template <bool ASCII>
+static void lz_execute(hipStream_t stream, const LzArgs &a) {
+    hipLaunchKernelGGL(k_rep_chain, dim3(1), dim3(1), 0, stream, a.blocks, a.n_blocks, a.rep_final, a.rep_init, a.status);
+    hipLaunchKernelGGL(k_lz_literals<ASCII>, dim3(a.n_blocks), dim3(256), 0, stream, a.blocks, a.seqs, a.lit, a.blk_base,
+                       a.mdst, a.blk_pending, a.out, a.t_char, a.status);
+    const uint32_t grid = a.n_blocks < 256u * 8u ? a.n_blocks : 256u * 8u;
+    for (uint32_t pass = 1; pass <= kLzPasses; pass++)
+        hipLaunchKernelGGL(k_lz_match_pass<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.mdst,
+                           a.flags, a.blk_pending, a.rep_init, a.blk_base, a.out, pass, a.status);
+    hipLaunchKernelGGL(k_lz_matches_ordered<ASCII>, dim3(1), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.mdst,
+                       a.flags, a.blk_pending, a.rep_init, a.blk_base, a.out, a.status);
+}
+
+void launch_lz_execute(hipStream_t stream, const LzArgs &a, bool ascii) {
+    if (!a.n_blocks) return;
+    (void)hipMemsetAsync(a.flags, 0, a.n_sequences * sizeof(uint32_t), stream);
+    if (ascii)
+        lz_execute<true>(stream, a);
+    else
+        lz_execute<false>(stream, a);
 }
 
 void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed, uint8_t *ascii, uint64_t n_bases,

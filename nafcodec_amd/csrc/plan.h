@@ -68,11 +68,20 @@ struct SeqBlock {        // one compressed block with nbSeq > 0
 };
 static_assert(sizeof(SeqBlock) == 64, "SeqBlock layout");
 
-struct Seq {             // one decoded sequence (offset still in "offset_value" form)
-    uint32_t ll, ml, ofv;
+struct Seq {             // one decoded sequence
+    uint32_t ll, ml;
+    uint32_t off;        // match offset; bit 31 set: symbolic (see kRepToken) -- depends on the
+                         // repeat-offset history the block inherits from its predecessor
     uint32_t opos;       // output position of its literals, relative to the block's first byte
     uint32_t lpos;       // position of its literals in the block's literal section
 };
+
+// Repeat offsets (App. B): a block starts from the three offsets its predecessor ends with, which
+// k_seq_decode does not know (blocks decode in parallel).  It tracks them symbolically instead:
+//   token = kRepToken | slot << 24 | d   means   (initial rep[slot]) - d
+// and k_rep_chain later walks the blocks in frame order to turn every block's final triple into
+// the next block's initial one.
+constexpr uint32_t kRepToken = 0x80000000u;
 
 // device status words
 enum : uint32_t {

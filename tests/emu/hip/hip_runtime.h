@@ -66,6 +66,12 @@ inline T atomicMax(T *p, T v) {
     return old;
 }
 template <class T>
+inline T atomicSub(T *p, T v) {
+    T old = *p;
+    *p = old - v;
+    return old;
+}
+template <class T>
 inline T atomicAdd(T *p, T v) {
     T old = *p;
     *p = old + v;

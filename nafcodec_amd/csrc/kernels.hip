@@ -401,10 +401,8 @@ struct BackBits {
             nb -= lsh;
             lo = 0;
         }
-        const uint8_t *q = p + (lo >> 3);
-        uint64_t v = static_cast<uint64_t>(q[0]) | (static_cast<uint64_t>(q[1]) << 8) |
-                     (static_cast<uint64_t>(q[2]) << 16) | (static_cast<uint64_t>(q[3]) << 24) |
-                     (static_cast<uint64_t>(q[4]) << 32);   // the source buffer is padded at the back
+        uint64_t v;
+        __builtin_memcpy(&v, p + (lo >> 3), 8);   // one unaligned 8-byte load; the source buffer is padded at the back
         v >>= (lo & 7);
         return static_cast<uint32_t>(v & ((1ull << nb) - 1)) << lsh;
     }

@@ -377,7 +377,26 @@ static int huf_decode_stream(const huf_table *t, const uint8_t *src, size_t n, u
     if (back_init(&b, src, n) < 0)
         return -ZO_E_CORRUPT;
     int mb = t->max_bits;
-    for (size_t i = 0; i < count; i++) {
+    uint32_t mask = (1u << mb) - 1;
+    size_t i = 0;
+    /* bulk: one unaligned 64-bit load serves five symbols (5 x 11 bits <= 57) */
+    while (count - i >= 5 && b.pos >= 57) {
+        int64_t lo = b.pos - 57;
+        size_t byte = (size_t)(lo >> 3);
+        if (byte + 8 > n)
+            break;
+        uint64_t v;
+        memcpy(&v, src + byte, 8);
+        v >>= (lo & 7); /* bits [0,57) of v = stream bits [lo, pos) */
+        int used = 0;
+        for (int k = 0; k < 5; k++) {
+            huf_cell c = t->cell[(v >> (57 - used - mb)) & mask];
+            dst[i++] = c.sym;
+            used += c.len;
+        }
+        b.pos -= used;
+    }
+    for (; i < count; i++) {
         uint32_t v = back_peek(&b, mb);
         huf_cell c = t->cell[v];
         dst[i] = c.sym;

@@ -175,6 +175,8 @@ typedef struct {
     float ms_host_plan;          /* host: frame walk + table build (outside ms_total) */
     float ms_h2d;                /* host->device upload of archive + task lists (outside ms_total) */
     uint32_t n_huf_launches;
+    uint32_t reserved3;
+    uint64_t lz_residue_matches; /* LZ matches the parallel passes left to the pointer-jumping stage (all sections) */
 } nafgpu_device_result;
 
 int nafgpu_decode_all_device(nafgpu_decoder *dec, nafgpu_device_result *out);

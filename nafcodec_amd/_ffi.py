@@ -54,7 +54,7 @@ class DeviceResult(Structure):
                 ("carry", c_uint8), ("reserved", c_uint8 * 7),
                 ("ms_total", c_float), ("ms_huf", c_float), ("ms_unpack", c_float), ("ms_seq_lz", c_float),
                 ("ms_other", c_float), ("ms_host_plan", c_float), ("ms_h2d", c_float),
-                ("n_huf_launches", c_uint32)]
+                ("n_huf_launches", c_uint32), ("reserved3", c_uint32), ("lz_residue_matches", c_uint64)]
 
 
 class SynthSpec(Structure):

@@ -425,6 +425,7 @@ int nafgpu_decode_all_device(nafgpu_decoder *d, nafgpu_device_result *out) {
     out->ms_seq_lz = t.seq_lz;
     out->ms_other = t.other;
     out->n_huf_launches = t.huf_launches;
+    for (int s = 0; s < kNumSections; s++) out->lz_residue_matches += j.job(s).lz_residue();
     out->ms_host_plan = j.host_plan_ms();
     out->ms_h2d = j.h2d_ms();
     return NAFGPU_OK;

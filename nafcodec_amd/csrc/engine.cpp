@@ -161,7 +161,8 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
               d_mdst_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(uint64_t) + 16) &&
               d_flags_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(uint32_t) + 16) &&
               d_rep_final_.alloc(n_seq_blocks_ * 12 + 16) && d_rep_init_.alloc(n_seq_blocks_ * 12 + 16) &&
-              d_blk_pending_.alloc(n_seq_blocks_ * 4 + 16);
+              d_blk_pending_.alloc(n_seq_blocks_ * 4 + 16) &&
+              d_roff_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(uint32_t) + 16) && d_counters_.alloc(64);
     if (!ok) return Failure::make(NAFGPU_E_DEVICE, "out of device memory while preparing a section");
     // the host vectors were consumed by asynchronous copies: keep them until the stream drains
     if (!hip_ok(hipStreamSynchronize(stream))) return Failure::make(NAFGPU_E_DEVICE, "upload of task lists failed");
@@ -225,7 +226,37 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer) {
         la.out = d_out_.bytes();
         la.t_char = t_char_;
         la.status = status;
+        la.roff = d_roff_.as<uint32_t>();
+        la.counters = d_counters_.as<unsigned long long>();
         launch_lz_execute(stream, la, ascii);
+        // What the fixed number of passes could not resolve (dependency chains as long as the frame:
+        // quality strings, tandem repeats).  The host needs the count to size the scratch memory.
+        unsigned long long cnt[2] = {0, 0};
+        lz_residue_ = 0;
+        if (hip_ok(hipMemcpyAsync(cnt, la.counters, sizeof cnt, hipMemcpyDeviceToHost, stream)) &&
+            hip_ok(hipStreamSynchronize(stream)) && cnt[0] > 0) {
+            const uint64_t n_pending = cnt[0];
+            lz_residue_ = n_pending;
+            uint32_t *changed = reinterpret_cast<uint32_t *>(la.counters + 2);
+            bool done = false;
+            if (d_pj_list_.alloc(n_pending * sizeof(uint64_t)) && d_pj_dist_.alloc(static_cast<size_t>(expect_) * sizeof(uint32_t) + 16)) {
+                uint32_t *D = d_pj_dist_.as<uint32_t>();
+                (void)hipMemsetAsync(D, 0, static_cast<size_t>(expect_) * sizeof(uint32_t), stream);
+                launch_pj_collect(stream, la, d_pj_list_.as<uint64_t>());
+                launch_pj_step(stream, la, ascii, d_pj_list_.as<uint64_t>(), n_pending, D, 0, changed);
+                for (int it = 0; it < 64 && !done; it++) {           // chain length halves per step
+                    (void)hipMemsetAsync(changed, 0, sizeof(uint32_t), stream);
+                    launch_pj_step(stream, la, ascii, d_pj_list_.as<uint64_t>(), n_pending, D, 1, changed);
+                    uint32_t ch = 1;
+                    if (!hip_ok(hipMemcpyAsync(&ch, changed, sizeof ch, hipMemcpyDeviceToHost, stream)) ||
+                        !hip_ok(hipStreamSynchronize(stream)))
+                        break;
+                    done = ch == 0;
+                }
+                if (done) launch_pj_step(stream, la, ascii, d_pj_list_.as<uint64_t>(), n_pending, D, 2, changed);
+            }
+            if (!done) launch_lz_ordered(stream, la, ascii);         // no scratch memory / no convergence: frame order
+        }
         if (timer) timer->end(stream);
     }
 }

@@ -98,16 +98,19 @@ public:
     uint64_t n_blocks() const { return n_blocks_; }
     uint64_t n_streams() const { return n_streams_; }
     float host_plan_ms() const { return plan_ms_; }
+    uint64_t lz_residue() const { return lz_residue_; }
 
 private:
     ZPlan plan_;
+    uint64_t lz_residue_ = 0;
     uint64_t expect_ = 0, n_blocks_ = 0, n_streams_ = 0, n_tasks_ = 0, n_copies_ = 0, n_seq_blocks_ = 0;
     uint32_t max_tbl_direct_ = 0, max_tbl_lit_ = 0, n_direct_tasks_ = 0, t_char_ = 0;
     const uint8_t *d_src_ = nullptr;
     float plan_ms_ = 0;
     bool ready_ = false;
     DevBuf d_out_, d_lit_, d_seqs_, d_blk_size_, d_blk_base_, d_scan_tmp_, d_status_;
-    DevBuf d_mdst_, d_flags_, d_rep_final_, d_rep_init_, d_blk_pending_;
+    DevBuf d_mdst_, d_flags_, d_rep_final_, d_rep_init_, d_blk_pending_, d_roff_, d_counters_;
+    DevBuf d_pj_list_, d_pj_dist_;   // pointer-jumping scratch, allocated only when the passes leave a residue
     DevBuf d_streams_, d_tasks_, d_tbl_copies_, d_pool_, d_copies_, d_seq_blocks_, d_cells_;
 };
 

@@ -60,11 +60,21 @@ struct LzArgs {
     uint64_t *mdst;              // per sequence: output position of its match
     uint32_t *flags;             // per sequence: pass in which its match was completed (0 = pending)
     uint32_t *blk_pending;       // per block: matches still pending
+    uint32_t *roff;              // per sequence: resolved offset of a match that is still pending
+    unsigned long long *counters;// [0] matches still pending after the passes, [1] length of the pending list
     uint8_t *out;
     uint32_t t_char;
     uint32_t *status;
 };
+// rep chain + literal scatter + the fixed number of match passes (asynchronous)
 void launch_lz_execute(hipStream_t stream, const LzArgs &args, bool ascii);
+// what the passes left pending (args.counters[0] != 0):
+//   pointer jumping: collect the pending list, then op 0 (init D), op 1 (jump, repeat while *changed), op 2 (copy)
+void launch_pj_collect(hipStream_t stream, const LzArgs &args, uint64_t *list);
+void launch_pj_step(hipStream_t stream, const LzArgs &args, bool ascii, const uint64_t *list, uint64_t n_list, uint32_t *D,
+                    int op, uint32_t *changed);
+//   or, without scratch memory for D: one workgroup in frame order
+void launch_lz_ordered(hipStream_t stream, const LzArgs &args, bool ascii);
 
 // K5: 4-bit -> IUPAC ASCII; t_char = 'T' (DNA) or 'U' (RNA)
 void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed, uint8_t *ascii, uint64_t n_bases,

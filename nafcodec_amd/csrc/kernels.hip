@@ -682,7 +682,7 @@ __global__ __launch_bounds__(256) void k_copy_fill(const uint8_t *__restrict__ s
 // match of `ml` packed bytes at distance `off` copies ml 16-bit elements at distance off, and
 // literals are expanded while they are scattered.  The ASCII buffer itself is the LZ window.
 constexpr uint32_t kLzShort = 48;        // runs up to this many elements are copied by their own thread
-constexpr uint32_t kLzPasses = 12;
+constexpr uint32_t kLzPasses = 8;
 
 __device__ inline uint32_t rep_resolve(uint32_t tok, const uint32_t *init, bool *bad) {
     if (!(tok & kRepToken)) return tok;
@@ -791,7 +791,8 @@ __device__ inline bool lz_range_final(uint64_t lo, uint64_t hi, const uint64_t *
 template <bool ASCII>
 __global__ __launch_bounds__(256) void k_lz_match_pass(const SeqBlock *__restrict__ blocks, uint32_t n_blocks,
                                                        const Seq *__restrict__ seqs, const uint64_t *__restrict__ mdst,
-                                                       uint32_t *flags, uint32_t *blk_pending, const uint32_t *__restrict__ rep_init,
+                                                       uint32_t *flags, uint32_t *blk_pending, uint32_t *roff,
+                                                       unsigned long long *remaining, const uint32_t *__restrict__ rep_init,
                                                        const uint64_t *__restrict__ blk_base, uint8_t *out_bytes, uint32_t pass,
                                                        uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
@@ -830,6 +831,7 @@ __global__ __launch_bounds__(256) void k_lz_match_pass(const SeqBlock *__restric
                 } else {
                     const uint64_t src = mpos - off;
                     const uint64_t need_hi = src + q.ml < mpos ? src + q.ml : mpos;   // the rest is the match itself
+                    roff[g] = off;                               // kept for the pointer-jumping stage
                     if (lz_range_final(src, need_hi, mdst, seqs, flags, g, pass)) {
                         if (q.ml <= kLzShort) {
                             Elem *d = out + mpos;
@@ -860,10 +862,79 @@ __global__ __launch_bounds__(256) void k_lz_match_pass(const SeqBlock *__restric
                 if (tid == 0) flags[gi] = pass;
             }
             __syncthreads();
-            if (tid == 0 && (s_ndone + nl)) atomicSub(&blk_pending[b], s_ndone + nl);
+            if (tid == 0 && (s_ndone + nl)) {
+                atomicSub(&blk_pending[b], s_ndone + nl);
+                atomicAdd(remaining, ~static_cast<unsigned long long>(s_ndone + nl) + 1ull);   // -= done
+            }
             __syncthreads();
         }
     }
+}
+
+// ---- pointer jumping for what the passes leave behind --------------------------------------
+// Dense short-offset matches (quality strings, tandem repeats) form dependency chains as long as
+// the frame, which no fixed number of passes resolves.  For those, every element p of a pending
+// match gets D[p] = distance to an element it is a copy of (initially the match offset; 0 for every
+// final element).  One jump step replaces D[p] by D[p] + D[p - D[p]] -- the chain above p halves --
+// so after ~log2(chain length) steps every pending element points at a final one and is copied.
+__global__ __launch_bounds__(256) void k_pj_collect(const uint32_t *__restrict__ flags, uint64_t n_sequences, uint64_t *list,
+                                                    unsigned long long *count) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n_sequences; g += stride)
+        if (flags[g] == 0) list[atomicAdd(count, 1ull)] = g;
+}
+
+enum PjOp { kPjInit = 0, kPjJump = 1, kPjCopy = 2 };
+
+template <bool ASCII, int OP>
+__global__ __launch_bounds__(256) void k_pj_step(const uint64_t *__restrict__ list, uint64_t n_list, const Seq *__restrict__ seqs,
+                                                 const uint64_t *__restrict__ mdst, const uint32_t *__restrict__ roff, uint32_t *D,
+                                                 uint8_t *out_bytes, uint32_t *changed) {
+    using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
+    Elem *out = reinterpret_cast<Elem *>(out_bytes);
+    __shared__ uint32_t s_long[256];
+    __shared__ uint32_t s_nlong;
+    const uint32_t tid = threadIdx.x;
+    bool any_change = false;
+    auto element = [&](uint64_t p, uint32_t off) {
+        if (OP == kPjInit) {
+            D[p] = off;
+        } else if (OP == kPjJump) {
+            const uint32_t d = D[p];
+            const uint32_t da = D[p - d];
+            if (da != 0 && static_cast<uint64_t>(d) + da <= 0xFFFFFFFFull) {
+                D[p] = d + da;
+                any_change = true;
+            }
+        } else {
+            out[p] = out[p - D[p]];
+        }
+    };
+    for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * 256; base < n_list; base += static_cast<uint64_t>(gridDim.x) * 256) {
+        if (tid == 0) s_nlong = 0;
+        __syncthreads();
+        if (base + tid < n_list) {
+            const uint64_t g = list[base + tid];
+            const uint32_t ml = seqs[g].ml;
+            if (ml <= kLzShort) {
+                const uint64_t mpos = mdst[g];
+                const uint32_t off = roff[g];
+                for (uint32_t k = 0; k < ml; k++) element(mpos + k, off);
+            } else {
+                s_long[atomicAdd(&s_nlong, 1u)] = tid;
+            }
+        }
+        __syncthreads();
+        const uint32_t nl = s_nlong;
+        for (uint32_t j = 0; j < nl; j++) {
+            const uint64_t g = list[base + s_long[j]];
+            const uint32_t ml = seqs[g].ml, off = roff[g];
+            const uint64_t mpos = mdst[g];
+            for (uint32_t k = tid; k < ml; k += 256) element(mpos + k, off);
+        }
+        __syncthreads();
+    }
+    if (OP == kPjJump && any_change) *changed = 1;
 }
 
 template <bool ASCII>
@@ -875,7 +946,8 @@ __global__ __launch_bounds__(256) void k_lz_matches_ordered(const SeqBlock *__re
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
     __shared__ uint32_t s_abort, s_pending, s_n;
-    __shared__ uint32_t s_idx[256];
+    __shared__ uint32_t s_idx[256], s_ml[256], s_off[256];
+    __shared__ uint64_t s_mpos[256];
     const uint32_t tid = threadIdx.x;
     if (tid == 0) s_abort = status[0];
     __syncthreads();
@@ -906,21 +978,29 @@ __global__ __launch_bounds__(256) void k_lz_matches_ordered(const SeqBlock *__re
                 if (tid < n) s_idx[rank] = mine;
                 __syncthreads();
             }
-            for (uint32_t j = 0; j < n; j++) {               // strictly in order: every source is final by now
-                const uint64_t g = sb.seq_first + s_idx[j];
+            // stage the pending records in LDS: the in-order loop below must not wait on global loads
+            if (tid < n) {
+                const uint64_t g = sb.seq_first + s_idx[tid];
                 const Seq q = seqs[g];
                 bool bad = false;
                 const uint32_t off = rep_resolve(q.off, init, &bad);
                 const uint64_t mpos = mdst[g];
-                if (bad || off > mpos - fstart) {
+                s_mpos[tid] = mpos;
+                s_ml[tid] = q.ml;
+                s_off[tid] = (bad || off > mpos - fstart) ? 0u : off;
+            }
+            __syncthreads();
+            for (uint32_t j = 0; j < n; j++) {               // strictly in order: every source is final by now
+                const uint32_t off = s_off[j], ml = s_ml[j];
+                if (off == 0) {
                     flag_error(status, kStBadOffset, sb.blk);
                 } else {
-                    Elem *d = out + mpos;
+                    Elem *d = out + s_mpos[j];
                     const Elem *s = d - off;
-                    if (off >= q.ml) {
-                        for (uint32_t k = tid; k < q.ml; k += 256) d[k] = s[k];
+                    if (off >= ml) {
+                        for (uint32_t k = tid; k < ml; k += 256) d[k] = s[k];
                     } else {
-                        for (uint32_t k = tid; k < q.ml; k += 256) d[k] = s[k % off];
+                        for (uint32_t k = tid; k < ml; k += 256) d[k] = s[k % off];
                     }
                 }
                 __syncthreads();
@@ -1192,18 +1272,54 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
     const uint32_t grid = a.n_blocks < 256u * 8u ? a.n_blocks : 256u * 8u;
     for (uint32_t pass = 1; pass <= kLzPasses; pass++)
         hipLaunchKernelGGL(k_lz_match_pass<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.mdst,
-                           a.flags, a.blk_pending, a.rep_init, a.blk_base, a.out, pass, a.status);
-    hipLaunchKernelGGL(k_lz_matches_ordered<ASCII>, dim3(1), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.mdst,
-                       a.flags, a.blk_pending, a.rep_init, a.blk_base, a.out, a.status);
+                           a.flags, a.blk_pending, a.roff, a.counters, a.rep_init, a.blk_base, a.out, pass, a.status);
 }
 
 void launch_lz_execute(hipStream_t stream, const LzArgs &a, bool ascii) {
     if (!a.n_blocks) return;
     (void)hipMemsetAsync(a.flags, 0, a.n_sequences * sizeof(uint32_t), stream);
+    const unsigned long long init[2] = {a.n_sequences, 0ull};          // remaining matches, pending-list length
+    (void)hipMemcpyAsync(a.counters, init, sizeof init, hipMemcpyHostToDevice, stream);
     if (ascii)
         lz_execute<true>(stream, a);
     else
         lz_execute<false>(stream, a);
+}
+
+void launch_lz_ordered(hipStream_t stream, const LzArgs &a, bool ascii) {
+    if (ascii)
+        hipLaunchKernelGGL(k_lz_matches_ordered<true>, dim3(1), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.mdst,
+                           a.flags, a.blk_pending, a.rep_init, a.blk_base, a.out, a.status);
+    else
+        hipLaunchKernelGGL(k_lz_matches_ordered<false>, dim3(1), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.mdst,
+                           a.flags, a.blk_pending, a.rep_init, a.blk_base, a.out, a.status);
+}
+
+void launch_pj_collect(hipStream_t stream, const LzArgs &a, uint64_t *list) {
+    hipLaunchKernelGGL(k_pj_collect, dim3(256 * 8), dim3(256), 0, stream, a.flags, a.n_sequences, list, a.counters + 1);
+}
+
+template <bool ASCII>
+static void pj_step(hipStream_t stream, const LzArgs &a, const uint64_t *list, uint64_t n_list, uint32_t *D, int op,
+                    uint32_t *changed) {
+    uint64_t blocks = (n_list + 255) / 256;
+    if (blocks > 256u * 16u) blocks = 256u * 16u;
+    const dim3 grid(static_cast<uint32_t>(blocks));
+    if (op == kPjInit)
+        hipLaunchKernelGGL((k_pj_step<ASCII, kPjInit>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.mdst, a.roff, D, a.out, changed);
+    else if (op == kPjJump)
+        hipLaunchKernelGGL((k_pj_step<ASCII, kPjJump>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.mdst, a.roff, D, a.out, changed);
+    else
+        hipLaunchKernelGGL((k_pj_step<ASCII, kPjCopy>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.mdst, a.roff, D, a.out, changed);
+}
+
+void launch_pj_step(hipStream_t stream, const LzArgs &a, bool ascii, const uint64_t *list, uint64_t n_list, uint32_t *D, int op,
+                    uint32_t *changed) {
+    if (!n_list) return;
+    if (ascii)
+        pj_step<true>(stream, a, list, n_list, D, op, changed);
+    else
+        pj_step<false>(stream, a, list, n_list, D, op, changed);
 }
 
 void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed, uint8_t *ascii, uint64_t n_bases,

@@ -52,6 +52,11 @@ def build_cases(scale=1):
                                      quality=True, level=3, line_length=301))
     add("fastq_flush_per_record", nw.write_naf(make_records(rng, [151] * 300, quality=True), quality=True, level=3,
                                                zstd_kwargs={"flush_every": 151}))
+    # dense short-offset match chains (what real quality strings look like to zstd): deeper than any
+    # fixed number of match passes, resolved by the pointer-jumping stage
+    dense = "".join(rng.choice(list("GGGGGGGJJJJF#"), 60000 * scale))
+    add("text_dense_chains", nw.write_naf([{"id": "q", "sequence": dense}], sequence_type="text", level=3))
+    add("dna_dense_chains", nw.write_naf([{"id": "d", "sequence": "".join(rng.choice(list("AAAAAAAT"), 150001 * scale))}], level=3))
     add("title_and_extended", nw.write_naf(make_records(rng, [10, 20, 30]), title="a title ✓", extended=True))
     add("v2_dna", nw.write_naf(make_records(rng, [100, 101]), version=2))
     add("no_ids_no_comments", nw.write_naf(make_records(rng, [5, 6, 7]), ids=False, comments=False))

@@ -45,6 +45,15 @@ def test_fixtures_match_oracle(emu, name):
     assert cases.run_product(blob, {}, emu) == cases.run_oracle(blob, {})
 
 
+def test_pointer_jumping_stage_is_exercised(emu, all_cases):
+    import io
+    from nafcodec_amd.decoder import Decoder
+    for name, blob, opts in all_cases:
+        if name in ("text_dense_chains", "dna_dense_chains"):
+            res = Decoder(io.BytesIO(blob), _lib=emu).decode_all_device()
+            assert res.lz_residue_matches > 0, name
+
+
 def test_synthetic_writer_roundtrip(emu):
     """nafgpu_synth_write output: valid for libzstd, decodes to the writer's own checksums."""
     import ctypes

@@ -145,3 +145,16 @@ def test_shared_cases_match_oracle(lib):
         if cases.run_product(blob, opts) != cases.run_oracle(blob, opts):
             bad.append(name)
     assert not bad
+
+
+def test_pointer_jumping_stage_is_exercised(lib):
+    """Dense short-offset chains must leave a residue after the fixed match passes (else this test
+    stopped covering the pointer-jumping stage) and still decode bit-exactly."""
+    import cases
+    import nafcodec_amd
+    for name, blob, opts in cases.build_cases(scale=4):
+        if name in ("text_dense_chains", "dna_dense_chains"):
+            dec = nafcodec_amd.Decoder(io.BytesIO(blob))
+            res = dec.decode_all_device()
+            assert res.lz_residue_matches > 0, name
+            assert cases.run_product(blob, opts) == cases.run_oracle(blob, opts)

@@ -232,9 +232,11 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer) {
         // What the fixed number of passes could not resolve (dependency chains as long as the frame:
         // quality strings, tandem repeats).  The host needs the count to size the scratch memory.
         unsigned long long cnt[2] = {0, 0};
+        uint32_t st_now = 1;
         lz_residue_ = 0;
         if (hip_ok(hipMemcpyAsync(cnt, la.counters, sizeof cnt, hipMemcpyDeviceToHost, stream)) &&
-            hip_ok(hipStreamSynchronize(stream)) && cnt[0] > 0) {
+            hip_ok(hipMemcpyAsync(&st_now, status, sizeof st_now, hipMemcpyDeviceToHost, stream)) &&
+            hip_ok(hipStreamSynchronize(stream)) && st_now == 0 && cnt[0] > 0) {   // a flagged section stays untouched
             const uint64_t n_pending = cnt[0];
             lz_residue_ = n_pending;
             uint32_t *changed = reinterpret_cast<uint32_t *>(la.counters + 2);

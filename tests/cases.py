@@ -151,3 +151,42 @@ def run_product(blob, opts, lib=None):
     except OSError:
         return recs, "io:invalid"
     return recs, None
+
+
+def fuzz_cases(seed=1, n=120):
+    """Corrupted variants (bit flips, byte overwrites, truncations) of small valid archives.
+    Every decoder must terminate on them; where both the oracle and the product succeed they must
+    agree (error *detection* may differ in strictness, the data may not)."""
+    from conftest import golden_bytes
+    rng = np.random.default_rng(seed)
+    seeds = [golden_bytes(name + ".naf") for name in ("phix", "masked", "CP040672", "LuxC")]
+    recs = make_records(rng, [3000, 2000, 151, 0, 77], iupac=0.02, quality=True)
+    seeds.append(nw.write_naf(recs, level=3, quality=True, mask_runs=[100, 50, 5000, 20, 58]))
+    seeds.append(nw.write_naf(make_records(rng, [40000]), level=1))
+    dense = "".join(rng.choice(list("GGGGGGGJJJJF#"), 30000))
+    seeds.append(nw.write_naf([{"id": "q", "sequence": dense}], sequence_type="text", level=3))
+    out = []
+    for it in range(n):
+        blob = bytearray(seeds[it % len(seeds)])
+        for _ in range(int(rng.integers(1, 4))):
+            mode = int(rng.integers(0, 3))
+            pos = int(rng.integers(0, len(blob)))
+            if mode == 0:
+                blob[pos] ^= 1 << int(rng.integers(0, 8))
+            elif mode == 1:
+                blob[pos] = int(rng.integers(0, 256))
+            else:
+                blob = blob[:pos]
+            if not blob:
+                break
+        out.append(("fuzz%d" % it, bytes(blob), {}))
+    return out
+
+
+def fuzz_disagreements(cases_list, lib=None):
+    bad = []
+    for name, blob, opts in cases_list:
+        got, want = run_product(blob, opts, lib), run_oracle(blob, opts)
+        if got[1] is None and want[1] is None and got != want:
+            bad.append(name)
+    return bad

@@ -96,6 +96,7 @@ lib = _ffi.Library(%r)
 todo = [c for c in cases.build_cases(1) if not c[0].endswith("_big")]
 todo += [(n, golden_bytes(n + ".naf"), {}) for n in ("phix", "masked", "CP040672")]
 bad = [n for n, blob, opts in todo if cases.run_product(blob, opts, lib) != cases.run_oracle(blob, opts)]
+bad += cases.fuzz_disagreements(cases.fuzz_cases(seed=7, n=70), lib)      # corrupted archives: no OOB, no silent garbage
 print("BAD", bad)
 sys.exit(1 if bad else 0)
 """ % (ROOT, os.path.join(ROOT, "tests"), os.path.join(EMU_DIR, "libnafgpu_emu_asan.so"))

@@ -158,3 +158,11 @@ def test_pointer_jumping_stage_is_exercised(lib):
             res = dec.decode_all_device()
             assert res.lz_residue_matches > 0, name
             assert cases.run_product(blob, opts) == cases.run_oracle(blob, opts)
+
+
+def test_corrupted_archives_terminate_and_never_disagree_silently(lib):
+    """The same corrupted inputs the CPU harness runs under AddressSanitizer: on the GPU they must
+    come back as errors (or as the same records the oracle gives), never as a fault or a hang."""
+    import cases
+    assert cases.fuzz_disagreements(cases.fuzz_cases(seed=7, n=70)) == []
+    assert cases.fuzz_disagreements(cases.fuzz_cases(seed=11, n=120)) == []

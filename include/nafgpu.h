@@ -163,9 +163,10 @@ typedef struct {
     uint64_t seq_compressed_bytes;
     uint64_t n_zstd_blocks;      /* sequence section */
     uint64_t n_huf_streams;      /* sequence section */
-    uint64_t first_record;       /* shard: index of the first record starting in this shard */
-    uint8_t carry;               /* shard: 1 if the shard starts on an odd nibble */
-    uint8_t reserved[7];
+    uint64_t first_record;       /* shard: index of the first record that STARTS in this shard */
+    uint8_t carry;               /* shard: 1 if the shard begins inside a record (its head belongs to record first_record-1) */
+    uint8_t sharded;             /* 1 if shard_count > 1 was honoured (sequence section without LZ sequences) */
+    uint8_t reserved[6];
     /* timing of the last decode_all, milliseconds (HIP events on the decoder's stream) */
     float ms_total;              /* first kernel launch -> last kernel done */
     float ms_huf;                /* sum over launches of the Huffman literal kernel */
@@ -177,6 +178,7 @@ typedef struct {
     uint32_t n_huf_launches;
     uint32_t reserved3;
     uint64_t lz_residue_matches; /* LZ matches the parallel passes left to the pointer-jumping stage (all sections) */
+    uint64_t base_offset;        /* shard: global index of d_sequence[0] (0 unless sharded) */
 } nafgpu_device_result;
 
 int nafgpu_decode_all_device(nafgpu_decoder *dec, nafgpu_device_result *out);
@@ -223,6 +225,9 @@ void nafgpu_synth_free(nafgpu_synth_archive *a);
  * sum over 4 KiB chunks c of mix(c, sum_i (byte_i + 1) * (2 i + 1)) -- see hash64.h */
 uint64_t nafgpu_hash64_host(const uint8_t *p, uint64_t n);
 int nafgpu_hash64_device(const nafgpu_decoder *dec, const void *d_ptr, uint64_t n, uint64_t *out);
+/* same, for a buffer that starts at 4 KiB chunk `first_chunk` of a larger object: the values of
+ * consecutive shards add up (mod 2^64) to the checksum of the whole object */
+int nafgpu_hash64_device_at(const nafgpu_decoder *dec, const void *d_ptr, uint64_t n, uint64_t first_chunk, uint64_t *out);
 
 /* library / device identification, for logs */
 int nafgpu_abi_version(void);

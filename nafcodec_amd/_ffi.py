@@ -51,10 +51,11 @@ class DeviceResult(Structure):
                 ("n_ids_bytes", c_uint64), ("n_comments_bytes", c_uint64),
                 ("packed_bytes", c_uint64), ("compressed_bytes", c_uint64), ("seq_compressed_bytes", c_uint64),
                 ("n_zstd_blocks", c_uint64), ("n_huf_streams", c_uint64), ("first_record", c_uint64),
-                ("carry", c_uint8), ("reserved", c_uint8 * 7),
+                ("carry", c_uint8), ("sharded", c_uint8), ("reserved", c_uint8 * 6),
                 ("ms_total", c_float), ("ms_huf", c_float), ("ms_unpack", c_float), ("ms_seq_lz", c_float),
                 ("ms_other", c_float), ("ms_host_plan", c_float), ("ms_h2d", c_float),
-                ("n_huf_launches", c_uint32), ("reserved3", c_uint32), ("lz_residue_matches", c_uint64)]
+                ("n_huf_launches", c_uint32), ("reserved3", c_uint32), ("lz_residue_matches", c_uint64),
+                ("base_offset", c_uint64)]
 
 
 class SynthSpec(Structure):
@@ -76,7 +77,7 @@ EXPORTS = [
     "nafgpu_get_header", "nafgpu_remaining", "nafgpu_next", "nafgpu_close", "nafgpu_last_error",
     "nafgpu_decode_all_device", "nafgpu_zstd_decompress", "nafgpu_synth_write", "nafgpu_synth_free",
     "nafgpu_hash64_host", "nafgpu_hash64_device", "nafgpu_abi_version", "nafgpu_device_info",
-    "nafgpu_upload", "nafgpu_device_synchronize",
+    "nafgpu_upload", "nafgpu_device_synchronize", "nafgpu_hash64_device_at",
 ]
 
 
@@ -115,6 +116,7 @@ class Library:
         L.nafgpu_hash64_host.argtypes = [c_char_p, c_uint64]
         L.nafgpu_hash64_host.restype = c_uint64
         L.nafgpu_hash64_device.argtypes = [c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]
+        L.nafgpu_hash64_device_at.argtypes = [c_void_p, c_void_p, c_uint64, c_uint64, POINTER(c_uint64)]
         L.nafgpu_device_info.argtypes = [c_int, c_char_p, c_size_t, POINTER(c_uint64), POINTER(c_int)]
 
     # ---- helpers ---------------------------------------------------------------------------

@@ -4,6 +4,7 @@
 // open = header + section table only (cheap, errors as the reference raises them at open);
 // the first next() / decode_all_device() runs the whole GPU decode; next() then slices
 // records out of the decoded sections exactly as next_record (mod.rs:356-399) zips its readers.
+#include <algorithm>
 #include <cerrno>
 #include <cstdio>
 #include <cstring>
@@ -167,6 +168,8 @@ Failure ensure_uploaded(nafgpu_decoder *d) {
                                          d->opts.sequence != 0, d->opts.quality != 0};
         for (int s = 0; s < kNumSections; s++) ao.want[s] = want[s];
         ao.spec_mask = d->opts.spec_mask != 0;
+        ao.shard_count = d->opts.shard_count > 1 ? static_cast<uint32_t>(d->opts.shard_count) : 1u;
+        ao.shard_rank = d->opts.shard_rank > 0 ? static_cast<uint32_t>(d->opts.shard_rank) : 0u;
         f = d->job.upload(d->bytes, d->n_bytes, d->header, d->sec, ao);
         if (!f.ok()) return d->fatal = f;
         d->device_ready = true;
@@ -404,7 +407,22 @@ int nafgpu_decode_all_device(nafgpu_decoder *d, nafgpu_device_result *out) {
     const ArchiveJob &j = d->job;
     out->d_sequence = d->use[kSequence] ? j.d_sequence() : nullptr;
     const bool nuc = d->header.sequence_type <= 1;
-    out->n_bases = d->use[kSequence] ? (nuc ? d->sec[kSequence].original_size : j.n_sequence_bytes()) : 0;
+    // bases held by this decoder: the whole section, or (sharded) global bases [base0, base1)
+    const uint64_t total_bases = d->use[kSequence] ? (nuc ? d->sec[kSequence].original_size : j.job(kSequence).total_size()) : 0;
+    const uint64_t base0 = std::min(j.sequence_offset(), total_bases);
+    const uint64_t base1 = std::min(j.sequence_offset() + j.n_sequence_bytes(), total_bases);
+    out->n_bases = base1 - base0;
+    out->base_offset = base0;
+    out->sharded = j.job(kSequence).ready() && j.job(kSequence).sharded() ? 1 : 0;
+    if (d->use[kLengths] && !d->rec_ends.empty()) {
+        // first record that STARTS in this shard (start_k = end_{k-1}); carry: the shard begins inside a record
+        const auto it = std::lower_bound(d->rec_ends.begin(), d->rec_ends.end(), base0);   // first end >= base0
+        uint64_t k = static_cast<uint64_t>(it - d->rec_ends.begin());                     // records ending before base0 ... k-1
+        const bool at_start = base0 == 0 || (k > 0 && d->rec_ends[k - 1] == base0) || (it != d->rec_ends.end() && *it == base0);
+        if (it != d->rec_ends.end() && *it == base0) k += 1;      // record k ends exactly here: the next one starts here
+        out->carry = at_start ? 0 : 1;
+        out->first_record = at_start ? k : k + 1;
+    }
     out->d_quality = j.d_section(kQuality);
     out->n_quality = j.section_size(kQuality);
     out->d_record_end = d->use[kLengths] ? j.d_rec_ends() : nullptr;
@@ -443,8 +461,12 @@ int nafgpu_device_synchronize(int device) {
 }
 
 int nafgpu_hash64_device(const nafgpu_decoder *d, const void *d_ptr, uint64_t n, uint64_t *out) {
+    return nafgpu_hash64_device_at(d, d_ptr, n, 0, out);
+}
+
+int nafgpu_hash64_device_at(const nafgpu_decoder *d, const void *d_ptr, uint64_t n, uint64_t first_chunk, uint64_t *out) {
     if (!d || !out) return NAFGPU_E_INVALID_ARG;
-    Failure f = const_cast<nafgpu_decoder *>(d)->job.hash_device(d_ptr, n, out);
+    Failure f = const_cast<nafgpu_decoder *>(d)->job.hash_device(d_ptr, n, first_chunk, out);
     return f.status;
 }
 

@@ -115,13 +115,13 @@ StageTimes StageTimer::collect() {
 
 // ------------------------------------------------------------------ SectionJob
 Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expect_size, const uint8_t *d_payload,
-                            hipStream_t stream, uint32_t ascii_t_char) {
+                            hipStream_t stream, uint32_t ascii_t_char, uint32_t shard_rank, uint32_t shard_count) {
     ready_ = false;
     t_char_ = ascii_t_char;
     plan_ = ZPlan();
     const double t0 = now_ms();
     bool truncated = false;
-    std::string err = build_zplan(host_payload, n, &plan_, &truncated);
+    std::string err = build_zplan(host_payload, n, &plan_, &truncated, shard_rank, shard_count);
     plan_ms_ = static_cast<float>(now_ms() - t0);
     if (!err.empty())
         return Failure::io(truncated ? NAFGPU_IO_UNEXPECTED_EOF : NAFGPU_IO_INVALID_DATA, "zstd: " + err);
@@ -134,6 +134,8 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
     n_seq_blocks_ = plan_.seq_blocks.size();
     if (plan_.seq_blocks.empty() && plan_.known_out != expect_size)
         return Failure::io(NAFGPU_IO_INVALID_DATA, "zstd: decoded size differs from the size recorded in the archive");
+    out0_ = plan_.sharded ? plan_.shard_out0 : 0;
+    out1_ = plan_.sharded ? plan_.shard_out1 : expect_size;
     max_tbl_direct_ = max_tbl_lit_ = 0;
     n_direct_tasks_ = plan_.n_direct_tasks;
     for (size_t i = 0; i < plan_.tasks.size(); i++) {
@@ -191,13 +193,15 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer) {
     launch_scan_blocks(stream, d_blk_size_.as<uint32_t>(), n_blocks_, d_blk_base_.as<uint64_t>(), d_scan_tmp_.bytes(),
                        expect_, status);
     const bool ascii = t_char_ != 0;
+    // kernels address the section output as out + position; a shard holds positions [out0_, out1_)
+    uint8_t *const out_base = d_out_.bytes() - out0_ * (ascii ? 2 : 1);
     launch_copy_fill(stream, d_src_, d_copies_.as<CopyTask>(), static_cast<uint32_t>(n_copies_),
-                     d_blk_base_.as<uint64_t>(), d_out_.bytes(), d_lit_.bytes(), ascii, t_char_, status);
+                     d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(), ascii, t_char_, status);
     if (timer) timer->end(stream);
     if (n_direct_tasks_) {                                   // streams of literal-only blocks: straight to the output
         if (timer) timer->begin(stream, StageTimer::kHuf);
         launch_huf_decode(stream, d_src_, d_tasks_.as<HufTask>(), n_direct_tasks_, d_tbl_copies_.as<HufTblCopy>(),
-                          d_streams_.as<HufStream>(), d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), d_out_.bytes(),
+                          d_streams_.as<HufStream>(), d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), out_base,
                           d_lit_.bytes(), max_tbl_direct_, ascii, t_char_, status);
         if (timer) timer->end(stream);
     }
@@ -205,7 +209,7 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer) {
         if (timer) timer->begin(stream, StageTimer::kHuf);
         launch_huf_decode(stream, d_src_, d_tasks_.as<HufTask>() + n_direct_tasks_,
                           static_cast<uint32_t>(n_tasks_ - n_direct_tasks_), d_tbl_copies_.as<HufTblCopy>(),
-                          d_streams_.as<HufStream>(), d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), d_out_.bytes(),
+                          d_streams_.as<HufStream>(), d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), out_base,
                           d_lit_.bytes(), max_tbl_lit_, false, t_char_, status);
         if (timer) timer->end(stream);
     }
@@ -223,7 +227,7 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer) {
         la.mdst = d_mdst_.as<uint64_t>();
         la.flags = d_flags_.as<uint32_t>();
         la.blk_pending = d_blk_pending_.as<uint32_t>();
-        la.out = d_out_.bytes();
+        la.out = out_base;
         la.t_char = t_char_;
         la.status = status;
         la.roff = d_roff_.as<uint32_t>();
@@ -325,8 +329,10 @@ Failure ArchiveJob::upload(const uint8_t *bytes, size_t n, const nafgpu_header &
         uint64_t expect = sec[s].original_size;
         if (s == kSequence && is_nuc_) expect = (expect + 1) / 2;     // nucleotides -> packed bytes
         const uint32_t t_char = (s == kSequence && is_nuc_) ? (h.sequence_type == 1 ? 'U' : 'T') : 0;
+        const bool shard_this = s == kSequence && opt.shard_count > 1;
         fail_[s] = job_[s].prepare(bytes + sec[s].offset, static_cast<size_t>(sec[s].compressed_size), expect,
-                                   d_archive_.bytes() + kSrcFrontPad + sec[s].offset, stream_, t_char);
+                                   d_archive_.bytes() + kSrcFrontPad + sec[s].offset, stream_, t_char,
+                                   shard_this ? opt.shard_rank : 0, shard_this ? opt.shard_count : 1);
         plan_ms_ += job_[s].host_plan_ms();
         if (fail_[s].status == NAFGPU_E_DEVICE) return fail_[s];
         if (fail_[s].ok()) compressed_ += sec[s].compressed_size;
@@ -368,10 +374,12 @@ Failure ArchiveJob::decode() {
         timer_.begin(stream_, StageTimer::kOther);
         launch_scan_runs_u8(stream_, job_[kMask].out(), mask_cap_, d_mask_ends_.as<uint64_t>(), mask_cap_,
                             d_scan_tmp_.bytes(), &totals[1], status);
-        uint8_t *seq = job_[kSequence].out_mut();
-        const uint64_t n_seq = is_nuc_ ? mask_total_bases_ : std::min<uint64_t>(mask_total_bases_, job_[kSequence].size());
-        launch_mask_apply(stream_, seq, std::min<uint64_t>(n_seq, n_sequence_bytes()), d_mask_ends_.as<uint64_t>(),
-                          &totals[1], d_rec_ends_.as<uint64_t>(), &totals[0], mask_cap_, opt_.spec_mask ? 1 : 0, status);
+        const uint64_t mult = is_nuc_ ? 2 : 1;
+        const uint64_t lo = job_[kSequence].shard_out0() * mult, hi = job_[kSequence].shard_out1() * mult;   // bases held here
+        uint8_t *seq = job_[kSequence].out_mut() - lo;         // addressed by global base index
+        const uint64_t n_all = is_nuc_ ? mask_total_bases_ : std::min<uint64_t>(mask_total_bases_, job_[kSequence].total_size());
+        launch_mask_apply(stream_, seq, n_all, lo, hi, d_mask_ends_.as<uint64_t>(), &totals[1], d_rec_ends_.as<uint64_t>(),
+                          &totals[0], mask_cap_, opt_.spec_mask ? 1 : 0, status);
         timer_.end(stream_);
     }
     timer_.mark_total_end(stream_);
@@ -396,6 +404,11 @@ const uint8_t *ArchiveJob::d_sequence() const {
     return job_[kSequence].out();
 }
 
+uint64_t ArchiveJob::sequence_offset() const {
+    if (!job_[kSequence].ready()) return 0;
+    return job_[kSequence].shard_out0() * (is_nuc_ ? 2 : 1);
+}
+
 uint64_t ArchiveJob::n_sequence_bytes() const {
     if (!job_[kSequence].ready()) return 0;
     return job_[kSequence].out_bytes();
@@ -409,11 +422,11 @@ Failure ArchiveJob::copy_to_host(void *dst, const void *d_src, size_t n) {
     return Failure();
 }
 
-Failure ArchiveJob::hash_device(const void *d_ptr, uint64_t n, uint64_t *out) {
+Failure ArchiveJob::hash_device(const void *d_ptr, uint64_t n, uint64_t first_chunk, uint64_t *out) {
     (void)hipSetDevice(device_);
     unsigned long long *acc = d_hash_.as<unsigned long long>();
     (void)hipMemsetAsync(acc, 0, 8, stream_);
-    launch_hash64(stream_, static_cast<const uint8_t *>(d_ptr), n, acc);
+    launch_hash64(stream_, static_cast<const uint8_t *>(d_ptr), n, first_chunk, acc);
     unsigned long long v = 0;
     Failure f = copy_to_host(&v, acc, 8);
     *out = v;

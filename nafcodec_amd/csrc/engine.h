@@ -81,8 +81,10 @@ public:
     // ascii_t_char != 0: nucleotide sequence section -- every byte bound for the section output is
     // expanded to its two IUPAC characters on the way ('T' / 'U' for code 1); out() then holds
     // 2 * size() ASCII bytes and the packed form never exists in HBM.
+    // shard_count > 1: decode only this rank's contiguous block range (see build_zplan); out() then
+    // holds decoded bytes [shard_out0(), shard_out1()) of the section.
     Failure prepare(const uint8_t *host_payload, size_t n, uint64_t expect_size, const uint8_t *d_payload,
-                    hipStream_t stream, uint32_t ascii_t_char = 0);
+                    hipStream_t stream, uint32_t ascii_t_char = 0, uint32_t shard_rank = 0, uint32_t shard_count = 1);
     // Enqueues the decode kernels.  Results: out() holds size() bytes once the stream is done.
     void run(hipStream_t stream, StageTimer *timer);
     // After synchronisation: device status -> Failure
@@ -90,8 +92,12 @@ public:
 
     const uint8_t *out() const { return d_out_.bytes(); }
     uint8_t *out_mut() const { return d_out_.bytes(); }
-    uint64_t size() const { return expect_; }                       // decoded zstd bytes
-    uint64_t out_bytes() const { return expect_ * (t_char_ ? 2 : 1); }   // bytes behind out()
+    uint64_t size() const { return out1_ - out0_; }                 // decoded zstd bytes held (the whole section unless sharded)
+    uint64_t total_size() const { return expect_; }                 // decoded zstd bytes of the whole section
+    uint64_t shard_out0() const { return out0_; }
+    uint64_t shard_out1() const { return out1_; }
+    bool sharded() const { return plan_.sharded; }
+    uint64_t out_bytes() const { return size() * (t_char_ ? 2 : 1); }   // bytes behind out()
     bool ascii() const { return t_char_ != 0; }
     bool ready() const { return ready_; }
     const ZPlan &plan() const { return plan_; }
@@ -103,6 +109,7 @@ public:
 private:
     ZPlan plan_;
     uint64_t lz_residue_ = 0;
+    uint64_t out0_ = 0, out1_ = 0;
     uint64_t expect_ = 0, n_blocks_ = 0, n_streams_ = 0, n_tasks_ = 0, n_copies_ = 0, n_seq_blocks_ = 0;
     uint32_t max_tbl_direct_ = 0, max_tbl_lit_ = 0, n_direct_tasks_ = 0, t_char_ = 0;
     const uint8_t *d_src_ = nullptr;
@@ -117,6 +124,7 @@ private:
 struct ArchiveOptions {
     bool want[kNumSections] = {true, true, true, true, true, true};
     bool spec_mask = false;
+    uint32_t shard_rank = 0, shard_count = 1;   // block-range sharding of the sequence section
 };
 
 // A whole archive on one GPU: sections -> record table -> ASCII bases.
@@ -134,6 +142,8 @@ public:
     const uint8_t *d_sequence() const;       // ASCII (nucleotides) or text
     uint64_t n_sequence_bytes() const;       // nucleotides: 2 * packed bytes (incl. a possible pad nibble)
     uint64_t packed_bytes() const { return is_nuc_ && job_[kSequence].ready() ? job_[kSequence].size() : 0; }
+    // first base / byte of the sequence section held by this shard (0 unless sharded)
+    uint64_t sequence_offset() const;
     const uint8_t *d_section(int s) const { return job_[s].ready() ? job_[s].out() : nullptr; }
     uint64_t section_size(int s) const { return job_[s].ready() ? job_[s].size() : 0; }
     const uint64_t *d_rec_ends() const { return d_rec_ends_.as<uint64_t>(); }
@@ -149,7 +159,7 @@ public:
     hipStream_t stream() const { return stream_; }
     int device() const { return device_; }
     Failure copy_to_host(void *dst, const void *d_src, size_t n);
-    Failure hash_device(const void *d_ptr, uint64_t n, uint64_t *out);
+    Failure hash_device(const void *d_ptr, uint64_t n, uint64_t first_chunk, uint64_t *out);
 
 private:
     int device_ = -1;

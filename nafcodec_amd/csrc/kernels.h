@@ -80,12 +80,15 @@ void launch_lz_ordered(hipStream_t stream, const LzArgs &args, bool ascii);
 void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed, uint8_t *ascii, uint64_t n_bases,
                     uint32_t t_char, uint32_t *status);
 
-// soft-mask: lower-case the masked runs (odd-numbered runs of mask_ends) honouring record ends
-void launch_mask_apply(hipStream_t stream, uint8_t *ascii, uint64_t n_bases, const uint64_t *mask_ends,
-                       const ScanTotals *mask_totals, const uint64_t *rec_ends, const ScanTotals *rec_totals,
+// soft-mask: lower-case the masked runs (odd-numbered runs of mask_ends) honouring record ends.
+// `ascii` is addressed by global base index; only bases [lo_clamp, hi_clamp) are touched (a shard).
+void launch_mask_apply(hipStream_t stream, uint8_t *ascii, uint64_t n_bases, uint64_t lo_clamp, uint64_t hi_clamp,
+                       const uint64_t *mask_ends, const ScanTotals *mask_totals, const uint64_t *rec_ends,
+                       const ScanTotals *rec_totals,
                        uint64_t max_runs, int spec_mask, uint32_t *status);
 
-// order-sensitive checksum of a device buffer (see hash64.h); *result must be zeroed first
-void launch_hash64(hipStream_t stream, const uint8_t *p, uint64_t n, unsigned long long *result);
+// order-sensitive checksum of a device buffer (see hash64.h); *result must be zeroed first.
+// first_chunk: index of the buffer's first 4 KiB chunk in the whole object (shards add up)
+void launch_hash64(hipStream_t stream, const uint8_t *p, uint64_t n, uint64_t first_chunk, unsigned long long *result);
 
 }  // namespace nafgpu

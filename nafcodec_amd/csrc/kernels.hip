@@ -1085,7 +1085,8 @@ __device__ inline uint32_t lower4(uint32_t w, uint32_t byte_mask) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_bases, const uint64_t *__restrict__ mask_ends,
+__global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_bases, uint64_t lo_clamp, uint64_t hi_clamp,
+                                                    const uint64_t *__restrict__ mask_ends,
                                                     const ScanTotals *mask_totals, const uint64_t *__restrict__ rec_ends,
                                                     const ScanTotals *rec_totals, int spec_mask, const uint32_t *status) {
     // A workgroup takes 256 consecutive masked runs.  Phase 1: one run per thread -- clamp it and
@@ -1128,6 +1129,10 @@ __global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_b
                         s = rstart;
                 }
             }
+            // a shard holds bases [lo_clamp, hi_clamp) only
+            if (s < lo_clamp) s = lo_clamp;
+            if (e > hi_clamp) e = hi_clamp;
+            if (e < s) e = s;
         }
         __syncthreads();                                   // previous round's readers are done
         s_lo[tid] = s;
@@ -1160,7 +1165,8 @@ __global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_b
 // ======================================================================================
 // checksum (hash64.h)
 // ======================================================================================
-__global__ __launch_bounds__(256) void k_hash64(const uint8_t *__restrict__ p, uint64_t n, unsigned long long *result) {
+__global__ __launch_bounds__(256) void k_hash64(const uint8_t *__restrict__ p, uint64_t n, uint64_t first_chunk,
+                                                unsigned long long *result) {
     __shared__ uint64_t s_part[256];
     const uint64_t n_chunks = (n + kHashChunk - 1) / kHashChunk;
     uint64_t acc = 0;
@@ -1177,7 +1183,7 @@ __global__ __launch_bounds__(256) void k_hash64(const uint8_t *__restrict__ p, u
             if (threadIdx.x < d) s_part[threadIdx.x] += s_part[threadIdx.x + d];
             __syncthreads();
         }
-        if (threadIdx.x == 0) acc += hash_chunk_final(c, s_part[0]);
+        if (threadIdx.x == 0) acc += hash_chunk_final(first_chunk + c, s_part[0]);
         __syncthreads();
     }
     if (threadIdx.x == 0 && acc) atomicAdd(result, static_cast<unsigned long long>(acc));
@@ -1333,23 +1339,23 @@ void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed
                        n_bases, t_char, status);
 }
 
-void launch_mask_apply(hipStream_t stream, uint8_t *ascii, uint64_t n_bases, const uint64_t *mask_ends,
-                       const ScanTotals *mask_totals, const uint64_t *rec_ends, const ScanTotals *rec_totals,
-                       uint64_t max_runs, int spec_mask, uint32_t *status) {
-    if (!n_bases || !max_runs) return;
+void launch_mask_apply(hipStream_t stream, uint8_t *ascii, uint64_t n_bases, uint64_t lo_clamp, uint64_t hi_clamp,
+                       const uint64_t *mask_ends, const ScanTotals *mask_totals, const uint64_t *rec_ends,
+                       const ScanTotals *rec_totals, uint64_t max_runs, int spec_mask, uint32_t *status) {
+    if (!n_bases || !max_runs || hi_clamp <= lo_clamp) return;
     const uint64_t masked_runs = (max_runs + 1) / 2;
     uint64_t blocks = (masked_runs + 255) / 256;
     if (blocks > 256u * 8u) blocks = 256u * 8u;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(k_mask_apply, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, ascii, n_bases, mask_ends,
-                       mask_totals, rec_ends, rec_totals, spec_mask, status);
+    hipLaunchKernelGGL(k_mask_apply, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, ascii, n_bases, lo_clamp,
+                       hi_clamp, mask_ends, mask_totals, rec_ends, rec_totals, spec_mask, status);
 }
 
-void launch_hash64(hipStream_t stream, const uint8_t *p, uint64_t n, unsigned long long *result) {
+void launch_hash64(hipStream_t stream, const uint8_t *p, uint64_t n, uint64_t first_chunk, unsigned long long *result) {
     if (!n) return;
     uint64_t chunks = (n + kHashChunk - 1) / kHashChunk;
     if (chunks > 256u * 32u) chunks = 256u * 32u;
-    hipLaunchKernelGGL(k_hash64, dim3(static_cast<uint32_t>(chunks)), dim3(256), 0, stream, p, n, result);
+    hipLaunchKernelGGL(k_hash64, dim3(static_cast<uint32_t>(chunks)), dim3(256), 0, stream, p, n, first_chunk, result);
 }
 
 }  // namespace nafgpu

@@ -721,7 +721,8 @@ struct Walker {
 
 }  // namespace
 
-std::string build_zplan(const uint8_t *payload, size_t n, ZPlan *plan, bool *truncated) {
+std::string build_zplan(const uint8_t *payload, size_t n, ZPlan *plan, bool *truncated, uint32_t shard_rank,
+                        uint32_t shard_count) {
     Walker w{payload, n, plan, {}, {}, {}};
     *truncated = false;
     if (n == 0) {
@@ -735,10 +736,54 @@ std::string build_zplan(const uint8_t *payload, size_t n, ZPlan *plan, bool *tru
             return w.fail.msg.empty() ? std::string("malformed zstd frame") : w.fail.msg;
         }
     }
+    if (shard_count > 1 && plan->seq_blocks.empty() && !plan->blk_size.empty()) {
+        // contiguous block ranges balanced by decoded bytes; block boundaries only
+        const uint64_t total = plan->known_out;
+        const uint64_t lo_target = total / shard_count * shard_rank + std::min<uint64_t>(shard_rank, total % shard_count);
+        const uint64_t hi_target = total / shard_count * (shard_rank + 1) + std::min<uint64_t>(shard_rank + 1, total % shard_count);
+        uint64_t pos = 0;
+        uint32_t b0 = 0, b1 = 0;
+        uint64_t o0 = 0, o1 = 0;
+        bool have0 = false;
+        const uint32_t nb = static_cast<uint32_t>(plan->blk_size.size());
+        for (uint32_t b = 0; b <= nb; b++) {                 // a block belongs to the shard its first byte falls in
+            if (!have0 && (pos >= lo_target || b == nb)) {
+                b0 = b;
+                o0 = pos;
+                have0 = true;
+            }
+            if (have0 && (pos >= hi_target || b == nb)) {
+                b1 = b;
+                o1 = pos;
+                break;
+            }
+            if (b < nb) pos += plan->blk_size[b];
+        }
+        if (shard_rank + 1 == shard_count) {
+            b1 = nb;
+            o1 = total;
+        }
+        plan->sharded = true;
+        plan->shard_blk0 = b0;
+        plan->shard_blk1 = b1;
+        plan->shard_out0 = o0;
+        plan->shard_out1 = o1;
+        std::vector<HufStream> ks;
+        std::vector<HufRef> kt;
+        for (size_t s = 0; s < plan->streams.size(); s++)
+            if (plan->streams[s].blk >= b0 && plan->streams[s].blk < b1) {
+                ks.push_back(plan->streams[s]);
+                kt.push_back(w.stream_tbl[s]);
+            }
+        plan->streams.swap(ks);
+        w.stream_tbl.swap(kt);
+        std::vector<CopyTask> kc;
+        for (const CopyTask &t : plan->copies)
+            if (t.blk >= b0 && t.blk < b1) kc.push_back(t);
+        plan->copies.swap(kc);
+    }
     w.pack_tasks();
     return std::string();
 }
-
-bool zplan_is_literal_only(const ZPlan &plan) { return plan.seq_blocks.empty(); }
 
 }  // namespace nafgpu

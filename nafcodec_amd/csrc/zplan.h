@@ -38,14 +38,19 @@ struct ZPlan {
     uint32_t n_huf_tables = 0;
     uint64_t window_max = 0;
     bool has_checksum = false;
+    // multi-GPU sharding: this plan covers zstd blocks [shard_blk0, shard_blk1) only
+    bool sharded = false;
+    uint32_t shard_blk0 = 0, shard_blk1 = 0;
+    uint64_t shard_out0 = 0, shard_out1 = 0;   // decoded-byte range of those blocks
 };
 
 // Returns "" on success, else a description of the first malformed field.
 // `truncated` is set when the payload ends early (maps to Io(UnexpectedEof)).
-std::string build_zplan(const uint8_t *payload, size_t n, ZPlan *plan, bool *truncated);
-
-// Contiguous block range for multi-GPU sharding: restricts a plan to blocks [b0, b1).
-// Only valid when no block in the range has sequences reaching before b0 (literal-only ranges).
-bool zplan_is_literal_only(const ZPlan &plan);
+// shard_count > 1 restricts the task lists to the shard_rank-th of shard_count contiguous block
+// ranges balanced by decoded bytes.  That is only possible when no block has LZ sequences (every
+// block is then independent once treeless chains are resolved, which the walk has done); otherwise
+// the plan stays complete and `sharded` stays false (every rank decodes the whole section).
+std::string build_zplan(const uint8_t *payload, size_t n, ZPlan *plan, bool *truncated, uint32_t shard_rank = 0,
+                        uint32_t shard_count = 1);
 
 }  // namespace nafgpu

@@ -45,7 +45,7 @@ class Decoder:
     """lib.pyi:35-67.  `file` is a path or a binary file-like object."""
 
     def __init__(self, file, *, id=True, comment=True, sequence=True, quality=True, mask=True, buffer_size=None,
-                 device=-1, spec_mask=False, _lib=None):
+                 device=-1, spec_mask=False, shard_rank=0, shard_count=1, _lib=None):
         self._lib = _lib or _ffi.default()
         self._h = None
         opts = _ffi.Opts()
@@ -54,6 +54,7 @@ class Decoder:
         opts.spec_mask = int(spec_mask)
         opts.buffer_size = io.DEFAULT_BUFFER_SIZE if buffer_size is None else int(buffer_size)  # lib.rs:350-354
         opts.device = device
+        opts.shard_rank, opts.shard_count = shard_rank, shard_count   # bulk device path only (decode_all_device)
         h, err = c_void_p(), _ffi.Error()
         if isinstance(file, (str, bytes, os.PathLike)):
             path = os.fsencode(file)
@@ -157,9 +158,9 @@ class Decoder:
             _raise(err)
         return res
 
-    def hash_device(self, d_ptr, n):
+    def hash_device(self, d_ptr, n, first_chunk=0):
         out = ctypes.c_uint64()
-        rc = self._lib.c.nafgpu_hash64_device(self._h, d_ptr, n, byref(out))
+        rc = self._lib.c.nafgpu_hash64_device_at(self._h, d_ptr, n, first_chunk, byref(out))
         if rc != _ffi.OK:
             raise RuntimeError("nafgpu_hash64_device failed: %d" % rc)
         return out.value

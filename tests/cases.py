@@ -190,3 +190,39 @@ def fuzz_disagreements(cases_list, lib=None):
         if got[1] is None and want[1] is None and got != want:
             bad.append(name)
     return bad
+
+
+def check_sharding(lib, n_bases, mask, worlds=(2, 3, 5), seed=5):
+    """Block-range sharding of ONE archive (nafgpu_opts.shard_rank/shard_count): the shards tile the
+    base stream, their checksums add up to the whole archive's, and first_record / carry place each
+    shard in the global record table."""
+    import ctypes
+    import io
+    from nafcodec_amd.decoder import Decoder
+    kw = {} if lib is None else {"_lib": lib}
+    from nafcodec_amd import _ffi
+    L = lib or _ffi.default()
+    arc = L.synth(n_bases, seed=seed, with_mask=mask)
+    try:
+        blob = ctypes.string_at(arc.bytes, arc.n)
+        ends, pos = [], 0
+        for r in run_oracle(blob, {"sequence": False, "mask": False})[0]:
+            pos += r[4]
+            ends.append(pos)
+        starts = [0] + ends[:-1]
+        for world in worlds:
+            nxt, hsum = 0, 0
+            for rank in range(world):
+                d = Decoder(io.BytesIO(blob), shard_rank=rank, shard_count=world, **kw)
+                res = d.decode_all_device()
+                assert res.sharded == 1 and res.base_offset == nxt
+                assert res.n_bases == 0 or res.base_offset % 4096 == 0
+                hsum = (hsum + d.hash_device(res.d_sequence, res.n_bases, res.base_offset // 4096)) % (1 << 64)
+                want_first = sum(1 for st in starts if st < res.base_offset)
+                assert res.first_record == want_first, (world, rank, res.first_record, want_first)
+                assert res.carry == (0 if res.base_offset in starts or res.base_offset in (0, pos) else 1)
+                assert res.n_records == len(ends)
+                nxt = res.base_offset + res.n_bases
+            assert nxt == arc.n_bases and hsum == arc.seq_hash, (world, nxt, hsum)
+    finally:
+        L.c.nafgpu_synth_free(ctypes.byref(arc))

@@ -54,6 +54,11 @@ def test_pointer_jumping_stage_is_exercised(emu, all_cases):
             assert res.lz_residue_matches > 0, name
 
 
+def test_block_range_sharding(emu):
+    cases.check_sharding(emu, 3_000_001, True)
+    cases.check_sharding(emu, 1_500_000, False, worlds=(2, 8))
+
+
 def test_synthetic_writer_roundtrip(emu):
     """nafgpu_synth_write output: valid for libzstd, decodes to the writer's own checksums."""
     import ctypes

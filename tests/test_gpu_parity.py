@@ -166,3 +166,10 @@ def test_corrupted_archives_terminate_and_never_disagree_silently(lib):
     import cases
     assert cases.fuzz_disagreements(cases.fuzz_cases(seed=7, n=70)) == []
     assert cases.fuzz_disagreements(cases.fuzz_cases(seed=11, n=120)) == []
+
+
+def test_block_range_sharding(lib):
+    """configs[4] at small scale: one archive, every rank decodes a contiguous zstd-block range."""
+    import cases
+    cases.check_sharding(None, 40_000_001, True, worlds=(2, 8))
+    cases.check_sharding(None, 3_000_001, False, worlds=(3,))

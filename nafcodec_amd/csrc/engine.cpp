@@ -21,6 +21,7 @@ const char *status_text(uint32_t code) {
     case kStBadOffset: return "zstd: match offset reaches before the frame start";
     case kStSizeMismatch: return "zstd: decoded size differs from the size recorded in the archive";
     case kStRunsOverflow: return "run table overflow";
+    case kStInternal: return "internal error: a decode task exceeds its address window";
     default: return "zstd: device decoder reported an error";
     }
 }
@@ -273,6 +274,8 @@ Failure SectionJob::check(hipStream_t stream) {
     if (!hip_ok(hipMemcpyAsync(st, d_status_.bytes(), sizeof st, hipMemcpyDeviceToHost, stream)) ||
         !hip_ok(hipStreamSynchronize(stream)))
         return Failure::make(NAFGPU_E_DEVICE, "device status read-back failed");
+    if (st[0] == kStInternal)
+        return Failure::io(NAFGPU_IO_INVALID_DATA, std::string(status_text(st[0])) + " (detail " + std::to_string(st[1]) + ")");
     if (st[0] != 0) return Failure::io(NAFGPU_IO_INVALID_DATA, status_text(st[0]));
     return Failure();
 }

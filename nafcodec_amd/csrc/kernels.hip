@@ -56,8 +56,14 @@ __device__ inline void flag_error(uint32_t *status, uint32_t code, uint32_t deta
 //     [land the pair]: the loads are older than the round's stores in the in-order VM counter and
 //     have a whole round to arrive.
 constexpr uint32_t kRingWords = 16;
-constexpr uint32_t kOutPitch = 136;      // row pitch in bytes: 128 used, 8-byte aligned rows, 2-way banks at worst
-constexpr uint32_t kUnit = 64;           // output bytes flushed per row at a time
+constexpr uint32_t kUnit = 128;          // output bytes flushed per row at a time: one whole 128-byte line
+constexpr uint32_t kOutPitch = 200;      // row pitch in bytes: kUnit + 64 used, 8-byte aligned rows, 50-dword stride (conflict-free b16 writes)
+#ifndef NAFGPU_EMU
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#endif
+constexpr uint32_t kBufRange = 0x80000000u;   // bytes a wave's buffer descriptors cover
+constexpr uint32_t kBufOff = 0xFFFFFF00u;     // an offset outside that range: switches the lane off
+constexpr int kBufWord3 = 0x00020000;         // raw buffer descriptor word 3 (gfx9 family: DATA_FORMAT = 32)
 
 // Ordering point for LDS traffic inside a ONE-WAVE workgroup.  LDS instructions of a wave execute in
 // issue order, so no s_waitcnt / s_barrier is needed -- only the compiler must not move LDS accesses
@@ -115,8 +121,7 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     HIP_DYNAMIC_SHARED(uint2, s_tbl)
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[kRingWords * 64 * 4];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[64 * kOutPitch];
-    __shared__ uint64_t s_dst[64];     // destination byte offset of row coordinate 0 (64-byte aligned); bit 63: literal buffer
-    __shared__ uint64_t s_unit[64];    // per round: the row's flush descriptor (see publish)
+    __shared__ __attribute__((aligned(16))) uint32_t s_cunit[64];   // per round: descriptors of the ready rows, compacted (see publish)
     __shared__ uint32_t s_h[64];       // first row coordinate that belongs to this stream
     __shared__ uint32_t s_q[64];       // row coordinate of the next write
     __shared__ uint32_t s_fl[64];      // row coordinate of the row's byte 0 (multiple of kUnit)
@@ -184,6 +189,14 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     bool bad = false;
     uint8_t *wa = orow;                  // next write address inside the row
     uint32_t rbase = 0, end_abs = 0, h = 0;   // row coordinate of orow[0]; end and start of the stream in row coordinates
+    // A wave addresses memory through two buffer descriptors (input, output) whose bases are the
+    // lowest address any of its lanes touches; lanes use 32-bit offsets, and an offset outside the
+    // descriptor's range switches a lane off (load returns 0, store is dropped, no memory traffic).
+    // That makes every round issue the SAME number of vector-memory instructions whatever the lanes
+    // need, which is what lets hipcc wait for the round's loads with vmcnt(4) -- the four flush
+    // stores issued after them stay in flight across the next round instead of being drained.
+    uint64_t my_dst = ~0ull;             // destination offset of row coordinate 0 (64-byte aligned)
+    uint64_t my_low = ~0ull;             // lowest input address this lane may load
     if (have) {
         const uint8_t *lastp = src + st.src_end - 1;
         const uint32_t lastb = *lastp;
@@ -213,87 +226,120 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         h = static_cast<uint32_t>(dstart & (kUnit - 1));
         end_abs = h + st.n_syms * ((st.flags & 1) ? 1 : kOutB);
         wa = orow + h;
-        s_dst[lane] = (dstart - h) | ((st.flags & 1) ? (1ull << 63) : 0ull);
-    } else {
-        s_dst[lane] = 0;
+        my_dst = dstart - h;
+        my_low = (reinterpret_cast<uintptr_t>(src) + st.src_end - st.src_len - 192u) & ~static_cast<uint64_t>(15);   // look-ahead stays inside kSrcFrontPad
     }
     s_h[lane] = h;
-    __syncthreads();                                       // tables and row metadata are staged
+    {   // wave minima of my_dst / my_low through the (still unused) output rows
+        uint64_t *scratch = reinterpret_cast<uint64_t *>(s_out);
+        scratch[lane] = my_dst;
+        scratch[64 + lane] = my_low;
+        if (lane == 0) scratch[128] = st.flags & 1u;       // destination kind: uniform per launch (pack_tasks)
+    }
+    __syncthreads();                                       // tables, row metadata and the scratch are staged
+    uint64_t dbase = ~0ull, sbase = ~0ull;
+    for (uint32_t i = 0; i < 64; i++) {
+        const uint64_t a = reinterpret_cast<const uint64_t *>(s_out)[i], b = reinterpret_cast<const uint64_t *>(s_out)[64 + i];
+        dbase = a < dbase ? a : dbase;
+        sbase = b < sbase ? b : sbase;
+    }
+    const bool to_lit = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<const uint64_t *>(s_out)[128])) != 0;
+    __syncthreads();                                       // scratch is dead, rows may be written
+    auto uniform64 = [](uint64_t v) -> uint64_t {          // the builtin returns int: cast before widening
+        const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v)));
+        const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32)));
+        return (static_cast<uint64_t>(hi) << 32) | lo;
+    };
+    dbase = uniform64(dbase);
+    sbase = uniform64(sbase);
+    // pack_tasks keeps a task's streams within 1 GiB of input and of output; a lane that is not is a host bug
+    const bool in_range = !have || (my_dst - dbase < kBufRange - (1u << 20) &&
+                                    reinterpret_cast<uintptr_t>(ctop) - sbase < kBufRange - (1u << 20));
+    if (__any(in_range ? 0 : 1)) {
+        if (!in_range) flag_error(status, kStInternal, (my_dst - dbase < kBufRange - (1u << 20) ? 0u : 1u << 31) | (lane << 24) | (blockIdx.x & 0xFFFFFFu));
+        return;
+    }
+    const uint32_t dst_rel = have ? static_cast<uint32_t>(my_dst - dbase) : 0u;
+    const uint32_t src_rel = have ? static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ctop) - sbase) : 0u;
+    uint8_t *const obase = (to_lit ? lit : out) + dbase;
+    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(obase, 0, static_cast<int>(kBufRange), kBufWord3);
+    const __amdgpu_buffer_rsrc_t rs_src =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(static_cast<uintptr_t>(sbase)), 0, static_cast<int>(kBufRange), kBufWord3);
 
-    // ---- flush: one 64-byte unit per ready row, 4 lanes per row.  The row's owner publishes a
-    // descriptor; complete units (the common case) take the branch-light fast path, the first and
-    // last unit of a stream (bytes of a neighbouring stream / not produced yet) the generic one.
-    constexpr uint64_t kFlagLit = 1ull << 63, kFlagReady = 1ull << 62, kFlagFull = 1ull << 61;
-    constexpr uint64_t kPosMask = kFlagFull - 1;
-    const uint32_t qd = lane & 3;
-    const uint32_t frow0 = lane >> 2;                      // this lane serves rows frow0 + 16 k
-    auto publish = [&](bool final) {
+    // ---- flush: one 128-byte unit (a whole cache line / HBM burst pair) per ready row, 8 lanes per row.
+    // A round produces <= 64 bytes per row, so about half the rows are ready in any round: the owners
+    // compact their descriptors (position >> 7 | row | full) into a list, and store instruction k
+    // serves list entries 8 k .. 8 k + 7 -- every instruction writes eight whole 128-byte lines.
+    // The list is stored transposed (entry i at dword (i & 7) * 8 + (i >> 3)) so that the eight lanes
+    // of a group fetch their eight entries with two ds_read_b128.  The first and last unit of a stream
+    // (bytes of a neighbouring stream / not produced yet) are written byte-wise.
+    const uint32_t oct = lane & 7, grp = lane >> 3;
+    auto publish = [&](bool final) -> uint32_t {           // returns the number of ready rows
         const uint32_t avail = static_cast<uint32_t>(wa - orow);
         const bool ready = have && (avail >= kUnit || (final && avail > 0));
         const bool full = rbase >= h && avail >= kUnit;
-        const uint64_t d = s_dst[lane];
-        s_unit[lane] = ((d & ~kFlagLit) + rbase) | (d & kFlagLit) | (ready ? kFlagReady : 0) | (ready && full ? kFlagFull : 0);
+        const unsigned long long m = __ballot(ready ? 1 : 0);
+        const uint32_t rank = static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+        if (ready) s_cunit[(rank & 7u) * 8u + (rank >> 3)] = (((dst_rel + rbase) >> 7) << 8) | (lane << 2) | (full ? 3u : 1u);
         s_q[lane] = rbase + avail;
         s_fl[lane] = rbase;
+        return static_cast<uint32_t>(__popcll(m));
     };
-    auto flush = [&]() {
-        uint64_t u[4];
+    auto flush = [&](uint32_t n_ready) {
+        const uint32_t wmask = (dbg & 64u) ? 0x1FFF80u : ~127u;   // ablation: all stores into a small window
+        const uint4 c0 = *reinterpret_cast<const uint4 *>(&s_cunit[grp * 8]);
+        const uint4 c1 = *reinterpret_cast<const uint4 *>(&s_cunit[grp * 8 + 4]);
+        const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) u[k] = s_unit[frow0 + 16 * k];
-        const bool slow = __any((((u[0] & kFlagReady) && !(u[0] & kFlagFull)) || ((u[1] & kFlagReady) && !(u[1] & kFlagFull)) ||
-                                 ((u[2] & kFlagReady) && !(u[2] & kFlagFull)) || ((u[3] & kFlagReady) && !(u[3] & kFlagFull)))
-                                    ? 1 : 0) != 0;
-        if (!slow) {
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                if ((u[k] & kFlagReady) && !(dbg & 1u)) {
-                    const uint8_t *rowp = s_out + (frow0 + 16 * k) * kOutPitch + 16 * qd;
-                    const uint2 w0 = *reinterpret_cast<const uint2 *>(rowp);
-                    const uint2 w1 = *reinterpret_cast<const uint2 *>(rowp + 8);
-                    uint8_t *d = ((u[k] & kFlagLit) ? lit : out) + ((u[k] & kPosMask) & ((dbg & 64u) ? 0x1FFFC0ull : ~0ull)) + 16 * qd;
-                    *reinterpret_cast<uint4 *>(d) = make_uint4(w0.x, w0.y, w1.x, w1.y);
+        for (uint32_t k = 0; k < 8; k++) {
+            if (8 * k >= n_ready) break;                   // uniform
+            const bool valid = 8 * k + grp < n_ready;
+            const uint32_t row = (c[k] >> 2) & 63u, fl = c[k] & 3u, pos = (c[k] >> 8) << 7;
+            const uint8_t *rowp = s_out + row * kOutPitch + 16 * oct;
+            const uint2 w0 = *reinterpret_cast<const uint2 *>(rowp);
+            const uint2 w1 = *reinterpret_cast<const uint2 *>(rowp + 8);
+            const bool part = valid && fl == 1u && !(dbg & 1u);
+            if (__any(part ? 1 : 0)) {
+                if (part) {
+                    const uint32_t rfl = s_fl[row], rq = s_q[row], rh = s_h[row];
+                    const uint32_t lo_x = rfl + 16 * oct, hi_x = lo_x + 16;
+                    const uint32_t v_lo = lo_x > rh ? lo_x : rh, v_hi = hi_x < rq ? hi_x : rq;
+                    uint8_t *d = obase + pos + 16 * oct;
+                    for (uint32_t x = v_lo; x < v_hi; x++) d[x - lo_x] = rowp[x - lo_x];
                 }
             }
-            return;
-        }
-        // first / last unit of a stream: bytes of a neighbouring stream or not produced yet
-#pragma unroll 1
-        for (uint32_t k = 0; k < 4; k++) {
-            if (!(u[k] & kFlagReady) || (dbg & 1u)) continue;
-            const uint32_t row = frow0 + 16 * k;
-            const uint32_t rfl = s_fl[row], rq = s_q[row], rh = s_h[row];
-            const uint32_t lo_x = rfl + 16 * qd, hi_x = lo_x + 16;
-            const uint32_t v_lo = lo_x > rh ? lo_x : rh, v_hi = hi_x < rq ? hi_x : rq;
-            uint8_t *d = ((u[k] & kFlagLit) ? lit : out) + (u[k] & kPosMask) + 16 * qd;
-            const uint8_t *rowp = s_out + row * kOutPitch + 16 * qd;
-            for (uint32_t x = v_lo; x < v_hi; x++) d[x - lo_x] = rowp[x - lo_x];
+            const uint32_t voff = (valid && fl == 3u && !(dbg & 1u)) ? (pos & wmask) + 16 * oct : kBufOff;
+            u32x4 v;
+            v[0] = w0.x;
+            v[1] = w0.y;
+            v[2] = w1.x;
+            v[3] = w1.y;
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_dst, voff, 0, 0);
         }
     };
 
     // One round = [request the next 32-byte input pair unless one is still waiting for room] ->
-    // [flush what the previous round produced] -> [16 look-ups] -> [land the pair if it fits].
-    // Requesting before the flush makes the loads older than the round's stores in the in-order
-    // VM counter; measured alternatives (stores to a sink to make the count fixed, inline-asm
-    // counted waits) were slower or unsafe -- see DESIGN.md section 4.
-    const uint8_t *const lbase = have ? ctop : src;
+    // [flush the units the previous rounds completed] -> [16 look-ups] -> [land the pair if it fits].
+    // The loads are requested before the flush, so they are older than the round's stores in the
+    // in-order VM counter and have the whole round to arrive.
     uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0;
     bool pending = false;
     int any = 1;
     while (any) {
-        if (!pending && have) {
-            p0 = *reinterpret_cast<const uint4 *>(lbase - 32 * static_cast<size_t>(wp));
-            p1 = *reinterpret_cast<const uint4 *>(lbase - 32 * static_cast<size_t>(wp) - 16);
-            pending = true;
-        }
-        publish(false);
+        const uint32_t n_ready = publish(false);
         wave_sync();
-        flush();
+        const bool req = have && !pending;
+        const uint32_t loff = req ? src_rel - 32u * wp : kBufOff;
+        const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, loff, 0, 0);
+        const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, loff - 16u, 0, 0);
+        flush(n_ready);
         wave_sync();
-        if (static_cast<uint32_t>(wa - orow) >= kUnit) {   // the flush above took this row's first 64 bytes
-            const uint2 m0 = *reinterpret_cast<const uint2 *>(orow + 64), m1 = *reinterpret_cast<const uint2 *>(orow + 72);
-            const uint2 m2 = *reinterpret_cast<const uint2 *>(orow + 80), m3 = *reinterpret_cast<const uint2 *>(orow + 88);
-            const uint2 m4 = *reinterpret_cast<const uint2 *>(orow + 96), m5 = *reinterpret_cast<const uint2 *>(orow + 104);
-            const uint2 m6 = *reinterpret_cast<const uint2 *>(orow + 112), m7 = *reinterpret_cast<const uint2 *>(orow + 120);
+        if (static_cast<uint32_t>(wa - orow) >= kUnit) {   // the flush above took this row's first unit: < 64 bytes stay
+            const uint8_t *mv = orow + kUnit;
+            const uint2 m0 = *reinterpret_cast<const uint2 *>(mv), m1 = *reinterpret_cast<const uint2 *>(mv + 8);
+            const uint2 m2 = *reinterpret_cast<const uint2 *>(mv + 16), m3 = *reinterpret_cast<const uint2 *>(mv + 24);
+            const uint2 m4 = *reinterpret_cast<const uint2 *>(mv + 32), m5 = *reinterpret_cast<const uint2 *>(mv + 40);
+            const uint2 m6 = *reinterpret_cast<const uint2 *>(mv + 48), m7 = *reinterpret_cast<const uint2 *>(mv + 56);
             *reinterpret_cast<uint2 *>(orow + 0) = m0;
             *reinterpret_cast<uint2 *>(orow + 8) = m1;
             *reinterpret_cast<uint2 *>(orow + 16) = m2;
@@ -307,7 +353,7 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         }
         const uint32_t pos = rbase + static_cast<uint32_t>(wa - orow);
         if (dbg & 4u) {                                    // ablation: no decode, rows fill instantly
-            if (pos < end_abs) wa += (end_abs - pos < kUnit ? end_abs - pos : kUnit);
+            if (pos < end_abs) wa += (end_abs - pos < 64u ? end_abs - pos : 64u);
         } else if (pos + 32 * kOutB <= end_abs) {          // 16 look-ups cannot overrun the stream
 #pragma unroll
             for (uint32_t k = 0; k < 16; k++) {
@@ -343,6 +389,11 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         // d = words between the oldest ring slot and the cursor; staged past the cursor = 16 - d;
         // 8 words fit once d >= 8.  A round uses <= 6 words + 2 of look-ahead, and d >= 8 whenever
         // fewer than 9 are staged, so the cursor never outruns the ring.
+        if (req) {
+            p0 = make_uint4(t0[0], t0[1], t0[2], t0[3]);
+            p1 = make_uint4(t1[0], t1[1], t1[2], t1[3]);
+            pending = true;
+        }
         const uint32_t rp_mod = ((L.ra >> 8) - 2u) & 15u;
         const uint32_t d = (rp_mod - 8u * wp) & 15u;
         if (pending && d >= 8u && !(dbg & 32u)) {
@@ -360,14 +411,14 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         }
         any = __any(rbase + static_cast<uint32_t>(wa - orow) < end_abs ? 1 : 0);
     }
-    for (uint32_t t = 0; t < 2; t++) {                     // at most 63 + 64 bytes are left in a row
-        publish(true);
+    for (uint32_t t = 0; t < 2; t++) {                     // at most 127 + 64 bytes are left in a row
+        const uint32_t n_ready = publish(true);
         wave_sync();
-        flush();
+        flush(n_ready);
         wave_sync();
         const uint32_t avail = static_cast<uint32_t>(wa - orow);
         if (avail > kUnit) {
-            for (uint32_t j = 0; j < 64; j += 8) *reinterpret_cast<uint2 *>(orow + j) = *reinterpret_cast<const uint2 *>(orow + 64 + j);
+            for (uint32_t j = 0; j < 64; j += 8) *reinterpret_cast<uint2 *>(orow + j) = *reinterpret_cast<const uint2 *>(orow + kUnit + j);
             wa -= kUnit;
             rbase += kUnit;
         } else {

@@ -9,6 +9,7 @@ namespace nafgpu {
 constexpr uint32_t kBlockMax = 128u << 10;   // zstd Block_Maximum_Size
 constexpr int kHufWave = 64;                 // one Huffman stream per lane, one wave per workgroup
 constexpr uint32_t kHufLdsEntries = 2048;    // 8-byte decode-table entries a wave task may stage in LDS
+constexpr uint32_t kHufTaskSpan = 1u << 30;   // a wave task's streams lie within this many bytes of input and of output
 constexpr uint32_t kSrcFrontPad = 256;       // bytes readable in front of any device source buffer
 constexpr uint32_t kSrcBackPad = 64;
 
@@ -92,6 +93,7 @@ enum : uint32_t {
     kStBadOffset = 4,      // match offset reaches before the frame start
     kStSizeMismatch = 5,   // decoded size != section original size / block too large
     kStRunsOverflow = 6,
+    kStInternal = 7,       // a host-side guarantee did not hold (k_huf_decode: task spans > kHufTaskSpan)
 };
 
 }  // namespace nafgpu

@@ -666,6 +666,19 @@ struct Walker {
             size_t s = g0;
             while (s < g1) {
                 size_t e = std::min(g1, s + kHufWave);
+                // k_huf_decode addresses a task's input and output with 32-bit offsets from the lowest
+                // address of the task: keep both spans within kHufTaskSpan (output of a block with
+                // sequences is not known here: bound it by the block maximum, x2 for the ASCII expansion)
+                for (size_t k = s + 1; k < e; k++) {
+                    const HufStream &a = plan->streams[s], &b = plan->streams[k];
+                    const uint64_t src_span = b.src_end - (a.src_end - a.src_len);
+                    const uint64_t dst_span = (b.flags & 1) ? b.dst + b.n_syms - a.dst
+                                                            : (uint64_t(b.blk) - a.blk + 1) * kBlockMax * 2;
+                    if (b.src_end < a.src_end || b.blk < a.blk || src_span > kHufTaskSpan || dst_span > kHufTaskSpan) {
+                        e = k;
+                        break;
+                    }
+                }
                 uint32_t W = 8;
                 std::vector<HufRef> distinct;
                 for (;;) {

@@ -96,6 +96,29 @@ inline uint32_t __builtin_amdgcn_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
     return r;
 }
 
+// buffer descriptors (raw, stride 0): base + 32-bit offset, accesses outside [0, num_records) are
+// dropped (stores) or return 0 (loads) -- the range check k_huf_decode uses to switch lanes off
+#define NAFGPU_EMU 1
+typedef uint32_t u32x4 __attribute__((vector_size(16)));
+struct __amdgpu_buffer_rsrc_t {
+    uint8_t *base;
+    uint32_t n;
+};
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void *p, short, int n, int) {
+    return __amdgpu_buffer_rsrc_t{static_cast<uint8_t *>(p), static_cast<uint32_t>(n)};
+}
+inline u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, int) {
+    u32x4 v = {0, 0, 0, 0};
+    const uint64_t o = static_cast<uint64_t>(voff) + soff;
+    if (o + 16 <= r.n) std::memcpy(&v, r.base + o, 16);
+    return v;
+}
+inline void __builtin_amdgcn_raw_buffer_store_b128(u32x4 v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, int) {
+    const uint64_t o = static_cast<uint64_t>(voff) + soff;
+    if (o + 16 <= r.n) std::memcpy(r.base + o, &v, 16);
+}
+inline uint32_t __builtin_amdgcn_readfirstlane(uint32_t v) { return v; }   // only applied to wave-uniform values
+
 // ---- runtime API subset ----------------------------------------------------------------------
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };

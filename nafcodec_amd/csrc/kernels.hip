@@ -177,10 +177,14 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
 
     HufLane L{0, 0, 0, 31, 0};
     // one table look-up on the next bits of the stream; rare long codes take a second, sub-table look-up
-    auto lookup = [&]() -> uint2 {
+    // (tasks none of whose trees is deeper than W bits -- the common case -- run a copy of the loop without the test)
+    const bool task_esc = __any(esc_bits != 0 ? 1 : 0) != 0;
+    auto lookup = [&](auto esc) -> uint2 {
         const uint32_t peek = __builtin_amdgcn_alignbit(L.hi, L.lo, L.s);
         uint2 e = tbl[peek >> sh];
-        if (e.y & (1u << 25)) e = tbl[e.x + ((peek >> sh2) & esc_mask)];
+        if (decltype(esc)::value) {
+            if (e.y & (1u << 25)) e = tbl[e.x + ((peek >> sh2) & esc_mask)];
+        }
         return e;
     };
     const uint8_t *ctop = nullptr;       // 16-byte chunk holding the stream's last byte
@@ -274,6 +278,7 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     // of a group fetch their eight entries with two ds_read_b128.  The first and last unit of a stream
     // (bytes of a neighbouring stream / not produced yet) are written byte-wise.
     const uint32_t oct = lane & 7, grp = lane >> 3;
+    uint32_t n_part = 0;                                   // set by publish: rows whose unit is incomplete (uniform)
     auto publish = [&](bool final) -> uint32_t {           // returns the number of ready rows
         const uint32_t avail = static_cast<uint32_t>(wa - orow);
         const bool ready = have && (avail >= kUnit || (final && avail > 0));
@@ -281,8 +286,11 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         const unsigned long long m = __ballot(ready ? 1 : 0);
         const uint32_t rank = static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
         if (ready) s_cunit[(rank & 7u) * 8u + (rank >> 3)] = (((dst_rel + rbase) >> 7) << 8) | (lane << 2) | (full ? 3u : 1u);
-        s_q[lane] = rbase + avail;
-        s_fl[lane] = rbase;
+        n_part = static_cast<uint32_t>(__popcll(__ballot(ready && !full ? 1 : 0)));
+        if (n_part) {                                      // only the byte-wise path needs these
+            s_q[lane] = rbase + avail;
+            s_fl[lane] = rbase;
+        }
         return static_cast<uint32_t>(__popcll(m));
     };
     auto flush = [&](uint32_t n_ready) {
@@ -290,30 +298,40 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         const uint4 c0 = *reinterpret_cast<const uint4 *>(&s_cunit[grp * 8]);
         const uint4 c1 = *reinterpret_cast<const uint4 *>(&s_cunit[grp * 8 + 4]);
         const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        if (n_part && !(dbg & 1u)) {                       // first / last unit of a stream: byte-wise, rare
+#pragma unroll 1
+            for (uint32_t k = 0; 8 * k < n_ready; k++) {
+                const uint32_t ck = s_cunit[grp * 8 + k];
+                if (8 * k + grp >= n_ready || (ck & 3u) != 1u) continue;
+                const uint32_t row = (ck >> 2) & 63u, pos = (ck >> 8) << 7;
+                const uint32_t rfl = s_fl[row], rq = s_q[row], rh = s_h[row];
+                const uint32_t lo_x = rfl + 16 * oct, hi_x = lo_x + 16;
+                const uint32_t v_lo = lo_x > rh ? lo_x : rh, v_hi = hi_x < rq ? hi_x : rq;
+                uint8_t *d = obase + pos + 16 * oct;
+                const uint8_t *rowp = s_out + row * kOutPitch + 16 * oct;
+#pragma clang loop vectorize(disable) unroll(disable)
+                for (uint32_t x = v_lo; x < v_hi; x++) d[x - lo_x] = rowp[x - lo_x];
+            }
+        }
+        uint2 w[8][2];                                     // all LDS reads first: the stores then go out back to back
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) {
             if (8 * k >= n_ready) break;                   // uniform
-            const bool valid = 8 * k + grp < n_ready;
-            const uint32_t row = (c[k] >> 2) & 63u, fl = c[k] & 3u, pos = (c[k] >> 8) << 7;
-            const uint8_t *rowp = s_out + row * kOutPitch + 16 * oct;
-            const uint2 w0 = *reinterpret_cast<const uint2 *>(rowp);
-            const uint2 w1 = *reinterpret_cast<const uint2 *>(rowp + 8);
-            const bool part = valid && fl == 1u && !(dbg & 1u);
-            if (__any(part ? 1 : 0)) {
-                if (part) {
-                    const uint32_t rfl = s_fl[row], rq = s_q[row], rh = s_h[row];
-                    const uint32_t lo_x = rfl + 16 * oct, hi_x = lo_x + 16;
-                    const uint32_t v_lo = lo_x > rh ? lo_x : rh, v_hi = hi_x < rq ? hi_x : rq;
-                    uint8_t *d = obase + pos + 16 * oct;
-                    for (uint32_t x = v_lo; x < v_hi; x++) d[x - lo_x] = rowp[x - lo_x];
-                }
-            }
-            const uint32_t voff = (valid && fl == 3u && !(dbg & 1u)) ? (pos & wmask) + 16 * oct : kBufOff;
+            const uint8_t *rowp = s_out + ((c[k] >> 2) & 63u) * kOutPitch + 16 * oct;
+            w[k][0] = *reinterpret_cast<const uint2 *>(rowp);
+            w[k][1] = *reinterpret_cast<const uint2 *>(rowp + 8);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            if (8 * k >= n_ready) break;                   // uniform
+            const uint32_t pos = (c[k] >> 8) << 7;
+            const bool on = 8 * k + grp < n_ready && (c[k] & 3u) == 3u && !(dbg & 1u);
+            const uint32_t voff = on ? (pos & wmask) + 16 * oct : kBufOff;
             u32x4 v;
-            v[0] = w0.x;
-            v[1] = w0.y;
-            v[2] = w1.x;
-            v[3] = w1.y;
+            v[0] = w[k][0].x;
+            v[1] = w[k][0].y;
+            v[2] = w[k][1].x;
+            v[3] = w[k][1].y;
             __builtin_amdgcn_raw_buffer_store_b128(v, rs_dst, voff, 0, 0);
         }
     };
@@ -322,6 +340,42 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     // [flush the units the previous rounds completed] -> [16 look-ups] -> [land the pair if it fits].
     // The loads are requested before the flush, so they are older than the round's stores in the
     // in-order VM counter and have the whole round to arrive.
+    auto decode_round = [&](auto esc) {
+        const uint32_t pos = rbase + static_cast<uint32_t>(wa - orow);
+        if (dbg & 4u) {                                    // ablation: no decode, rows fill instantly
+            if (pos < end_abs) wa += (end_abs - pos < 64u ? end_abs - pos : 64u);
+        } else if (pos + 32 * kOutB <= end_abs) {          // 16 look-ups cannot overrun the stream
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint2 e = lookup(esc);
+                if (ASCII) {
+                    reinterpret_cast<uint16_t *>(wa)[0] = static_cast<uint16_t>(e.x);
+                    reinterpret_cast<uint16_t *>(wa)[1] = static_cast<uint16_t>(e.x >> 16);
+                } else {
+                    wa[0] = static_cast<uint8_t>(e.x);
+                    wa[1] = static_cast<uint8_t>(e.x >> 16);
+                }
+                wa += (e.y >> 8) & 0xFFu;
+                huf_advance(L, s_ring, e.y & 0xFFu);
+            }
+        } else if (pos < end_abs) {                        // tail of the stream: never take more than is left
+#pragma unroll 4
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint2 e = lookup(esc);
+                const uint32_t left = end_abs - (rbase + static_cast<uint32_t>(wa - orow));   // bytes
+                const bool two = ((e.y >> 24) & 1u) && left >= 2 * kOutB;
+                if (ASCII) {
+                    reinterpret_cast<uint16_t *>(wa)[0] = static_cast<uint16_t>(e.x);
+                    reinterpret_cast<uint16_t *>(wa)[1] = static_cast<uint16_t>(e.x >> 16);
+                } else {
+                    wa[0] = static_cast<uint8_t>(e.x);
+                    wa[1] = static_cast<uint8_t>(e.x >> 16);
+                }
+                wa += left == 0 ? 0u : (two ? 2 * kOutB : kOutB);
+                huf_advance(L, s_ring, left == 0 ? 0u : (two ? e.y & 0xFFu : (e.y >> 16) & 0xFFu));
+            }
+        }
+    };
     uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0;
     bool pending = false;
     int any = 1;
@@ -351,40 +405,8 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
             wa -= kUnit;
             rbase += kUnit;
         }
-        const uint32_t pos = rbase + static_cast<uint32_t>(wa - orow);
-        if (dbg & 4u) {                                    // ablation: no decode, rows fill instantly
-            if (pos < end_abs) wa += (end_abs - pos < 64u ? end_abs - pos : 64u);
-        } else if (pos + 32 * kOutB <= end_abs) {          // 16 look-ups cannot overrun the stream
-#pragma unroll
-            for (uint32_t k = 0; k < 16; k++) {
-                const uint2 e = lookup();
-                if (ASCII) {
-                    reinterpret_cast<uint16_t *>(wa)[0] = static_cast<uint16_t>(e.x);
-                    reinterpret_cast<uint16_t *>(wa)[1] = static_cast<uint16_t>(e.x >> 16);
-                } else {
-                    wa[0] = static_cast<uint8_t>(e.x);
-                    wa[1] = static_cast<uint8_t>(e.x >> 16);
-                }
-                wa += (e.y >> 8) & 0xFFu;
-                huf_advance(L, s_ring, e.y & 0xFFu);
-            }
-        } else if (pos < end_abs) {                        // tail of the stream: never take more than is left
-#pragma unroll 4
-            for (uint32_t k = 0; k < 16; k++) {
-                const uint2 e = lookup();
-                const uint32_t left = end_abs - (rbase + static_cast<uint32_t>(wa - orow));   // bytes
-                const bool two = ((e.y >> 24) & 1u) && left >= 2 * kOutB;
-                if (ASCII) {
-                    reinterpret_cast<uint16_t *>(wa)[0] = static_cast<uint16_t>(e.x);
-                    reinterpret_cast<uint16_t *>(wa)[1] = static_cast<uint16_t>(e.x >> 16);
-                } else {
-                    wa[0] = static_cast<uint8_t>(e.x);
-                    wa[1] = static_cast<uint8_t>(e.x >> 16);
-                }
-                wa += left == 0 ? 0u : (two ? 2 * kOutB : kOutB);
-                huf_advance(L, s_ring, left == 0 ? 0u : (two ? e.y & 0xFFu : (e.y >> 16) & 0xFFu));
-            }
-        }
+        if (task_esc) decode_round(std::true_type{});
+        else decode_round(std::false_type{});
         // ---- land the pair requested at the top of the round, if the ring has room for it.
         // d = words between the oldest ring slot and the cursor; staged past the cursor = 16 - d;
         // 8 words fit once d >= 8.  A round uses <= 6 words + 2 of look-ahead, and d >= 8 whenever

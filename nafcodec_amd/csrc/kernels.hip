@@ -187,20 +187,17 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         }
         return e;
     };
-    const uint8_t *ctop = nullptr;       // 16-byte chunk holding the stream's last byte
-    uint32_t wp = 0;                     // 32-byte chunk pairs landed in the ring
+    uintptr_t ptop = 0;                  // address of the 32-byte piece holding the stream's last byte
+    uint32_t wp = 0;                     // 32-byte pieces landed in the ring
     uint32_t c0 = 1, rp0 = 0, bits_total = 0;
     bool bad = false;
     uint8_t *wa = orow;                  // next write address inside the row
     uint32_t rbase = 0, end_abs = 0, h = 0;   // row coordinate of orow[0]; end and start of the stream in row coordinates
     // A wave addresses memory through two buffer descriptors (input, output) whose bases are the
     // lowest address any of its lanes touches; lanes use 32-bit offsets, and an offset outside the
-    // descriptor's range switches a lane off (load returns 0, store is dropped, no memory traffic).
-    // That makes every round issue the SAME number of vector-memory instructions whatever the lanes
-    // need, which is what lets hipcc wait for the round's loads with vmcnt(4) -- the four flush
-    // stores issued after them stay in flight across the next round instead of being drained.
-    uint64_t my_dst = ~0ull;             // destination offset of row coordinate 0 (64-byte aligned)
-    uint64_t my_low = ~0ull;             // lowest input address this lane may load
+    // descriptor's range switches a lane off (store is dropped, no memory traffic).
+    uint64_t my_dst = ~0ull;             // destination offset of row coordinate 0 (kUnit aligned)
+    uint64_t my_low = ~0ull;             // lowest input address this lane may load (128-byte aligned)
     if (have) {
         const uint8_t *lastp = src + st.src_end - 1;
         const uint32_t lastb = *lastp;
@@ -208,30 +205,17 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         const uint32_t hb = 31u - static_cast<uint32_t>(__clz(static_cast<int>(lastb | 1u)));
         bits_total = (st.src_len - 1u) * 8u + hb;
         const uintptr_t a = reinterpret_cast<uintptr_t>(lastp);
-        ctop = lastp - (a & 15);                                 // stays a global-memory pointer (no flat loads)
-        rp0 = 3u - static_cast<uint32_t>((a >> 2) & 3u);
+        ptop = a - (a & 31);
+        rp0 = 7u - static_cast<uint32_t>((a >> 2) & 7u);
         c0 = (3u - static_cast<uint32_t>(a & 3u)) * 8u + (8u - hb);   // bits of the top word already "consumed"
         L.s = 32u - c0;
-        for (uint32_t j = 0; j < 4; j++) {                       // the whole ring: 4 chunks = 2 pairs
-            const uint4 v = *reinterpret_cast<const uint4 *>(ctop - 16 * j);
-            uint32_t *r = reinterpret_cast<uint32_t *>(s_ring) + lane;
-            r[(4 * j + 0) * 64] = v.w;
-            r[(4 * j + 1) * 64] = v.z;
-            r[(4 * j + 2) * 64] = v.y;
-            r[(4 * j + 3) * 64] = v.x;
-        }
-        wp = 2;
-        const uint32_t *r = reinterpret_cast<const uint32_t *>(s_ring) + lane;
-        L.hi = r[rp0 * 64];
-        L.lo = r[(rp0 + 1) * 64];
-        L.nw = r[(rp0 + 2) * 64];
-        L.ra = ((rp0 + 2) << 8) | (lane << 2);
         const uint64_t dstart = ((st.flags & 1) ? st.dst : blk_base[st.blk] + st.dst) * ((st.flags & 1) ? 1 : kOutB);
         h = static_cast<uint32_t>(dstart & (kUnit - 1));
         end_abs = h + st.n_syms * ((st.flags & 1) ? 1 : kOutB);
         wa = orow + h;
         my_dst = dstart - h;
-        my_low = (reinterpret_cast<uintptr_t>(src) + st.src_end - st.src_len - 192u) & ~static_cast<uint64_t>(15);   // look-ahead stays inside kSrcFrontPad
+        // look-ahead of the ring (<= 96 bytes past the stream start), the rest of that line and the line requested after it: inside kSrcFrontPad
+        my_low = (reinterpret_cast<uintptr_t>(src) + st.src_end - st.src_len - 384u) & ~static_cast<uint64_t>(127);
     }
     s_h[lane] = h;
     {   // wave minima of my_dst / my_low through the (still unused) output rows
@@ -258,17 +242,59 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     sbase = uniform64(sbase);
     // pack_tasks keeps a task's streams within 1 GiB of input and of output; a lane that is not is a host bug
     const bool in_range = !have || (my_dst - dbase < kBufRange - (1u << 20) &&
-                                    reinterpret_cast<uintptr_t>(ctop) - sbase < kBufRange - (1u << 20));
+                                    ptop - sbase < kBufRange - (1u << 20));
     if (__any(in_range ? 0 : 1)) {
         if (!in_range) flag_error(status, kStInternal, (my_dst - dbase < kBufRange - (1u << 20) ? 0u : 1u << 31) | (lane << 24) | (blockIdx.x & 0xFFFFFFu));
         return;
     }
     const uint32_t dst_rel = have ? static_cast<uint32_t>(my_dst - dbase) : 0u;
-    const uint32_t src_rel = have ? static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ctop) - sbase) : 0u;
+    const uint32_t src_rel = have ? static_cast<uint32_t>(ptop - sbase) : 0u;   // sbase is 128-byte aligned: offsets and addresses share their low 7 bits
     uint8_t *const obase = (to_lit ? lit : out) + dbase;
     const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(obase, 0, static_cast<int>(kBufRange), kBufWord3);
     const __amdgpu_buffer_rsrc_t rs_src =
         __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(static_cast<uintptr_t>(sbase)), 0, static_cast<int>(kBufRange), kBufWord3);
+
+    // ---- input.  The stream is consumed in 32-byte aligned PIECES, numbered backwards from the one
+    // that holds its last byte (piece j = bytes [ptop - 32 j, ptop - 32 j + 32); ring word 8 j + i is the
+    // dword at offset 28 - 4 i of piece j).  Pieces come out of a whole 128-byte LINE that the lane keeps
+    // in 32 VGPRs: every line of compressed input is requested from L2 exactly once (with 16- or
+    // 32-byte refills the line had been evicted before its next piece was needed: twice the fetch
+    // traffic, four times the requests -- the refill loads then cost as much as the decode itself).
+    u32x4 line[8];                       // line[2 q], line[2 q + 1] = piece at offset 32 q of the line
+    uint32_t line_rel = 0;               // offset (from sbase) of the line held in `line`
+#pragma unroll
+    for (int i = 0; i < 8; i++) line[i] = u32x4{0, 0, 0, 0};
+    auto load_line = [&](uint32_t rel) {
+        line_rel = rel;
+#pragma unroll
+        for (int i = 0; i < 8; i++) line[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, rel + 16u * i, 0, 0);
+    };
+    // piece `wp` -> ring words 8 wp .. 8 wp + 7 (mod 16); requests the next lower line once this one is used up
+    auto land_piece = [&]() {
+        const uint32_t pa = src_rel - 32u * wp;
+        const uint32_t q = (pa >> 5) & 3u;
+        const bool b0 = q & 1u, b1 = q & 2u;
+        auto sel = [&](uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) { return b1 ? (b0 ? x3 : x2) : (b0 ? x1 : x0); };
+        uint32_t *r = reinterpret_cast<uint32_t *>(s_ring) + lane + ((8 * wp) & (kRingWords - 1)) * 64;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            r[i * 64] = sel(line[1][3 - i], line[3][3 - i], line[5][3 - i], line[7][3 - i]);
+            r[(4 + i) * 64] = sel(line[0][3 - i], line[2][3 - i], line[4][3 - i], line[6][3 - i]);
+        }
+        wp++;
+        if (q == 0) load_line(line_rel - 128u);            // wanted one or two rounds from now
+    };
+    if (have) {
+        load_line(src_rel & ~127u);
+        land_piece();                                      // the ring holds two pieces
+        land_piece();
+        const uint32_t *r = reinterpret_cast<const uint32_t *>(s_ring) + lane;
+        L.hi = r[rp0 * 64];
+        L.lo = r[(rp0 + 1) * 64];
+        L.nw = r[(rp0 + 2) * 64];
+        L.ra = ((rp0 + 2) << 8) | (lane << 2);
+    }
+    wave_sync();
 
     // ---- flush: one 128-byte unit (a whole cache line / HBM burst pair) per ready row, 8 lanes per row.
     // A round produces <= 64 bytes per row, so about half the rows are ready in any round: the owners
@@ -376,16 +402,10 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
             }
         }
     };
-    uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0;
-    bool pending = false;
     int any = 1;
     while (any) {
         const uint32_t n_ready = publish(false);
         wave_sync();
-        const bool req = have && !pending;
-        const uint32_t loff = req ? src_rel - 32u * wp : kBufOff;
-        const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, loff, 0, 0);
-        const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, loff - 16u, 0, 0);
         flush(n_ready);
         wave_sync();
         if (static_cast<uint32_t>(wa - orow) >= kUnit) {   // the flush above took this row's first unit: < 64 bytes stay
@@ -411,25 +431,10 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         // d = words between the oldest ring slot and the cursor; staged past the cursor = 16 - d;
         // 8 words fit once d >= 8.  A round uses <= 6 words + 2 of look-ahead, and d >= 8 whenever
         // fewer than 9 are staged, so the cursor never outruns the ring.
-        if (req) {
-            p0 = make_uint4(t0[0], t0[1], t0[2], t0[3]);
-            p1 = make_uint4(t1[0], t1[1], t1[2], t1[3]);
-            pending = true;
-        }
-        const uint32_t rp_mod = ((L.ra >> 8) - 2u) & 15u;
-        const uint32_t d = (rp_mod - 8u * wp) & 15u;
-        if (pending && d >= 8u && !(dbg & 32u)) {
-            uint32_t *r = reinterpret_cast<uint32_t *>(s_ring) + lane + ((8 * wp) & (kRingWords - 1)) * 64;
-            r[0 * 64] = p0.w;
-            r[1 * 64] = p0.z;
-            r[2 * 64] = p0.y;
-            r[3 * 64] = p0.x;
-            r[4 * 64] = p1.w;
-            r[5 * 64] = p1.z;
-            r[6 * 64] = p1.y;
-            r[7 * 64] = p1.x;
-            wp++;
-            pending = false;
+        {
+            const uint32_t rp_mod = ((L.ra >> 8) - 2u) & 15u;
+            const uint32_t d = (rp_mod - 8u * wp) & 15u;
+            if (have && d >= 8u && !(dbg & 32u)) land_piece();
         }
         any = __any(rbase + static_cast<uint32_t>(wa - orow) < end_abs ? 1 : 0);
     }

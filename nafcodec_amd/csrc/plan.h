@@ -10,8 +10,8 @@ constexpr uint32_t kBlockMax = 128u << 10;   // zstd Block_Maximum_Size
 constexpr int kHufWave = 64;                 // one Huffman stream per lane, one wave per workgroup
 constexpr uint32_t kHufLdsEntries = 2048;    // 8-byte decode-table entries a wave task may stage in LDS
 constexpr uint32_t kHufTaskSpan = 1u << 30;   // a wave task's streams lie within this many bytes of input and of output
-constexpr uint32_t kSrcFrontPad = 256;       // bytes readable in front of any device source buffer
-constexpr uint32_t kSrcBackPad = 64;
+constexpr uint32_t kSrcFrontPad = 512;       // bytes readable in front of any device source buffer (k_huf_decode: ring look-ahead + whole lines)
+constexpr uint32_t kSrcBackPad = 256;        // ... and behind it (k_huf_decode reads whole 128-byte lines)
 
 // One Huffman-coded literal stream = one lane of k_huf_decode.
 struct alignas(16) HufStream {

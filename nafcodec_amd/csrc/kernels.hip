@@ -1153,14 +1153,12 @@ __global__ __launch_bounds__(256) void k_unpack4(const uint8_t *__restrict__ pac
 // (SURVEY App. D-1).  In global coordinates: for a masked run [s, e) let r be the record that
 // holds base e-1; it is lower-cased over [max(s, start_r), e) iff e < end_r.  spec_mask != 0
 // lower-cases the whole run instead.
-__device__ inline uint32_t lower4(uint32_t w, uint32_t byte_mask) {
-    uint32_t r = w;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t c = (w >> (8 * k)) & 0xFFu;
-        if (((byte_mask >> k) & 1u) && c - 'A' < 26u) r |= 0x20u << (8 * k);
-    }
-    return r;
+// make_ascii_lowercase on four bytes at once: bytes in 'A'..'Z' get bit 5 set, everything else
+// (including bytes >= 0x80) stays
+__device__ inline uint32_t lower4(uint32_t w) {
+    const uint32_t w7 = w & 0x7F7F7F7Fu;
+    const uint32_t up = (w7 + 0x3F3F3F3Fu) & ~(w7 + 0x25252525u) & ~w & 0x80808080u;
+    return w | (up >> 2);
 }
 
 __global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_bases, uint64_t lo_clamp, uint64_t hi_clamp,
@@ -1169,12 +1167,19 @@ __global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_b
                                                     const ScanTotals *rec_totals, int spec_mask, const uint32_t *status) {
     // A workgroup takes 256 consecutive masked runs.  Phase 1: one run per thread -- clamp it and
     // (reference behaviour) find the record that holds its last base with a binary search, 256
-    // searches in flight at once.  Phase 2: each wave lower-cases its 64 runs, all lanes on one run.
+    // searches in flight at once.  Phase 2: the runs are cut into 16-byte aligned chunks, an exclusive
+    // prefix sum of the chunk counts turns (run, chunk) into one flat index, and the 256 threads sweep
+    // that index space -- consecutive threads on consecutive 16 bytes, whatever the run lengths.
+    // Chunks inside a run are rewritten as one uint4; the (at most two) chunks a run shares with its
+    // neighbours are done byte-wise, so no thread ever writes a byte outside its own run.
     __shared__ uint64_t s_lo[256], s_hi[256];
+    __shared__ uint64_t s_pre[2][257];                      // chunk-count prefix sums (ping-pong for the scan)
     const uint32_t abort_now = status[0];                  // same word for every thread of the launch
     const uint64_t n_runs = mask_totals->count;
     const uint64_t n_rec = rec_totals->count;
     const uint32_t tid = threadIdx.x;
+    const uint64_t skew = reinterpret_cast<uintptr_t>(ascii) & 15;   // a shard's base pointer need not be 16-byte aligned
+    uint8_t *const abase = ascii - skew;
     for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * 256; 2 * base + 1 < n_runs && !abort_now;
          base += static_cast<uint64_t>(gridDim.x) * 256) {
         const uint64_t k = 2 * (base + tid) + 1;           // odd runs are the masked ones
@@ -1185,9 +1190,9 @@ __global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_b
             if (s >= n_bases) {
                 s = e = 0;
             } else if (e > n_bases) {                      // MaskReader stops at `total`: the overshoot is never applied
-                e = spec_mask ? n_bases : s;
+                e = (spec_mask & 0xFF) ? n_bases : s;
             }
-            if (e > s && !spec_mask) {
+            if (e > s && !(spec_mask & 0x2FF)) {
                 uint64_t lo = 0, hi = n_rec;               // first record whose end is > e - 1
                 while (lo < hi) {
                     const uint64_t mid = (lo + hi) >> 1;
@@ -1215,25 +1220,62 @@ __global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_b
         __syncthreads();                                   // previous round's readers are done
         s_lo[tid] = s;
         s_hi[tid] = e;
+        s_pre[0][tid + 1] = e > s ? ((e + skew + 15) >> 4) - ((s + skew) >> 4) : 0;
+        if (tid == 0) s_pre[0][0] = s_pre[1][0] = 0;
         __syncthreads();
-        const uint32_t lane = tid & 63, w = tid >> 6;
-        uint32_t *words = reinterpret_cast<uint32_t *>(ascii);
-        for (uint32_t r = 0; r < 64; r++) {
-            const uint64_t lo = s_lo[w * 64 + r], hi = s_hi[w * 64 + r];
-            if (hi <= lo) continue;
-            const uint64_t w0 = lo >> 2, w1 = (hi + 3) >> 2;
-            for (uint64_t x = w0 + lane; x < w1; x += 64) {
-                uint32_t bm = 0xFu;
-                if (x == w0) bm &= 0xFu << (lo & 3);
-                if (x == w1 - 1 && (hi & 3)) bm &= 0xFu >> (4 - (hi & 3));
-                if (bm == 0xFu) {
-                    words[x] = lower4(words[x], 0xFu);
-                } else {                                   // edge dword: touch only our bytes (neighbours belong to other waves)
-                    for (uint32_t b = 0; b < 4; b++)
-                        if ((bm >> b) & 1u) {
-                            const uint8_t c = ascii[4 * x + b];
-                            if (static_cast<uint32_t>(c) - 'A' < 26u) ascii[4 * x + b] = c | 0x20;
-                        }
+        uint32_t cur = 0;
+        for (uint32_t d = 1; d < 256; d <<= 1) {           // inclusive scan of entries 1..256
+            const uint64_t v = s_pre[cur][tid + 1] + (tid >= d ? s_pre[cur][tid + 1 - d] : 0);
+            s_pre[cur ^ 1][tid + 1] = v;
+            cur ^= 1;
+            __syncthreads();
+        }
+        const uint64_t *pre = s_pre[cur];                  // pre[r] = chunks of runs 0..r-1
+        const uint64_t total = (spec_mask & 0x100) ? 0 : pre[256];
+        // four chunks per thread and step: the loads of all four are in flight before the first store
+        for (uint64_t c0 = tid; c0 < total; c0 += 4 * 256) {
+            uint64_t addr[4], e0[4], e1[4];
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint64_t c = c0 + 256 * u;
+                uint32_t lo = 0, hi = 256;                 // largest r with pre[r] <= c
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (pre[mid] <= c)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                // in coordinates whose multiples of 16 are aligned addresses
+                const uint64_t rs = s_lo[lo] + skew, re = s_hi[lo] + skew;
+                const uint64_t a = ((rs >> 4) + (c - pre[lo])) << 4;
+                addr[u] = a;
+                e0[u] = a > rs ? a : rs;
+                e1[u] = a + 16 < re ? a + 16 : re;
+                if (c >= total) e0[u] = e1[u] = a;         // past the end: nothing to do
+                if (e1[u] > e0[u]) v[u] = *reinterpret_cast<const uint4 *>(abase + a);   // whole aligned chunk: inside the buffer's padding at worst
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (e1[u] - e0[u] == 16) {
+                    v[u].x = lower4(v[u].x);
+                    v[u].y = lower4(v[u].y);
+                    v[u].z = lower4(v[u].z);
+                    v[u].w = lower4(v[u].w);
+                    *reinterpret_cast<uint4 *>(abase + addr[u]) = v[u];
+                } else if (e1[u] > e0[u]) {
+                    // a chunk shared with the neighbours (unmasked bases, or another masked run that some other
+                    // thread is rewriting right now): set bit 5 of OUR upper-case bytes with one atomic OR per
+                    // dword -- no byte loops (a wave would wait for its slowest lane), no lost updates
+                    const uint32_t in_range = ((1u << (e1[u] - addr[u])) - 1u) & ~((1u << (e0[u] - addr[u])) - 1u);   // 16 bits
+                    const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        const uint32_t sel = (((in_range >> (4 * d)) & 0xFu) * 0x00204081u & 0x01010101u) * 0xFFu;
+                        const uint32_t m = (lower4(w[d]) ^ w[d]) & sel;
+                        if (m) atomicOr(reinterpret_cast<uint32_t *>(abase + addr[u]) + d, m);
+                    }
                 }
             }
         }
@@ -1425,8 +1467,12 @@ void launch_mask_apply(hipStream_t stream, uint8_t *ascii, uint64_t n_bases, uin
     uint64_t blocks = (masked_runs + 255) / 256;
     if (blocks > 256u * 8u) blocks = 256u * 8u;
     if (blocks == 0) blocks = 1;
+    static const int dbg = [] {                          // timing ablations only; results are wrong when set
+        const char *e = std::getenv("NAFGPU_MASK_DEBUG");
+        return e ? std::atoi(e) : 0;
+    }();
     hipLaunchKernelGGL(k_mask_apply, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, ascii, n_bases, lo_clamp,
-                       hi_clamp, mask_ends, mask_totals, rec_ends, rec_totals, spec_mask, status);
+                       hi_clamp, mask_ends, mask_totals, rec_ends, rec_totals, spec_mask | (dbg << 8), status);
 }
 
 void launch_hash64(hipStream_t stream, const uint8_t *p, uint64_t n, uint64_t first_chunk, unsigned long long *result) {

@@ -72,6 +72,12 @@ inline T atomicSub(T *p, T v) {
     return old;
 }
 template <class T>
+inline T atomicOr(T *p, T v) {
+    T old = *p;
+    *p = old | v;
+    return old;
+}
+template <class T>
 inline T atomicAdd(T *p, T v) {
     T old = *p;
     *p = old + v;

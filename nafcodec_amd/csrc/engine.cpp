@@ -164,6 +164,8 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
               d_mdst_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(uint64_t) + 16) &&
               d_flags_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(uint32_t) + 16) &&
               d_rep_final_.alloc(n_seq_blocks_ * 12 + 16) && d_rep_init_.alloc(n_seq_blocks_ * 12 + 16) &&
+              d_rep_scratch_.alloc((n_seq_blocks_ / 64 + 1) * 24 + 16) &&
+              d_lz_index_.alloc(n_seq_blocks_ && plan_.n_sequences < 0xFFFFFFFFull ? ((static_cast<size_t>(expect_size) >> 7) + 2) * 4 : 0) &&
               d_blk_pending_.alloc(n_seq_blocks_ * 4 + 16) &&
               d_roff_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(uint32_t) + 16) && d_counters_.alloc(64);
     if (!ok) return Failure::make(NAFGPU_E_DEVICE, "out of device memory while preparing a section");
@@ -225,6 +227,15 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer) {
         la.blk_base = d_blk_base_.as<uint64_t>();
         la.rep_final = d_rep_final_.as<uint32_t>();
         la.rep_init = d_rep_init_.as<uint32_t>();
+        la.rep_scratch = d_rep_scratch_.as<uint32_t>();
+        // the pending lists are an accelerator: without memory for them every pass walks the blocks
+        const size_t list_bytes = static_cast<size_t>(plan_.n_sequences) * sizeof(uint64_t) + 16;
+        const bool lists = plan_.n_sequences < (1ull << 40) && n_seq_blocks_ < (1ull << 24) && d_lz_list_[0].alloc(list_bytes) &&
+                           d_lz_list_[1].alloc(list_bytes);
+        la.plist[0] = lists ? d_lz_list_[0].as<uint64_t>() : nullptr;
+        la.plist[1] = lists ? d_lz_list_[1].as<uint64_t>() : nullptr;
+        la.cidx = plan_.n_sequences < 0xFFFFFFFFull ? d_lz_index_.as<uint32_t>() : nullptr;
+        la.n_idx_chunks = (static_cast<uint64_t>(expect_) >> 7) + 2;
         la.mdst = d_mdst_.as<uint64_t>();
         la.flags = d_flags_.as<uint32_t>();
         la.blk_pending = d_blk_pending_.as<uint32_t>();

@@ -57,11 +57,15 @@ struct LzArgs {
     const uint64_t *blk_base;
     const uint32_t *rep_final;   // 3 per block, from k_seq_decode
     uint32_t *rep_init;          // 3 per block
+    uint32_t *rep_scratch;       // 6 words per chunk of 64 blocks (k_rep_partial / k_rep_scan)
+    uint32_t *cidx;              // sequence index per 128 output elements (null: plain binary search)
+    uint64_t n_idx_chunks;       // entries of cidx
     uint64_t *mdst;              // per sequence: output position of its match
     uint32_t *flags;             // per sequence: pass in which its match was completed (0 = pending)
     uint32_t *blk_pending;       // per block: matches still pending
     uint32_t *roff;              // per sequence: resolved offset of a match that is still pending
-    unsigned long long *counters;// [0] matches still pending after the passes, [1] length of the pending list
+    uint64_t *plist[2];          // two lists of pending matches (n_sequences entries each; null: block-wise passes only)
+    unsigned long long *counters;// [0] matches still pending after the passes, [1] pointer-jumping list length, [2] its flag, [4] [5] pending-list lengths
     uint8_t *out;
     uint32_t t_char;
     uint32_t *status;

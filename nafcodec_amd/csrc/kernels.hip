@@ -5,7 +5,7 @@
 //   k_seq_decode   K2  FSE sequence decode (LL / OF / ML)                     lane = block
 //   k_scan_*       K3/K6  tile scans: block bases, record ends, mask run ends
 //   k_copy_fill        Raw / RLE blocks and literal sections
-//   k_rep_chain / k_lz_literals / k_lz_match_pass / k_lz_matches_ordered   K4
+//   k_rep_partial/scan/apply, k_lz_literals, k_lz_index, k_lz_match_pass, k_lz_matches_ordered   K4
 //   k_unpack4      K5  4-bit -> IUPAC ASCII (reader.rs:121-172)
 //   k_mask_apply       soft-mask lower-casing incl. the record-end rule (mod.rs:402-441)
 //   k_hash64           checksum used by full-size parity tests
@@ -748,7 +748,8 @@ __global__ __launch_bounds__(256) void k_copy_fill(const uint8_t *__restrict__ s
 // ======================================================================================
 // K4  LZ77 execution (App. B "Repeat offsets" + "Execute")
 // ======================================================================================
-//   k_rep_chain      one thread: block b's initial repeat offsets from block b-1's final tokens
+//   k_rep_partial / k_rep_scan / k_rep_apply   block b's initial repeat offsets from its predecessors' final tokens
+//   k_lz_index       first sequence at or after every 128th output element (starting point of lz_range_final)
 //   k_lz_literals    every literal run to its final position; no dependencies; workgroup per block
 //   k_lz_match_pass  run several times: every pending match whose source bytes are all final
 //                    (literals, or matches completed in an EARLIER pass) is copied; matches are
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(256) void k_copy_fill(const uint8_t *__restrict__ s
 // match of `ml` packed bytes at distance `off` copies ml 16-bit elements at distance off, and
 // literals are expanded while they are scattered.  The ASCII buffer itself is the LZ window.
 constexpr uint32_t kLzShort = 48;        // runs up to this many elements are copied by their own thread
-constexpr uint32_t kLzPasses = 8;
+constexpr uint32_t kLzPasses = 64;       // at most; the first walks every block, the others the list of what is still pending
 
 __device__ inline uint32_t rep_resolve(uint32_t tok, const uint32_t *init, bool *bad) {
     if (!(tok & kRepToken)) return tok;
@@ -772,13 +773,89 @@ __device__ inline uint32_t rep_resolve(uint32_t tok, const uint32_t *init, bool 
     return base - d;
 }
 
-__global__ void k_rep_chain(const SeqBlock *__restrict__ blocks, uint32_t n_blocks, const uint32_t *__restrict__ rep_final,
-                            uint32_t *rep_init, uint32_t *status) {
+// A block maps the three repeat offsets it inherits to the three it leaves behind; k_seq_decode
+// recorded that map symbolically: each outgoing offset is a value, or "incoming rep[slot] - d".
+// Such maps compose (rep_resolve is "apply entry `tok` after the map `f`", whether f is concrete or
+// symbolic), so the chain over all blocks is done in three steps instead of one serial walk:
+//   k_rep_partial  thread t composes the maps of blocks [C t, C t + C)          (C = kRepChunk)
+//   k_rep_scan     one thread applies the chunk maps in order: the triple each chunk starts from
+//   k_rep_apply    thread t walks its C blocks from that triple and writes every block's initial triple
+// Repeat offsets restart at {1, 4, 8} with each frame.
+constexpr uint32_t kRepChunk = 64;
+
+__device__ inline uint32_t rep_apply_entry(uint32_t tok, const uint32_t *f, bool *bad) {
+    if (!(tok & kRepToken)) return tok;
+    const uint32_t fv = f[(tok >> 24) & 3u], d = tok & 0xFFFFFFu;
+    if (!(fv & kRepToken)) {
+        if (fv <= d) {
+            *bad = true;
+            return 1;
+        }
+        return fv - d;
+    }
+    const uint32_t d2 = (fv & 0xFFFFFFu) + d;
+    if (d2 > 0xFFFFFFu) *bad = true;
+    return (fv & 0xFF000000u) | (d2 & 0xFFFFFFu);
+}
+
+__global__ __launch_bounds__(256) void k_rep_partial(const SeqBlock *__restrict__ blocks, uint32_t n_blocks,
+                                                     const uint32_t *__restrict__ rep_final, uint32_t *partial, uint32_t *status) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t b0 = t * kRepChunk;
+    if (status[0] != 0 || b0 >= n_blocks) return;
+    const uint32_t b1 = b0 + kRepChunk < n_blocks ? b0 + kRepChunk : n_blocks;
+    uint32_t cur[3] = {kRepToken | (0u << 24), kRepToken | (1u << 24), kRepToken | (2u << 24)};   // identity
+    uint32_t frame = b0 ? blocks[b0 - 1].frame_first_blk : 0xFFFFFFFFu;
+    bool bad = false;
+    for (uint32_t b = b0; b < b1; b++) {
+        if (blocks[b].frame_first_blk != frame) {
+            frame = blocks[b].frame_first_blk;
+            cur[0] = 1;
+            cur[1] = 4;
+            cur[2] = 8;
+        }
+        const uint32_t n0 = rep_apply_entry(rep_final[3 * b + 0], cur, &bad);
+        const uint32_t n1 = rep_apply_entry(rep_final[3 * b + 1], cur, &bad);
+        const uint32_t n2 = rep_apply_entry(rep_final[3 * b + 2], cur, &bad);
+        cur[0] = n0;
+        cur[1] = n1;
+        cur[2] = n2;
+    }
+    partial[3 * t + 0] = cur[0];
+    partial[3 * t + 1] = cur[1];
+    partial[3 * t + 2] = cur[2];
+    if (bad) flag_error(status, kStBadOffset, 0xFFFFFFFEu);
+}
+
+__global__ void k_rep_scan(uint32_t n_chunks, const uint32_t *__restrict__ partial, uint32_t *chunk_init, uint32_t *status) {
     if (status[0] != 0 || blockIdx.x != 0 || threadIdx.x != 0) return;
     uint32_t cur[3] = {1, 4, 8};
-    uint32_t frame = 0xFFFFFFFFu;
     bool bad = false;
-    for (uint32_t b = 0; b < n_blocks; b++) {
+    for (uint32_t t = 0; t < n_chunks; t++) {
+        chunk_init[3 * t + 0] = cur[0];
+        chunk_init[3 * t + 1] = cur[1];
+        chunk_init[3 * t + 2] = cur[2];
+        const uint32_t n0 = rep_apply_entry(partial[3 * t + 0], cur, &bad);
+        const uint32_t n1 = rep_apply_entry(partial[3 * t + 1], cur, &bad);
+        const uint32_t n2 = rep_apply_entry(partial[3 * t + 2], cur, &bad);
+        cur[0] = n0;
+        cur[1] = n1;
+        cur[2] = n2;
+    }
+    if (bad) flag_error(status, kStBadOffset, 0xFFFFFFFEu);
+}
+
+__global__ __launch_bounds__(256) void k_rep_apply(const SeqBlock *__restrict__ blocks, uint32_t n_blocks,
+                                                   const uint32_t *__restrict__ rep_final, const uint32_t *__restrict__ chunk_init,
+                                                   uint32_t *rep_init, uint32_t *status) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t b0 = t * kRepChunk;
+    if (status[0] != 0 || b0 >= n_blocks) return;
+    const uint32_t b1 = b0 + kRepChunk < n_blocks ? b0 + kRepChunk : n_blocks;
+    uint32_t cur[3] = {chunk_init[3 * t], chunk_init[3 * t + 1], chunk_init[3 * t + 2]};
+    uint32_t frame = b0 ? blocks[b0 - 1].frame_first_blk : 0xFFFFFFFFu;
+    bool bad = false;
+    for (uint32_t b = b0; b < b1; b++) {
         if (blocks[b].frame_first_blk != frame) {        // repeat offsets restart with each frame
             frame = blocks[b].frame_first_blk;
             cur[0] = 1;
@@ -843,21 +920,49 @@ __global__ __launch_bounds__(256) void k_lz_literals(const SeqBlock *__restrict_
     for (uint32_t k = tid; k < sb.lit_size - lused; k += 256) put(out + oend + k, blit[lused + k]);
 }
 
+// cidx[c] = first sequence whose match starts at or after output element c << kLzIdxShift: where the
+// search for "who wrote this source range" starts (one load instead of a binary search over all
+// sequences per pending match and pass)
+constexpr uint32_t kLzIdxShift = 7;
+
+__global__ __launch_bounds__(256) void k_lz_index(const uint64_t *__restrict__ mdst, uint64_t n_seq, uint64_t n_chunks, uint32_t *cidx,
+                                                  const uint32_t *status) {
+    if (status[0] != 0) return;
+    for (uint64_t c = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; c < n_chunks; c += static_cast<uint64_t>(gridDim.x) * 256) {
+        const uint64_t target = c << kLzIdxShift;
+        uint64_t a = 0, b = n_seq;                        // first g with mdst[g] >= target
+        while (a < b) {
+            const uint64_t mid = (a + b) >> 1;
+            if (mdst[mid] < target)
+                a = mid + 1;
+            else
+                b = mid;
+        }
+        cidx[c] = static_cast<uint32_t>(a);
+    }
+}
+
 // Are all output bytes in [lo, hi) final for a reader in pass `pass`?  Bytes that no match writes
 // are literals (final since k_lz_literals / K1); bytes of match g are final once flags[g] holds an
 // earlier pass number.  mdst[] (match start positions) is sorted: sequences are stored in frame order.
 __device__ inline bool lz_range_final(uint64_t lo, uint64_t hi, const uint64_t *mdst, const Seq *seqs, const uint32_t *flags,
-                                      uint64_t g_self, uint32_t pass) {
+                                      const uint32_t *cidx, uint64_t g_self, uint32_t pass) {
     if (hi <= lo) return true;
-    uint64_t a = 0, b = g_self;                          // last g < g_self with mdst[g] <= lo
-    while (a < b) {
-        const uint64_t mid = (a + b) >> 1;
-        if (mdst[mid] <= lo)
-            a = mid + 1;
-        else
-            b = mid;
+    uint64_t g;
+    if (cidx) {                                          // the sequence before the first one of lo's chunk may reach into the range
+        const uint64_t f = cidx[lo >> kLzIdxShift];
+        g = f ? f - 1 : 0;
+    } else {
+        uint64_t a = 0, b = g_self;                      // last g < g_self with mdst[g] <= lo
+        while (a < b) {
+            const uint64_t mid = (a + b) >> 1;
+            if (mdst[mid] <= lo)
+                a = mid + 1;
+            else
+                b = mid;
+        }
+        g = a ? a - 1 : 0;
     }
-    uint64_t g = a ? a - 1 : 0;
     for (; g < g_self && mdst[g] < hi; g++) {
         if (mdst[g] + seqs[g].ml <= lo) continue;        // ends before the range
         const uint32_t f = flags[g];
@@ -869,14 +974,15 @@ __device__ inline bool lz_range_final(uint64_t lo, uint64_t hi, const uint64_t *
 template <bool ASCII>
 __global__ __launch_bounds__(256) void k_lz_match_pass(const SeqBlock *__restrict__ blocks, uint32_t n_blocks,
                                                        const Seq *__restrict__ seqs, const uint64_t *__restrict__ mdst,
-                                                       uint32_t *flags, uint32_t *blk_pending, uint32_t *roff,
-                                                       unsigned long long *remaining, const uint32_t *__restrict__ rep_init,
+                                                       const uint32_t *__restrict__ cidx, uint32_t *flags, uint32_t *blk_pending,
+                                                       uint32_t *roff, unsigned long long *remaining, const uint32_t *__restrict__ rep_init,
                                                        const uint64_t *__restrict__ blk_base, uint8_t *out_bytes, uint32_t pass,
-                                                       uint32_t *status) {
+                                                       uint64_t *plist, unsigned long long *pcount, uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
     __shared__ uint32_t s_long[256];
-    __shared__ uint32_t s_nlong, s_ndone, s_abort, s_pending;
+    __shared__ uint32_t s_nlong, s_ndone, s_abort, s_pending, s_npend;
+    __shared__ unsigned long long s_pbase;
     const uint32_t tid = threadIdx.x;
     if (tid == 0) s_abort = status[0];
     __syncthreads();
@@ -894,9 +1000,11 @@ __global__ __launch_bounds__(256) void k_lz_match_pass(const SeqBlock *__restric
             if (tid == 0) {
                 s_nlong = 0;
                 s_ndone = 0;
+                s_npend = 0;
             }
             __syncthreads();
             const uint64_t g = sb.seq_first + s0 + tid;
+            uint32_t my_slot = 0xFFFFFFFFu;                      // position in this step's part of the pending list
             if (s0 + tid < sb.n_seq && flags[g] == 0) {
                 const Seq q = seqs[g];
                 bool bad = false;
@@ -910,7 +1018,7 @@ __global__ __launch_bounds__(256) void k_lz_match_pass(const SeqBlock *__restric
                     const uint64_t src = mpos - off;
                     const uint64_t need_hi = src + q.ml < mpos ? src + q.ml : mpos;   // the rest is the match itself
                     roff[g] = off;                               // kept for the pointer-jumping stage
-                    if (lz_range_final(src, need_hi, mdst, seqs, flags, g, pass)) {
+                    if (lz_range_final(src, need_hi, mdst, seqs, flags, cidx, g, pass)) {
                         if (q.ml <= kLzShort) {
                             Elem *d = out + mpos;
                             const Elem *s = out + src;
@@ -920,6 +1028,8 @@ __global__ __launch_bounds__(256) void k_lz_match_pass(const SeqBlock *__restric
                         } else {
                             s_long[atomicAdd(&s_nlong, 1u)] = s0 + tid;
                         }
+                    } else if (plist) {
+                        my_slot = atomicAdd(&s_npend, 1u);       // stays pending: goes on the list the later passes work from
                     }
                 }
             }
@@ -944,8 +1054,108 @@ __global__ __launch_bounds__(256) void k_lz_match_pass(const SeqBlock *__restric
                 atomicSub(&blk_pending[b], s_ndone + nl);
                 atomicAdd(remaining, ~static_cast<unsigned long long>(s_ndone + nl) + 1ull);   // -= done
             }
+            if (tid == 0 && s_npend) s_pbase = atomicAdd(pcount, static_cast<unsigned long long>(s_npend));
             __syncthreads();
+            if (my_slot != 0xFFFFFFFFu) plist[s_pbase + my_slot] = (static_cast<uint64_t>(b) << 40) | g;
         }
+    }
+}
+
+// Between two list passes: empty the list the next pass appends to, and stop the passes (counters[6])
+// once nothing is pending or a pass has resolved less than 3 % of what it was given.  A list pass
+// costs what is pending, so chains a few dozen links deep (quality strings) are cheaper to walk link
+// by link than to hand to the pointer-jumping stage, which is for chains as long as the frame.
+__global__ void k_lz_pass_ctl(unsigned long long *counters, uint32_t in, uint32_t out, uint32_t pass) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const unsigned long long now = counters[4 + in];       // pending before the coming pass
+    const unsigned long long before = counters[7];         // pending before the previous pass
+    if (pass >= 3 && now * 200 > before * 199) counters[6] = 1;
+    if (now == 0) counters[6] = 1;
+    counters[7] = now;
+    counters[4 + out] = 0;
+}
+
+// Passes after the first work from the list of matches that are still pending (entry = seq-block
+// index << 40 | sequence index) instead of re-reading every sequence of every unfinished block: a
+// pass costs what is left, not what there was.  Survivors go to the next pass's list.
+template <bool ASCII>
+__global__ __launch_bounds__(256) void k_lz_match_list(const uint64_t *__restrict__ lin, const unsigned long long *__restrict__ nin,
+                                                       uint64_t *lout, unsigned long long *nout, const Seq *__restrict__ seqs,
+                                                       const uint64_t *__restrict__ mdst, const uint32_t *__restrict__ cidx,
+                                                       uint32_t *flags, uint32_t *blk_pending, const uint32_t *__restrict__ roff,
+                                                       unsigned long long *remaining, const unsigned long long *stop,
+                                                       uint8_t *out_bytes, uint32_t pass, const uint32_t *status) {
+    using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
+    Elem *out = reinterpret_cast<Elem *>(out_bytes);
+    __shared__ uint32_t s_long[256];
+    __shared__ uint64_t s_ent[256];
+    __shared__ uint32_t s_nlong, s_ndone, s_abort, s_npend;
+    __shared__ unsigned long long s_pbase;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_abort = status[0] | static_cast<uint32_t>(stop[0]);
+    __syncthreads();
+    if (s_abort) return;
+    const unsigned long long n = *nin;
+    for (unsigned long long base = static_cast<unsigned long long>(blockIdx.x) * 256; base < n;
+         base += static_cast<unsigned long long>(gridDim.x) * 256) {
+        if (tid == 0) {
+            s_nlong = 0;
+            s_ndone = 0;
+            s_npend = 0;
+        }
+        __syncthreads();
+        uint32_t my_slot = 0xFFFFFFFFu;
+        uint64_t ent = 0;
+        if (base + tid < n) {
+            ent = lin[base + tid];
+            s_ent[tid] = ent;
+            const uint64_t g = ent & ((1ull << 40) - 1ull);
+            const Seq q = seqs[g];
+            const uint32_t off = roff[g];                        // resolved in the first pass
+            const uint64_t mpos = mdst[g];
+            const uint64_t src = mpos - off;
+            const uint64_t need_hi = src + q.ml < mpos ? src + q.ml : mpos;
+            if (lz_range_final(src, need_hi, mdst, seqs, flags, cidx, g, pass)) {
+                if (q.ml <= kLzShort) {
+                    Elem *d = out + mpos;
+                    const Elem *sp = out + src;
+                    for (uint32_t k = 0; k < q.ml; k++) d[k] = sp[k];   // element-serial: overlap allowed
+                    flags[g] = pass;
+                    atomicSub(&blk_pending[ent >> 40], 1u);
+                    atomicAdd(&s_ndone, 1u);
+                } else {
+                    s_long[atomicAdd(&s_nlong, 1u)] = tid;
+                }
+            } else {
+                my_slot = atomicAdd(&s_npend, 1u);
+            }
+        }
+        __syncthreads();
+        const uint32_t nl = s_nlong;
+        for (uint32_t j = 0; j < nl; j++) {                      // long matches: the whole workgroup on each
+            const uint64_t e = s_ent[s_long[j]];
+            const uint64_t gi = e & ((1ull << 40) - 1ull);
+            const Seq q = seqs[gi];
+            const uint32_t off = roff[gi];
+            Elem *d = out + mdst[gi];
+            const Elem *sp = d - off;
+            if (off >= q.ml) {
+                for (uint32_t k = tid; k < q.ml; k += 256) d[k] = sp[k];
+            } else {
+                for (uint32_t k = tid; k < q.ml; k += 256) d[k] = sp[k % off];   // overlapping: periodic
+            }
+            if (tid == 0) {
+                flags[gi] = pass;
+                atomicSub(&blk_pending[e >> 40], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (s_ndone + nl) atomicAdd(remaining, ~static_cast<unsigned long long>(s_ndone + nl) + 1ull);   // -= done
+            if (s_npend) s_pbase = atomicAdd(nout, static_cast<unsigned long long>(s_npend));
+        }
+        __syncthreads();
+        if (my_slot != 0xFFFFFFFFu) lout[s_pbase + my_slot] = ent;
     }
 }
 
@@ -1392,20 +1602,50 @@ void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *ta
 
 template <bool ASCII>
 static void lz_execute(hipStream_t stream, const LzArgs &a) {
-    hipLaunchKernelGGL(k_rep_chain, dim3(1), dim3(1), 0, stream, a.blocks, a.n_blocks, a.rep_final, a.rep_init, a.status);
+    const uint32_t n_chunks = (a.n_blocks + kRepChunk - 1) / kRepChunk;
+    uint32_t *partial = a.rep_scratch, *chunk_init = a.rep_scratch + 3 * static_cast<size_t>(n_chunks);
+    hipLaunchKernelGGL(k_rep_partial, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, a.blocks, a.n_blocks, a.rep_final, partial,
+                       a.status);
+    hipLaunchKernelGGL(k_rep_scan, dim3(1), dim3(1), 0, stream, n_chunks, partial, chunk_init, a.status);
+    hipLaunchKernelGGL(k_rep_apply, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, a.blocks, a.n_blocks, a.rep_final,
+                       chunk_init, a.rep_init, a.status);
     hipLaunchKernelGGL(k_lz_literals<ASCII>, dim3(a.n_blocks), dim3(256), 0, stream, a.blocks, a.seqs, a.lit, a.blk_base,
                        a.mdst, a.blk_pending, a.out, a.t_char, a.status);
+    if (a.cidx) {
+        uint64_t ib = (a.n_idx_chunks + 255) / 256;
+        if (ib > 256u * 16u) ib = 256u * 16u;
+        hipLaunchKernelGGL(k_lz_index, dim3(static_cast<uint32_t>(ib)), dim3(256), 0, stream, a.mdst, a.n_sequences, a.n_idx_chunks,
+                           a.cidx, a.status);
+    }
     const uint32_t grid = a.n_blocks < 256u * 8u ? a.n_blocks : 256u * 8u;
-    for (uint32_t pass = 1; pass <= kLzPasses; pass++)
-        hipLaunchKernelGGL(k_lz_match_pass<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.mdst,
-                           a.flags, a.blk_pending, a.roff, a.counters, a.rep_init, a.blk_base, a.out, pass, a.status);
+    if (!a.plist[0] || !a.plist[1]) {                      // no memory for the pending lists: every pass walks the blocks
+        for (uint32_t pass = 1; pass <= kLzPasses; pass++)
+            hipLaunchKernelGGL(k_lz_match_pass<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.mdst,
+                               a.cidx, a.flags, a.blk_pending, a.roff, a.counters, a.rep_init, a.blk_base, a.out, pass, nullptr,
+                               nullptr, a.status);
+        return;
+    }
+    unsigned long long *cnt = a.counters + 4;              // lengths of the two pending lists
+    hipLaunchKernelGGL(k_lz_match_pass<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.mdst, a.cidx,
+                       a.flags, a.blk_pending, a.roff, a.counters, a.rep_init, a.blk_base, a.out, 1u, a.plist[0], cnt + 0, a.status);
+    uint64_t lgrid = (a.n_sequences + 255) / 256;
+    if (lgrid > 256u * 8u) lgrid = 256u * 8u;
+    for (uint32_t pass = 2; pass <= kLzPasses; pass++) {
+        const uint32_t in = pass & 1u, ol = in ^ 1u;       // pass 2 reads list 0 and writes list 1, pass 3 the other way round
+        hipLaunchKernelGGL(k_lz_pass_ctl, dim3(1), dim3(1), 0, stream, a.counters, in, ol, pass);
+        hipLaunchKernelGGL(k_lz_match_list<ASCII>, dim3(static_cast<uint32_t>(lgrid)), dim3(256), 0, stream, a.plist[in], cnt + in,
+                           a.plist[ol], cnt + ol, a.seqs, a.mdst, a.cidx, a.flags,
+                           a.blk_pending, a.roff, a.counters, a.counters + 6, a.out, pass, a.status);
+    }
 }
 
 void launch_lz_execute(hipStream_t stream, const LzArgs &a, bool ascii) {
     if (!a.n_blocks) return;
     (void)hipMemsetAsync(a.flags, 0, a.n_sequences * sizeof(uint32_t), stream);
-    const unsigned long long init[2] = {a.n_sequences, 0ull};          // remaining matches, pending-list length
-    (void)hipMemcpyAsync(a.counters, init, sizeof init, hipMemcpyHostToDevice, stream);
+    // remaining matches, pointer-jumping list length, [2] its `changed` flag, [4] [5] lengths of the two pending lists
+    static const unsigned long long zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyAsync(a.counters, zeros, sizeof zeros, hipMemcpyHostToDevice, stream);
+    (void)hipMemcpyAsync(a.counters, &a.n_sequences, sizeof(unsigned long long), hipMemcpyHostToDevice, stream);
     if (ascii)
         lz_execute<true>(stream, a);
     else

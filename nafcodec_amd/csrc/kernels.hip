@@ -30,9 +30,9 @@ __device__ inline void flag_error(uint32_t *status, uint32_t code, uint32_t deta
 // ======================================================================================
 // K1  Huffman literal streams
 // ======================================================================================
-// One wave per task, one lane per stream.  Measured on MI355X the kernel is bound
-// by VALU issue and by the length of the per-look-up dependency chain, so the design minimises
-// vector instructions per decoded byte:
+// One wave per task, one lane per stream.  What bounds it on MI355X, in this order:
+// the HBM request pattern (610 k scattered input and output fronts), LDS capacity (which caps the
+// waves per CU) and the dependent chain of one look-up.  Hence:
 //   * two-symbol table with the OUTPUT baked in: while a task's Huffman tables are staged into
 //     LDS they are widened to W = max(max_bits, 8) index bits; a 64-bit entry holds the bytes to
 //     emit for the next one or two symbols (for DNA/RNA: the 2 x 2 IUPAC characters of the two
@@ -42,19 +42,18 @@ __device__ inline void flag_error(uint32_t *status, uint32_t code, uint32_t deta
 //   * bit window: {hi, lo, nw} are three consecutive 32-bit words of the backward stream,
 //     s = 32 - (bits of hi consumed) in [0, 31]; peek = v_alignbit_b32(hi, lo, s); consuming len
 //     bits is s -= len, a borrow meaning "advance one word", s &= 31.
-//   * input ring: 16 words per lane in LDS, stored transposed (word x of lane l at x*64 + l: any
-//     mix of positions is bank-conflict free), refilled by the lane itself with 16-byte aligned
-//     global loads, one 32-byte pair in flight, serviced once per round of 16 look-ups.  Invariant
-//     (a look-up consumes <= 11 bits, so a round <= 6 words, + 2 words of look-ahead): >= 9
-//     staged words past the cursor after each service.
-//   * output: each lane appends to its own 128-byte row in LDS whose byte 0 is 64-byte aligned
-//     in the destination; look-ups store with constant offsets from a running write address (no
-//     wrap arithmetic).  Once per round the wave copies one complete 64-byte unit per ready row
-//     to HBM cooperatively -- 4 lanes per row, one aligned dwordx4 each, so a store instruction
-//     writes 16 whole 64-byte segments -- and the row's owner moves its leftover (< 64 B) down.
-//   * a round is [request next input pair] -> [flush previous round's output] -> [16 look-ups] ->
-//     [land the pair]: the loads are older than the round's stores in the in-order VM counter and
-//     have a whole round to arrive.
+//   * input: every lane keeps the current 128-byte line of its stream in 32 VGPRs and feeds a
+//     16-word ring in LDS from it (stored transposed, word x of lane l at x*64 + l: any mix of
+//     positions is bank-conflict free), one 32-byte piece per round at most.  Invariant (a look-up
+//     consumes <= 11 bits, so a round <= 6 words, + 2 words of look-ahead): >= 9 staged words past
+//     the cursor after each service.  Each line of compressed input is requested exactly once.
+//   * output: each lane appends to its own 192-byte row in LDS whose byte 0 is 128-byte aligned
+//     in the destination (one unaligned ds_write_b32 per look-up, no wrap arithmetic).  Once per
+//     round the rows holding a complete 128-byte unit are listed (ballot + rank) and written out
+//     eight rows per buffer_store_dwordx4, eight lanes per row: every store instruction writes
+//     eight whole lines.  The row's owner moves its leftover (< 64 B) down.
+//   * a round is [flush what earlier rounds completed] -> [16 look-ups] -> [land the next piece].
+// DESIGN.md section 4 has the measurements behind each of these choices.
 constexpr uint32_t kRingWords = 16;
 constexpr uint32_t kUnit = 128;          // output bytes flushed per row at a time: one whole 128-byte line
 constexpr uint32_t kOutPitch = 200;      // row pitch in bytes: kUnit + 64 used, 8-byte aligned rows, 50-dword stride (conflict-free b16 writes)
@@ -726,6 +725,8 @@ __global__ void k_scan_finish_blocks(uint64_t *blk_base, uint64_t n, const ScanT
 // ======================================================================================
 // Raw / RLE blocks and literal sections
 // ======================================================================================
+constexpr uint32_t kCopySlice = 8u << 10;
+
 template <bool ASCII>
 __global__ __launch_bounds__(256) void k_copy_fill(const uint8_t *__restrict__ src, const CopyTask *__restrict__ tasks,
                                                    const uint64_t *__restrict__ blk_base, uint8_t *out, uint8_t *lit,
@@ -735,13 +736,16 @@ __global__ __launch_bounds__(256) void k_copy_fill(const uint8_t *__restrict__ s
     const bool fill = (t.flags & 2) != 0;
     const uint8_t fv = static_cast<uint8_t>(t.src_off);
     const uint8_t *s = src + (fill ? 0 : t.src_off);
+    // a task (<= 128 KiB) is cut into kCopySlice-byte slices, one workgroup each (blockIdx.y)
+    const uint32_t lo = blockIdx.y * kCopySlice;
+    const uint32_t hi = lo + kCopySlice < t.len ? lo + kCopySlice : t.len;
     if (ASCII && !(t.flags & 1)) {                       // nucleotide section: expand while copying
         uint16_t *d = reinterpret_cast<uint16_t *>(out) + blk_base[t.blk] + t.dst;
-        for (uint32_t i = threadIdx.x; i < t.len; i += blockDim.x)
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
             d[i] = static_cast<uint16_t>(byte_chars(fill ? fv : s[i], t_char));
     } else {
         uint8_t *d = (t.flags & 1) ? lit + t.dst : out + blk_base[t.blk] + t.dst;
-        for (uint32_t i = threadIdx.x; i < t.len; i += blockDim.x) d[i] = fill ? fv : s[i];
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) d[i] = fill ? fv : s[i];
     }
 }
 
@@ -1571,10 +1575,10 @@ void launch_copy_fill(hipStream_t stream, const uint8_t *src, const CopyTask *ta
                       uint32_t *status) {
     if (!n_tasks) return;
     if (ascii)
-        hipLaunchKernelGGL(k_copy_fill<true>, dim3(n_tasks), dim3(256), 0, stream, src, tasks, blk_base, out, lit, t_char,
+        hipLaunchKernelGGL(k_copy_fill<true>, dim3(n_tasks, kBlockMax / kCopySlice), dim3(256), 0, stream, src, tasks, blk_base, out, lit, t_char,
                            status);
     else
-        hipLaunchKernelGGL(k_copy_fill<false>, dim3(n_tasks), dim3(256), 0, stream, src, tasks, blk_base, out, lit, t_char,
+        hipLaunchKernelGGL(k_copy_fill<false>, dim3(n_tasks, kBlockMax / kCopySlice), dim3(256), 0, stream, src, tasks, blk_base, out, lit, t_char,
                            status);
 }
 

@@ -85,6 +85,19 @@ def build_cases(scale=1):
     add("mask_no_sequence", nw.write_naf(recs, mask_runs=inside), sequence=False)
     add("mask_on_protein", nw.write_naf(make_records(rng, [100, 200], alphabet="ACDEFGHIKLMNPQRSTVWY"),
                                         sequence_type="protein", mask_runs=[50, 30, 40, 100, 80]))
+    # many short runs: several masked runs share one 16-byte chunk (k_mask_apply's atomic edge path), runs of
+    # length 0, 1 and 15-17 around chunk boundaries, > 256 masked runs (more than one workgroup batch)
+    dense_recs = make_records(rng, [5000 * scale + 7, 333, 12000])
+    dt = sum(len(r["sequence"]) for r in dense_recs)
+    dense, left = [], dt
+    pat = [3, 2, 1, 3, 0, 5, 9, 1, 1, 1, 2, 16, 15, 17, 1, 31, 33, 4, 0, 0, 7, 64, 5, 100]
+    while left > 400:
+        for v in pat:
+            dense.append(v)
+            left -= v
+    dense.append(left)
+    add("mask_dense_short_runs", nw.write_naf(dense_recs, mask_runs=dense))
+    add("mask_dense_short_runs_spec", nw.write_naf(dense_recs, mask_runs=dense), spec_mask=True)
     long_run = make_records(rng, [70000 * scale + 3, 40000])
     lt = sum(len(r["sequence"]) for r in long_run)
     add("mask_run_gt_65535", nw.write_naf(long_run, mask_runs=[10, 66000, lt - 66010]))
@@ -226,3 +239,23 @@ def check_sharding(lib, n_bases, mask, worlds=(2, 3, 5), seed=5):
             assert nxt == arc.n_bases and hsum == arc.seq_hash, (world, nxt, hsum)
     finally:
         L.c.nafgpu_synth_free(ctypes.byref(arc))
+
+
+def zstd_payload_cases(scale=1):
+    """(name, payload, decoded) triples at the zstd-section level (nafgpu_zstd_decompress): several
+    magicless frames back to back with > 64 blocks each, so that the repeat-offset
+    composition (k_rep_partial / k_rep_scan / k_rep_apply) crosses chunk AND frame boundaries, and
+    blocks without sequences sit between blocks with sequences."""
+    import zstd_ref
+    rng = np.random.default_rng(77)
+    out = []
+    motif = bytes(rng.integers(65, 91, 61, dtype=np.uint8))
+    parts = []
+    for f in range(3):
+        body = b"".join(motif[(i * 7 + f) % 50:][:11] + bytes([65 + (i * i + f) % 26]) * (i % 5) for i in range(2600 * scale))
+        noise = bytes(rng.integers(0, 256, 4000, dtype=np.uint8))            # literal-only / raw blocks in the middle
+        parts.append(body[:len(body) // 2] + noise + body[len(body) // 2:])
+    for level, step in ((3, 97), (1, 211), (19, 151)):
+        payload = b"".join(zstd_ref.compress_magicless(p, level, True, flush_every=step) for p in parts)
+        out.append(("multi_frame_l%d_flush%d" % (level, step), payload, b"".join(parts)))
+    return out

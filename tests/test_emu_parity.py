@@ -39,6 +39,13 @@ def test_cases_match_oracle(emu, all_cases):
     assert not bad
 
 
+def test_zstd_multi_frame_many_blocks(emu):
+    from oracle import oracle
+    for name, payload, data in cases.zstd_payload_cases(scale=1):
+        assert oracle.zstd_decode(payload, len(data)) == data, name
+        assert emu.zstd_decompress(payload, len(data)) == data, name
+
+
 @pytest.mark.parametrize("name", ["LuxC", "masked", "phix", "CP040672", "NZ_AAEN01000029"])
 def test_fixtures_match_oracle(emu, name):
     blob = golden_bytes(name + ".naf")

@@ -97,6 +97,15 @@ def test_zstd_text_sections(lib):
 
 
 @pytest.mark.skipif(not zstd_ref.available(), reason="libzstd not loadable")
+def test_zstd_multi_frame_many_blocks(lib):
+    """Frames back to back, > 64 blocks each: repeat offsets composed across chunks, reset per frame."""
+    import cases
+    for name, payload, data in cases.zstd_payload_cases(scale=2):
+        assert oracle.zstd_decode(payload, len(data)) == data, name
+        assert lib.zstd_decompress(payload, len(data)) == data, name
+
+
+@pytest.mark.skipif(not zstd_ref.available(), reason="libzstd not loadable")
 def test_zstd_corrupt_is_an_error_not_a_fault(lib):
     from nafcodec_amd import NafError
     rng = np.random.default_rng(11)

@@ -179,6 +179,16 @@ typedef struct {
     uint32_t reserved3;
     uint64_t lz_residue_matches; /* LZ matches the parallel passes left to the pointer-jumping stage (all sections) */
     uint64_t base_offset;        /* shard: global index of d_sequence[0] (0 unless sharded) */
+    /* ids / comments split on NUL on the device (CStringReader, reader.rs:22-30): string k of d_ids is
+     * d_ids[d_id_end[k-1] .. d_id_end[k] - 1) (d_id_end[k] = offset just past its NUL); at most
+     * number_of_sequences strings are listed */
+    const uint64_t *d_id_end;
+    const uint64_t *d_comment_end;
+    uint64_t n_ids, n_comments;
+    /* bit s set: section s (0 ids, 1 comments, 4 sequence of a protein/text archive, 5 quality) is not valid
+     * UTF-8 -- where the reference returns Error::Utf8 (reader.rs:108-109) or panics (mod.rs:362,368) */
+    uint32_t utf8_invalid;
+    uint32_t reserved4;
 } nafgpu_device_result;
 
 int nafgpu_decode_all_device(nafgpu_decoder *dec, nafgpu_device_result *out);
@@ -186,6 +196,25 @@ int nafgpu_decode_all_device(nafgpu_decoder *dec, nafgpu_device_result *out);
  * Idempotent; decode_all_device / next call it implicitly.  Lets a caller separate "compressed
  * bytes resident in HBM" from the decode itself. */
 int nafgpu_upload(nafgpu_decoder *dec);
+
+/* ---- text output on the device (what a consumer of the iterator does next, cf. unnaf) ----
+ * FASTA, or FASTQ when the archive has a Quality section and opts.quality is set, of the records the
+ * iterator would yield, built in HBM from the decoded buffers:
+ *   FASTA  '>' id [name_separator comment] '\n', then the sequence in lines of header.line_length characters
+ *   FASTQ  '@' id [name_separator comment] '\n' sequence '\n' '+' '\n' quality '\n'
+ * (separator and comment only when the comment is not empty; line_length 0 = one line).  Runs
+ * decode_all_device first if nothing is decoded yet.  d_text stays valid until close / the next call. */
+typedef struct {
+    const uint8_t *d_text;       /* device pointer */
+    uint64_t n_text;             /* bytes */
+    uint64_t n_records;
+    float ms;                    /* sizes + scan + write kernels, HIP events */
+    uint8_t fastq;
+    uint8_t reserved[3];
+} nafgpu_text_result;
+int nafgpu_format_device(nafgpu_decoder *dec, nafgpu_text_result *out);
+/* device -> host copy of `n` bytes of a buffer a result struct points to (tests, small consumers) */
+int nafgpu_copy_to_host(nafgpu_decoder *dec, const void *d_ptr, uint64_t n, void *dst);
 /* hipDeviceSynchronize on `device` (-1 = current) */
 int nafgpu_device_synchronize(int device);
 

@@ -55,7 +55,14 @@ class DeviceResult(Structure):
                 ("ms_total", c_float), ("ms_huf", c_float), ("ms_unpack", c_float), ("ms_seq_lz", c_float),
                 ("ms_other", c_float), ("ms_host_plan", c_float), ("ms_h2d", c_float),
                 ("n_huf_launches", c_uint32), ("reserved3", c_uint32), ("lz_residue_matches", c_uint64),
-                ("base_offset", c_uint64)]
+                ("base_offset", c_uint64),
+                ("d_id_end", c_void_p), ("d_comment_end", c_void_p), ("n_ids", c_uint64), ("n_comments", c_uint64),
+                ("utf8_invalid", c_uint32), ("reserved4", c_uint32)]
+
+
+class TextResult(Structure):
+    _fields_ = [("d_text", c_void_p), ("n_text", c_uint64), ("n_records", c_uint64), ("ms", c_float),
+                ("fastq", c_uint8), ("reserved", c_uint8 * 3)]
 
 
 class SynthSpec(Structure):
@@ -78,6 +85,7 @@ EXPORTS = [
     "nafgpu_decode_all_device", "nafgpu_zstd_decompress", "nafgpu_synth_write", "nafgpu_synth_free",
     "nafgpu_hash64_host", "nafgpu_hash64_device", "nafgpu_abi_version", "nafgpu_device_info",
     "nafgpu_upload", "nafgpu_device_synchronize", "nafgpu_hash64_device_at",
+    "nafgpu_format_device", "nafgpu_copy_to_host",
 ]
 
 
@@ -118,6 +126,8 @@ class Library:
         L.nafgpu_hash64_device.argtypes = [c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]
         L.nafgpu_hash64_device_at.argtypes = [c_void_p, c_void_p, c_uint64, c_uint64, POINTER(c_uint64)]
         L.nafgpu_device_info.argtypes = [c_int, c_char_p, c_size_t, POINTER(c_uint64), POINTER(c_int)]
+        L.nafgpu_format_device.argtypes = [c_void_p, POINTER(TextResult)]
+        L.nafgpu_copy_to_host.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p]
 
     # ---- helpers ---------------------------------------------------------------------------
     def zstd_decompress(self, payload: bytes, size: int, device: int = -1) -> bytes:

@@ -446,7 +446,36 @@ int nafgpu_decode_all_device(nafgpu_decoder *d, nafgpu_device_result *out) {
     for (int s = 0; s < kNumSections; s++) out->lz_residue_matches += j.job(s).lz_residue();
     out->ms_host_plan = j.host_plan_ms();
     out->ms_h2d = j.h2d_ms();
+    out->d_id_end = d->use[kIds] ? j.d_id_ends() : nullptr;
+    out->d_comment_end = d->use[kComments] ? j.d_com_ends() : nullptr;
+    out->n_ids = d->use[kIds] ? j.n_ids() : 0;
+    out->n_comments = d->use[kComments] ? j.n_comments() : 0;
+    out->utf8_invalid = j.utf8_invalid();
     return NAFGPU_OK;
+}
+
+int nafgpu_format_device(nafgpu_decoder *d, nafgpu_text_result *out) {
+    if (!d || !out) return NAFGPU_E_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    Failure f = ensure_decoded(d);
+    if (!f.ok()) return fail(d, f);
+    for (int s = 0; s < kNumSections; s++)
+        if (d->use[s] && !d->job.section_failure(s).ok()) return fail(d, d->job.section_failure(s));
+    if (!d->use[kSequence] || !d->use[kLengths])
+        return fail(d, Failure::make(NAFGPU_E_INVALID_ARG, "text output needs the sequence and length fields"));
+    const uint64_t n_rec = std::min<uint64_t>(d->header.number_of_sequences, d->job.n_records());
+    const bool fastq = d->use[kQuality] && d->job.job(kQuality).ready();
+    f = d->job.format_text(d->use[kIds], d->use[kComments], fastq, n_rec, &out->d_text, &out->n_text, &out->ms);
+    if (!f.ok()) return fail(d, f);
+    out->n_records = n_rec;
+    out->fastq = fastq ? 1 : 0;
+    return NAFGPU_OK;
+}
+
+int nafgpu_copy_to_host(nafgpu_decoder *d, const void *d_ptr, uint64_t n, void *dst) {
+    if (!d || (n && (!d_ptr || !dst))) return NAFGPU_E_INVALID_ARG;
+    Failure f = d->job.copy_to_host(dst, d_ptr, static_cast<size_t>(n));
+    return f.ok() ? NAFGPU_OK : fail(d, f);
 }
 
 int nafgpu_upload(nafgpu_decoder *d) {

@@ -352,7 +352,10 @@ Failure ArchiveJob::upload(const uint8_t *bytes, size_t n, const nafgpu_header &
         if (fail_[s].ok()) compressed_ += sec[s].compressed_size;
     }
     // ---- derived tables
-    bool ok = d_totals_.alloc(4 * sizeof(ScanTotals)) && d_status_.alloc(64) && d_hash_.alloc(16);
+    bool ok = d_totals_.alloc(8 * sizeof(ScanTotals)) && d_status_.alloc(64) && d_hash_.alloc(16);
+    str_cap_ = h.number_of_sequences;                          // the iterator never hands out more strings than records
+    if (job_[kIds].ready()) ok = ok && d_id_ends_.alloc((str_cap_ + 1) * sizeof(uint64_t));
+    if (job_[kComments].ready()) ok = ok && d_com_ends_.alloc((str_cap_ + 1) * sizeof(uint64_t));
     if (job_[kLengths].ready()) {
         rec_cap_ = job_[kLengths].size() / 4;
         ok = ok && d_rec_ends_.alloc((rec_cap_ + 1) * sizeof(uint64_t));
@@ -362,7 +365,9 @@ Failure ArchiveJob::upload(const uint8_t *bytes, size_t n, const nafgpu_header &
         mask_cap_ = job_[kMask].size();
         ok = ok && d_mask_ends_.alloc((mask_cap_ + 1) * sizeof(uint64_t));
     }
-    ok = ok && d_scan_tmp_.alloc(scan_tmp_bytes(std::max(rec_cap_, mask_cap_)));
+    const uint64_t scan_max = std::max({rec_cap_, mask_cap_, static_cast<uint64_t>(job_[kIds].ready() ? job_[kIds].size() : 0),
+                                        static_cast<uint64_t>(job_[kComments].ready() ? job_[kComments].size() : 0), str_cap_});
+    ok = ok && d_scan_tmp_.alloc(scan_tmp_bytes(scan_max));
     if (!ok) return Failure::make(NAFGPU_E_DEVICE, "out of device memory");
     return Failure();
 }
@@ -373,7 +378,7 @@ Failure ArchiveJob::decode() {
     uint32_t *status = d_status_.as<uint32_t>();
     ScanTotals *totals = d_totals_.as<ScanTotals>();
     (void)hipMemsetAsync(status, 0, 64, stream_);
-    (void)hipMemsetAsync(totals, 0, 4 * sizeof(ScanTotals), stream_);
+    (void)hipMemsetAsync(totals, 0, 8 * sizeof(ScanTotals), stream_);
     timer_.mark_total_begin(stream_);
     for (int s = 0; s < kNumSections; s++) job_[s].run(stream_, &timer_);
     if (job_[kLengths].ready()) {                                  // LengthReader, reader.rs:48-67
@@ -396,13 +401,34 @@ Failure ArchiveJob::decode() {
                           &totals[0], mask_cap_, opt_.spec_mask ? 1 : 0, status);
         timer_.end(stream_);
     }
+    // ids / comments: CStringReader (reader.rs:22-30) as a scan; UTF-8 validity of every text section
+    // (into_string().expect at mod.rs:362,368; from_utf8 at reader.rs:108-109) as one flag word
+    uint32_t *utf8 = status + 8;
+    timer_.begin(stream_, StageTimer::kOther);
+    if (job_[kIds].ready()) {
+        launch_scan_nul(stream_, job_[kIds].out(), job_[kIds].size(), d_id_ends_.as<uint64_t>(), str_cap_, d_scan_tmp_.bytes(),
+                        &totals[2], status);
+        launch_utf8_check(stream_, job_[kIds].out(), job_[kIds].size(), utf8, kIds);
+    }
+    if (job_[kComments].ready()) {
+        launch_scan_nul(stream_, job_[kComments].out(), job_[kComments].size(), d_com_ends_.as<uint64_t>(), str_cap_,
+                        d_scan_tmp_.bytes(), &totals[3], status);
+        launch_utf8_check(stream_, job_[kComments].out(), job_[kComments].size(), utf8, kComments);
+    }
+    if (job_[kSequence].ready() && !is_nuc_) launch_utf8_check(stream_, job_[kSequence].out(), job_[kSequence].size(), utf8, kSequence);
+    if (job_[kQuality].ready()) launch_utf8_check(stream_, job_[kQuality].out(), job_[kQuality].size(), utf8, kQuality);
+    timer_.end(stream_);
     timer_.mark_total_end(stream_);
-    ScanTotals host_totals[2] = {{0, 0}, {0, 0}};
+    ScanTotals host_totals[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    utf8_invalid_ = 0;
+    (void)hipMemcpyAsync(&utf8_invalid_, utf8, sizeof utf8_invalid_, hipMemcpyDeviceToHost, stream_);
     if (!hip_ok(hipMemcpyAsync(host_totals, totals, sizeof host_totals, hipMemcpyDeviceToHost, stream_)) ||
         !hip_ok(hipStreamSynchronize(stream_)))
         return Failure::make(NAFGPU_E_DEVICE, std::string("decode failed: ") + hipGetErrorString(hipGetLastError()));
     rec_totals_ = host_totals[0];
     mask_totals_ = host_totals[1];
+    id_totals_ = host_totals[2];
+    com_totals_ = host_totals[3];
     times_ = timer_.collect();
     for (int s = 0; s < kNumSections; s++) {
         if (!job_[s].ready()) continue;
@@ -410,6 +436,70 @@ Failure ArchiveJob::decode() {
         if (f.status == NAFGPU_E_DEVICE) return f;
         if (!f.ok()) fail_[s] = f;
     }
+    return Failure();
+}
+
+Failure ArchiveJob::format_text(bool with_ids, bool with_comments, bool with_quality, uint64_t n_rec, const uint8_t **d_text,
+                                uint64_t *n_text, float *ms) {
+    (void)hipSetDevice(device_);
+    *d_text = nullptr;
+    *n_text = 0;
+    *ms = 0;
+    if (!job_[kSequence].ready() || !job_[kLengths].ready())
+        return Failure::make(NAFGPU_E_INVALID_ARG, "text output needs the Sequence and Length sections");
+    if (job_[kSequence].sharded()) return Failure::make(NAFGPU_E_INVALID_ARG, "text output is not available on a shard");
+    n_rec = std::min<uint64_t>(n_rec, rec_totals_.count);
+    if (n_rec == 0) return Failure();
+    FmtText t{};
+    t.seq = job_[kSequence].out();
+    t.qual = with_quality && job_[kQuality].ready() ? job_[kQuality].out() : nullptr;
+    t.rec_end = d_rec_ends_.as<uint64_t>();
+    if (with_ids && job_[kIds].ready()) {
+        t.ids = job_[kIds].out();
+        t.id_end = d_id_ends_.as<uint64_t>();
+        t.n_ids = n_ids();
+    }
+    if (with_comments && job_[kComments].ready()) {
+        t.com = job_[kComments].out();
+        t.com_end = d_com_ends_.as<uint64_t>();
+        t.n_com = n_comments();
+    }
+    t.n_rec = n_rec;
+    t.line_length = h_.line_length;
+    t.sep = static_cast<uint8_t>(h_.name_separator);
+    // the records must lie inside what was decoded (lengths may promise more than the sequence holds)
+    uint64_t last_end = 0;
+    if (!hip_ok(hipMemcpyAsync(&last_end, t.rec_end + (n_rec - 1), sizeof last_end, hipMemcpyDeviceToHost, stream_)) ||
+        !hip_ok(hipStreamSynchronize(stream_)))
+        return Failure::make(NAFGPU_E_DEVICE, "record table read-back failed");
+    const uint64_t have = is_nuc_ ? std::min<uint64_t>(n_sequence_bytes(), mask_total_bases_) : job_[kSequence].total_size();
+    if (last_end > have || (t.qual && last_end > job_[kQuality].size()))
+        return Failure::io(NAFGPU_IO_UNEXPECTED_EOF, "record lengths exceed the decoded sequence");
+    if (!d_fmt_sizes_.alloc(n_rec * sizeof(uint64_t)) || !d_fmt_off_.alloc((n_rec + 1) * sizeof(uint64_t)) ||
+        !d_scan_tmp_.alloc(scan_tmp_bytes(std::max<uint64_t>(n_rec, 1))))
+        return Failure::make(NAFGPU_E_DEVICE, "out of device memory");
+    ScanTotals *totals = d_totals_.as<ScanTotals>();
+    uint32_t *status = d_status_.as<uint32_t>();
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, stream_);
+    (void)hipMemsetAsync(&totals[4], 0, sizeof(ScanTotals), stream_);
+    launch_fmt_sizes(stream_, t, d_fmt_sizes_.as<uint64_t>());
+    launch_scan_excl_u64(stream_, d_fmt_sizes_.as<uint64_t>(), n_rec, d_fmt_off_.as<uint64_t>(), d_scan_tmp_.bytes(), &totals[4], status);
+    ScanTotals tot{0, 0};
+    if (!hip_ok(hipMemcpyAsync(&tot, &totals[4], sizeof tot, hipMemcpyDeviceToHost, stream_)) || !hip_ok(hipStreamSynchronize(stream_)))
+        return Failure::make(NAFGPU_E_DEVICE, "text size read-back failed");
+    if (!d_text_.alloc(static_cast<size_t>(tot.sum) + 64)) return Failure::make(NAFGPU_E_DEVICE, "out of device memory for the text");
+    launch_fmt_write(stream_, t, d_fmt_off_.as<uint64_t>(), tot.sum, d_text_.bytes());
+    (void)hipEventRecord(e1, stream_);
+    if (!hip_ok(hipStreamSynchronize(stream_)))
+        return Failure::make(NAFGPU_E_DEVICE, std::string("text formatting failed: ") + hipGetErrorString(hipGetLastError()));
+    (void)hipEventElapsedTime(ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *d_text = d_text_.bytes();
+    *n_text = tot.sum;
     return Failure();
 }
 

@@ -12,6 +12,7 @@
 //   rec_ends  u64 inclusive prefix sum of record lengths
 //   mask_ends u64 inclusive prefix sum of mask runs
 #pragma once
+#include <algorithm>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -159,6 +160,16 @@ public:
     uint64_t compressed_bytes() const { return compressed_; }
     hipStream_t stream() const { return stream_; }
     int device() const { return device_; }
+    // ids / comments split on NUL on the device (CStringReader): offsets just past each NUL; at most number_of_sequences strings
+    const uint64_t *d_id_ends() const { return job_[kIds].ready() ? d_id_ends_.as<uint64_t>() : nullptr; }
+    const uint64_t *d_com_ends() const { return job_[kComments].ready() ? d_com_ends_.as<uint64_t>() : nullptr; }
+    uint64_t n_ids() const { return std::min<uint64_t>(id_totals_.count, str_cap_); }
+    uint64_t n_comments() const { return std::min<uint64_t>(com_totals_.count, str_cap_); }
+    // bit s set: section s (kIds, kComments, kSequence as text, kQuality) is not valid UTF-8 (Error::Utf8 in the reference)
+    uint32_t utf8_invalid() const { return utf8_invalid_; }
+    // FASTA (or FASTQ when `with_quality`) text of the first n_rec records, built on the device after decode()
+    Failure format_text(bool with_ids, bool with_comments, bool with_quality, uint64_t n_rec, const uint8_t **d_text, uint64_t *n_text,
+                        float *ms);
     Failure copy_to_host(void *dst, const void *d_src, size_t n);
     Failure hash_device(const void *d_ptr, uint64_t n, uint64_t first_chunk, uint64_t *out);
 
@@ -174,6 +185,10 @@ private:
     SectionJob job_[kNumSections];
     Failure fail_[kNumSections];
     DevBuf d_rec_ends_, d_mask_ends_, d_scan_tmp_, d_totals_, d_status_, d_hash_;
+    DevBuf d_id_ends_, d_com_ends_, d_fmt_sizes_, d_fmt_off_, d_text_;
+    uint64_t str_cap_ = 0;
+    ScanTotals id_totals_{0, 0}, com_totals_{0, 0};
+    uint32_t utf8_invalid_ = 0;
     uint64_t rec_cap_ = 0, mask_cap_ = 0, mask_total_bases_ = 0;
     ScanTotals rec_totals_{0, 0}, mask_totals_{0, 0};
     float plan_ms_ = 0, h2d_ms_ = 0;

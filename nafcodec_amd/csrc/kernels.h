@@ -32,6 +32,33 @@ void launch_scan_runs_u32(hipStream_t stream, const uint8_t *words, uint64_t n_w
 void launch_scan_runs_u8(hipStream_t stream, const uint8_t *bytes, uint64_t n_bytes, uint64_t *ends, uint64_t cap,
                          void *tile_tmp, ScanTotals *totals, uint32_t *status);
 
+// ids / comments: ends[k] = offset just past the k-th NUL (CStringReader, reader.rs:22-30); strings beyond `cap` are dropped
+void launch_scan_nul(hipStream_t stream, const uint8_t *bytes, uint64_t n_bytes, uint64_t *ends, uint64_t cap, void *tile_tmp,
+                     ScanTotals *totals, uint32_t *status);
+// exclusive prefix sums of n u64 items (out: n entries; totals->sum = grand total)
+void launch_scan_excl_u64(hipStream_t stream, const uint64_t *items, uint64_t n, uint64_t *out, void *tile_tmp, ScanTotals *totals,
+                          uint32_t *status);
+// sets bit `bit` of *flags when p[0..n) is not valid UTF-8 (mod.rs:362,368; reader.rs:108-109)
+void launch_utf8_check(hipStream_t stream, const uint8_t *p, uint64_t n, uint32_t *flags, uint32_t bit);
+
+// FASTA / FASTQ text from the decoded buffers
+struct FmtText {
+    const uint8_t *seq;          // ASCII bases / text, mask applied
+    const uint8_t *qual;         // non-null: FASTQ
+    const uint64_t *rec_end;
+    const uint8_t *ids;
+    const uint64_t *id_end;
+    uint64_t n_ids;
+    const uint8_t *com;
+    const uint64_t *com_end;
+    uint64_t n_com;
+    uint64_t n_rec;
+    uint64_t line_length;
+    uint32_t sep;
+};
+void launch_fmt_sizes(hipStream_t stream, const FmtText &t, uint64_t *sizes);
+void launch_fmt_write(hipStream_t stream, const FmtText &t, const uint64_t *off, uint64_t n_text, uint8_t *text);
+
 // raw / RLE blocks and literal sections
 // ascii = true (nucleotide sequence sections): bytes bound for `out` are expanded to two IUPAC
 // characters each on the way (t_char = 'T' DNA / 'U' RNA); bytes bound for `lit` stay packed.

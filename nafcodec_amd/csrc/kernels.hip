@@ -582,7 +582,13 @@ struct TileAgg {
     uint64_t cnt;
 };
 
-enum ScanMode { kModeExcl = 0, kModeRunsU32 = 1, kModeRunsU8 = 2 };
+enum ScanMode {
+    kModeExcl = 0,      // u32 items -> exclusive prefix sums
+    kModeRunsU32 = 1,   // length words, 0xFFFFFFFF continues a run
+    kModeRunsU8 = 2,    // mask bytes, 0xFF continues a run
+    kModeNul = 3,       // text bytes: ends[k] = offset just past the k-th NUL (CStringReader, reader.rs:22-30); extra strings are dropped
+    kModeExclU64 = 4,   // u64 items -> exclusive prefix sums
+};
 
 template <int MODE>
 __device__ inline void scan_item(const uint8_t *in, uint64_t i, uint64_t n, uint64_t *v, uint32_t *t) {
@@ -595,6 +601,12 @@ __device__ inline void scan_item(const uint8_t *in, uint64_t i, uint64_t n, uint
         const uint32_t b = in[i];
         *v = b;
         *t = b != 0xFFu;
+    } else if (MODE == kModeNul) {
+        *v = 1;
+        *t = in[i] == 0;
+    } else if (MODE == kModeExclU64) {
+        *v = reinterpret_cast<const uint64_t *>(in)[i];
+        *t = 1;
     } else {
         const uint8_t *q = in + 4 * i;      // length words are not guaranteed 4-byte aligned in memory
         const uint32_t w = static_cast<uint32_t>(q[0]) | (static_cast<uint32_t>(q[1]) << 8) |
@@ -699,7 +711,7 @@ __global__ __launch_bounds__(256) void k_scan_emit(const uint8_t *in, uint64_t n
 #pragma unroll
     for (uint32_t k = 0; k < kScanItems; k++) {
         if (base + k >= n) break;
-        if (MODE == kModeExcl) {
+        if (MODE == kModeExcl || MODE == kModeExclU64) {
             out[base + k] = run;
             run += v[k];
         } else {
@@ -707,7 +719,7 @@ __global__ __launch_bounds__(256) void k_scan_emit(const uint8_t *in, uint64_t n
             if (t[k]) {
                 if (idx < cap)
                     out[idx] = run;
-                else
+                else if (MODE != kModeNul)
                     flag_error(status, kStRunsOverflow, 0);
                 idx++;
             }
@@ -720,6 +732,183 @@ __global__ void k_scan_finish_blocks(uint64_t *blk_base, uint64_t n, const ScanT
     if (status[0] != 0) return;
     blk_base[n] = totals->sum;
     if (totals->sum != expect) flag_error(status, kStSizeMismatch, 0xFFFFFFFFu);
+}
+
+// ======================================================================================
+// UTF-8 validation (into_string().expect at mod.rs:362,368; std::str::from_utf8 at reader.rs:108-109)
+// ======================================================================================
+// Byte-parallel: byte i must be a continuation byte exactly when one of the three bytes before it is
+// a lead byte that reaches it; lead bytes C0, C1, F5..FF are invalid; the byte after E0 / ED / F0 / F4
+// has a narrower range (no overlong forms, no surrogates, nothing above U+10FFFF); a sequence must
+// not run past the end.  Sets bit `bit` of *flags if the buffer is not valid UTF-8.
+__device__ inline uint32_t utf8_lead_len(uint32_t b) {     // bytes a lead byte announces (0: not a lead byte)
+    if (b < 0x80u) return 1;
+    if (b < 0xC0u) return 0;
+    if (b < 0xE0u) return 2;
+    if (b < 0xF0u) return 3;
+    return 4;
+}
+
+__global__ __launch_bounds__(256) void k_utf8_check(const uint8_t *__restrict__ p, uint64_t n, uint32_t *flags, uint32_t bit) {
+    bool bad = false;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) {
+        const uint32_t b = p[i];
+        const uint32_t b1 = i >= 1 ? p[i - 1] : 0u, b2 = i >= 2 ? p[i - 2] : 0u, b3 = i >= 3 ? p[i - 3] : 0u;
+        const bool need_cont = utf8_lead_len(b1) >= 2 || utf8_lead_len(b2) >= 3 || (b3 >= 0xF0u && utf8_lead_len(b3) == 4);
+        const bool is_cont = (b & 0xC0u) == 0x80u;
+        if (need_cont != is_cont) bad = true;
+        if (b == 0xC0u || b == 0xC1u || b >= 0xF5u) bad = true;
+        if (b1 == 0xE0u && b < 0xA0u) bad = true;           // overlong 3-byte form
+        if (b1 == 0xEDu && b > 0x9Fu) bad = true;           // surrogates
+        if (b1 == 0xF0u && b < 0x90u) bad = true;           // overlong 4-byte form
+        if (b1 == 0xF4u && b > 0x8Fu) bad = true;           // above U+10FFFF
+        if (b >= 0xC0u && i + utf8_lead_len(b) > n) bad = true;   // truncated at the end
+    }
+    if (bad) atomicOr(flags, 1u << bit);
+}
+
+// ======================================================================================
+// FASTA / FASTQ text from the decoded buffers (what every consumer of the iterator does
+// next, cf. unnaf): record k becomes
+//   FASTA  '>' id [sep comment] '\n'  then the sequence in lines of `line_length` characters
+//   FASTQ  '@' id [sep comment] '\n' sequence '\n' '+' '\n' quality '\n'
+// (the comment, with its separator, only when it is not empty).  k_fmt_sizes computes every record's
+// text size, an exclusive scan turns sizes into offsets, k_fmt_write fills the text.
+// ======================================================================================
+struct FmtArgs {
+    const uint8_t *seq;          // ASCII, mask applied
+    const uint8_t *qual;         // null: FASTA
+    const uint64_t *rec_end;     // inclusive prefix sums of the record lengths
+    const uint8_t *ids;          // null: no names
+    const uint64_t *id_end;      // offset just past the k-th NUL
+    uint64_t n_ids;
+    const uint8_t *com;
+    const uint64_t *com_end;
+    uint64_t n_com;
+    uint64_t n_rec;
+    uint64_t line_length;        // 0: one line per sequence
+    uint32_t sep;
+    uint32_t pad;
+};
+
+struct FmtRec {                  // where the pieces of one record are
+    uint64_t id0, id_len, com0, com_len, s0, n, hdr, body;
+};
+
+__device__ inline FmtRec fmt_record(const FmtArgs &a, uint64_t k) {
+    FmtRec r;
+    r.id0 = r.id_len = r.com0 = r.com_len = 0;
+    if (a.ids && k < a.n_ids) {
+        r.id0 = k ? a.id_end[k - 1] : 0;
+        r.id_len = a.id_end[k] - r.id0 - 1;
+    }
+    if (a.com && k < a.n_com) {
+        r.com0 = k ? a.com_end[k - 1] : 0;
+        r.com_len = a.com_end[k] - r.com0 - 1;
+    }
+    r.s0 = k ? a.rec_end[k - 1] : 0;
+    r.n = a.rec_end[k] - r.s0;
+    r.hdr = 1 + r.id_len + (r.com_len ? 1 + r.com_len : 0) + 1;
+    if (a.qual)
+        r.body = 2 * r.n + 4;
+    else if (r.n == 0)
+        r.body = 0;
+    else
+        r.body = r.n + (a.line_length ? (r.n + a.line_length - 1) / a.line_length : 1);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_fmt_sizes(FmtArgs a, uint64_t *sizes) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256;
+    for (uint64_t k = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; k < a.n_rec; k += stride) {
+        const FmtRec r = fmt_record(a, k);
+        sizes[k] = r.hdr + r.body;
+    }
+}
+
+constexpr uint32_t kFmtChunk = 16u << 10;    // text bytes per workgroup step
+
+__global__ __launch_bounds__(256) void k_fmt_write(FmtArgs a, const uint64_t *__restrict__ off, uint64_t n_text, uint8_t *text) {
+    // A workgroup takes 16 KiB of text at a time: one binary search for the record its first byte
+    // belongs to, then record by record (uniformly) until the chunk is full; every thread produces
+    // four consecutive characters per step and stores them as one dword where it can.
+    const uint32_t tid = threadIdx.x;
+    const uint64_t n_chunks = (n_text + kFmtChunk - 1) / kFmtChunk;
+    for (uint64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        const uint64_t c0 = ch * kFmtChunk, c1 = c0 + kFmtChunk < n_text ? c0 + kFmtChunk : n_text;
+        uint64_t lo = 0, hi = a.n_rec;                     // last record with off[k] <= c0
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (off[mid] <= c0)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        for (uint64_t k = lo; k < a.n_rec && off[k] < c1; k++) {
+            const FmtRec r = fmt_record(a, k);
+            const uint64_t base = off[k], size = r.hdr + r.body;
+            const uint64_t t0 = c0 > base ? c0 - base : 0, t1 = c1 - base < size ? c1 - base : size;   // text range of this record in the chunk
+            const uint64_t Lp = a.line_length ? a.line_length + 1 : r.n + 1;
+            auto char_at = [&](uint64_t t) -> uint32_t {
+                if (t < r.hdr) {
+                    if (t == 0) return a.qual ? '@' : '>';
+                    if (t <= r.id_len) return a.ids[r.id0 + t - 1];
+                    if (t == r.hdr - 1) return '\n';
+                    if (t == r.id_len + 1) return a.sep;
+                    return a.com[r.com0 + t - r.id_len - 2];
+                }
+                const uint64_t q = t - r.hdr;
+                if (a.qual) {
+                    if (q < r.n) return a.seq[r.s0 + q];
+                    if (q == r.n) return '\n';
+                    if (q == r.n + 1) return '+';
+                    if (q == r.n + 2) return '\n';
+                    if (q < 2 * r.n + 3) return a.qual[r.s0 + q - r.n - 3];
+                    return '\n';
+                }
+                const uint64_t line = q / Lp, col = q - line * Lp;
+                if (col == Lp - 1 || q == r.body - 1) return '\n';
+                return a.seq[r.s0 + line * (Lp - 1) + col];
+            };
+            uint8_t *dst = text + base;
+            // head: up to the first 4-byte aligned address; then dwords; then the tail
+            const uint64_t a0 = (reinterpret_cast<uintptr_t>(dst + t0) & 3) ? ((t0 + 4 - (reinterpret_cast<uintptr_t>(dst + t0) & 3)) < t1
+                                                                                   ? t0 + 4 - (reinterpret_cast<uintptr_t>(dst + t0) & 3)
+                                                                                   : t1)
+                                                                            : t0;
+            if (tid < a0 - t0) dst[t0 + tid] = static_cast<uint8_t>(char_at(t0 + tid));
+            const uint64_t n_dw = (t1 - a0) >> 2;
+            for (uint64_t d = tid; d < n_dw; d += 256) {
+                const uint64_t t = a0 + 4 * d;
+                uint32_t w;
+                if (t >= r.hdr && !a.qual && t + 4 <= size) {      // FASTA body: one division per four characters
+                    const uint64_t q = t - r.hdr;
+                    const uint64_t line = q / Lp;
+                    uint64_t col = q - line * Lp;
+                    uint64_t src = r.s0 + line * (Lp - 1) + col;
+                    w = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t c;
+                        if (col == Lp - 1 || q + j == r.body - 1) {
+                            c = '\n';
+                            col = 0;
+                        } else {
+                            c = a.seq[src++];
+                            col++;
+                        }
+                        w |= c << (8 * j);
+                    }
+                } else {
+                    w = char_at(t) | (char_at(t + 1) << 8) | (char_at(t + 2) << 16) | (char_at(t + 3) << 24);
+                }
+                *reinterpret_cast<uint32_t *>(dst + t) = w;
+            }
+            const uint64_t tail0 = a0 + 4 * n_dw;
+            if (tid < t1 - tail0) dst[tail0 + tid] = static_cast<uint8_t>(char_at(tail0 + tid));
+        }
+    }
 }
 
 // ======================================================================================
@@ -1568,6 +1757,39 @@ void launch_scan_runs_u32(hipStream_t stream, const uint8_t *words, uint64_t n_w
 void launch_scan_runs_u8(hipStream_t stream, const uint8_t *bytes, uint64_t n_bytes, uint64_t *ends, uint64_t cap,
                          void *tile_tmp, ScanTotals *totals, uint32_t *status) {
     scan_generic<kModeRunsU8>(stream, bytes, n_bytes, ends, cap, tile_tmp, totals, status);
+}
+
+void launch_scan_nul(hipStream_t stream, const uint8_t *bytes, uint64_t n_bytes, uint64_t *ends, uint64_t cap, void *tile_tmp,
+                     ScanTotals *totals, uint32_t *status) {
+    scan_generic<kModeNul>(stream, bytes, n_bytes, ends, cap, tile_tmp, totals, status);
+}
+
+void launch_scan_excl_u64(hipStream_t stream, const uint64_t *items, uint64_t n, uint64_t *out, void *tile_tmp, ScanTotals *totals,
+                          uint32_t *status) {
+    scan_generic<kModeExclU64>(stream, reinterpret_cast<const uint8_t *>(items), n, out, n, tile_tmp, totals, status);
+}
+
+void launch_utf8_check(hipStream_t stream, const uint8_t *p, uint64_t n, uint32_t *flags, uint32_t bit) {
+    if (!n) return;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 256u * 8u) blocks = 256u * 8u;
+    hipLaunchKernelGGL(k_utf8_check, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, p, n, flags, bit);
+}
+
+void launch_fmt_sizes(hipStream_t stream, const FmtText &t, uint64_t *sizes) {
+    if (!t.n_rec) return;
+    FmtArgs a{t.seq, t.qual, t.rec_end, t.ids, t.id_end, t.n_ids, t.com, t.com_end, t.n_com, t.n_rec, t.line_length, t.sep, 0};
+    uint64_t blocks = (t.n_rec + 255) / 256;
+    if (blocks > 256u * 8u) blocks = 256u * 8u;
+    hipLaunchKernelGGL(k_fmt_sizes, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, a, sizes);
+}
+
+void launch_fmt_write(hipStream_t stream, const FmtText &t, const uint64_t *off, uint64_t n_text, uint8_t *text) {
+    if (!t.n_rec || !n_text) return;
+    FmtArgs a{t.seq, t.qual, t.rec_end, t.ids, t.id_end, t.n_ids, t.com, t.com_end, t.n_com, t.n_rec, t.line_length, t.sep, 0};
+    uint64_t blocks = (n_text + kFmtChunk - 1) / kFmtChunk;
+    if (blocks > 256u * 8u) blocks = 256u * 8u;
+    hipLaunchKernelGGL(k_fmt_write, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, a, off, n_text, text);
 }
 
 void launch_copy_fill(hipStream_t stream, const uint8_t *src, const CopyTask *tasks, uint32_t n_tasks,

@@ -158,6 +158,29 @@ class Decoder:
             _raise(err)
         return res
 
+    def format_device(self):
+        """FASTA (FASTQ when the archive has qualities and `quality` is selected) text of every record,
+        built on the GPU from the decoded buffers; returns the nafgpu_text_result struct (device pointer)."""
+        res = _ffi.TextResult()
+        rc = self._lib.c.nafgpu_format_device(self._h, byref(res))
+        if rc != _ffi.OK:
+            err = _ffi.Error()
+            self._lib.c.nafgpu_last_error(self._h, byref(err))
+            _raise(err)
+        return res
+
+    def to_text(self):
+        """format_device() copied to the host: the archive as FASTA / FASTQ bytes (what `unnaf` prints)."""
+        res = self.format_device()
+        return self.copy_to_host(res.d_text, res.n_text)
+
+    def copy_to_host(self, d_ptr, n):
+        buf = ctypes.create_string_buffer(int(n)) if n else ctypes.create_string_buffer(1)
+        rc = self._lib.c.nafgpu_copy_to_host(self._h, d_ptr, int(n), ctypes.cast(buf, ctypes.c_void_p))
+        if rc != _ffi.OK:
+            raise RuntimeError("nafgpu_copy_to_host failed: %d" % rc)
+        return buf.raw[:int(n)]
+
     def hash_device(self, d_ptr, n, first_chunk=0):
         out = ctypes.c_uint64()
         rc = self._lib.c.nafgpu_hash64_device_at(self._h, d_ptr, n, first_chunk, byref(out))

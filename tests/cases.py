@@ -259,3 +259,44 @@ def zstd_payload_cases(scale=1):
         payload = b"".join(zstd_ref.compress_magicless(p, level, True, flush_every=step) for p in parts)
         out.append(("multi_frame_l%d_flush%d" % (level, step), payload, b"".join(parts)))
     return out
+
+
+def oracle_text(blob, opts=None):
+    """FASTA / FASTQ text of an archive from the ORACLE's records (the checker for nafgpu_format_device):
+    '>' id [sep comment] newline + the sequence in lines of header.line_length characters, or
+    '@' id [sep comment] newline sequence newline '+' newline quality newline when the archive has qualities."""
+    from oracle import oracle
+    d = oracle.Decoder(blob, **(opts or {}))
+    sep = chr(d.header.name_separator)
+    width = int(d.header.line_length)
+    out = []
+    for r in d:
+        name = (r.id or "") + (sep + r.comment if r.comment else "")
+        seq = r.sequence or ""
+        if r.quality is not None:
+            out.append("@%s\n%s\n+\n%s\n" % (name, seq, r.quality))
+        else:
+            lines = [seq[i:i + width] for i in range(0, len(seq), width)] if width else ([seq] if seq else [])
+            out.append(">%s\n" % name + "".join(l + "\n" for l in lines))
+    return "".join(out).encode()
+
+
+def text_cases(scale=1):
+    """(name, blob) pairs for the text-output parity test: line lengths that do and do not divide the
+    record lengths, empty records, records longer than a 16 KiB text chunk, hundreds of short records per
+    chunk, no comments / no ids, line_length 0, FASTQ, protein, a mask crossing line ends."""
+    rng = np.random.default_rng(4242)
+    out = []
+    lens = [0, 1, 59, 60, 61, 120, 0, 7, 33000 * scale, 5, 16384, 16383, 1]
+    out.append(("fasta_l60", nw.write_naf(make_records(rng, lens), line_length=60)))
+    out.append(("fasta_l7_masked", nw.write_naf(make_records(rng, [100, 0, 50000, 3]), line_length=7,
+                                                 mask_runs=[5, 20, 30, 45, 2000, 12, 50103 - 2112])))
+    out.append(("fasta_l0", nw.write_naf(make_records(rng, [10, 0, 3000]), line_length=0)))
+    out.append(("fasta_many_short", nw.write_naf(make_records(rng, [int(x) for x in rng.integers(0, 90, 700 * scale)]), line_length=50)))
+    out.append(("fasta_no_comments", nw.write_naf(make_records(rng, [100, 200, 300]), comments=False)))
+    out.append(("fasta_no_ids", nw.write_naf(make_records(rng, [100, 200, 300]), ids=False, comments=False)))
+    out.append(("fasta_protein", nw.write_naf(make_records(rng, [488, 0, 30001], alphabet="ACDEFGHIKLMNPQRSTVWY"),
+                                              sequence_type="protein", line_length=80, level=3)))
+    out.append(("fastq_reads", nw.write_naf(make_records(rng, [151] * (300 * scale) + [0, 1, 301], quality=True), quality=True,
+                                            level=3, line_length=301)))
+    return out

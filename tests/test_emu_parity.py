@@ -3,6 +3,7 @@ tests/emu/hip/hip_runtime.h (one fiber per work-item, switched at __syncthreads(
 with the CPU oracle case by case.  This is test infrastructure for logic and memory-safety
 (AddressSanitizer / UBSan are not available on the GPU pool); the parity tests proper are the
 `-m gpu` ones, which run the hipcc build on an MI355X."""
+import io
 import os
 import subprocess
 import sys
@@ -109,9 +110,60 @@ todo = [c for c in cases.build_cases(1) if not c[0].endswith("_big")]
 todo += [(n, golden_bytes(n + ".naf"), {}) for n in ("phix", "masked", "CP040672")]
 bad = [n for n, blob, opts in todo if cases.run_product(blob, opts, lib) != cases.run_oracle(blob, opts)]
 bad += cases.fuzz_disagreements(cases.fuzz_cases(seed=7, n=70), lib)      # corrupted archives: no OOB, no silent garbage
+import io
+from nafcodec_amd.decoder import Decoder
+bad += ["text:" + n for n, blob in cases.text_cases(1) if Decoder(io.BytesIO(blob), _lib=lib).to_text() != cases.oracle_text(blob)]
 print("BAD", bad)
 sys.exit(1 if bad else 0)
 """ % (ROOT, os.path.join(ROOT, "tests"), os.path.join(EMU_DIR, "libnafgpu_emu_asan.so"))
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")
     p = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+GOLDEN_TEXT = [("LuxC", "LuxC.faa"), ("masked", "masked.fna"), ("phix", "phix.fastq")]
+
+
+@pytest.mark.parametrize("name,text", GOLDEN_TEXT)
+def test_text_output_equals_the_reference_fixture_texts(emu, name, text):
+    """nafgpu_format_device pinned on the source texts the reference's fixtures were made from."""
+    from nafcodec_amd.decoder import Decoder
+    want = golden_bytes(text)
+    if not want.endswith(b"\n"):
+        want += b"\n"                                   # masked.fna lacks the final newline
+    got = Decoder(io.BytesIO(golden_bytes(name + ".naf")), **({'_lib': emu})).to_text()
+    assert got == want
+
+
+def test_text_output_matches_oracle_records(emu):
+    from nafcodec_amd.decoder import Decoder
+    for name, blob in cases.text_cases(scale=1):
+        assert Decoder(io.BytesIO(blob), **({'_lib': emu})).to_text() == cases.oracle_text(blob), name
+    # field selection: no comments in the names, no quality -> FASTA of a FASTQ archive
+    name, blob = cases.text_cases(scale=1)[-1]
+    assert Decoder(io.BytesIO(blob), comment=False, quality=False, **({'_lib': emu})).to_text() == \
+        cases.oracle_text(blob, {"comment": False, "quality": False})
+
+
+def test_device_string_tables_and_utf8_flags(emu):
+    """CStringReader on the device (offsets past each NUL) and the UTF-8 verdict per text section."""
+    import numpy as np
+    import naf_writer as nw
+    from nafcodec_amd.decoder import Decoder
+    from oracle import oracle
+    blob = golden_bytes("phix.naf")
+    d = Decoder(io.BytesIO(blob), **({'_lib': emu}))
+    res = d.decode_all_device()
+    recs = list(oracle.Decoder(blob))
+    assert (res.n_ids, res.n_comments, res.utf8_invalid) == (len(recs), len(recs), 0)
+    ends = np.frombuffer(d.copy_to_host(res.d_id_end, 8 * res.n_ids), dtype=np.uint64)
+    assert list(ends) == list(np.cumsum([len(r.id.encode()) + 1 for r in recs]))
+    ends = np.frombuffer(d.copy_to_host(res.d_comment_end, 8 * res.n_comments), dtype=np.uint64)
+    assert list(ends) == list(np.cumsum([len(r.comment.encode()) + 1 for r in recs]))
+    recs = [{"id": "a", "comment": "x", "sequence": "ACGT"}, {"id": "b", "comment": "y", "sequence": "AC"}]
+    for section, bit, payload in (("ids", 0, b"a\xff\x00b\x00"), ("comments", 1, b"x\x00\xe0\x80\x80\x00"),
+                                  ("ids", 0, b"a\x00b\xc3\x00"), ("comments", 1, b"\xed\xa0\x80\x00y\x00")):
+        bad = nw.write_naf(recs, raw_sections={section: payload})
+        assert Decoder(io.BytesIO(bad), **({'_lib': emu})).decode_all_device().utf8_invalid == 1 << bit, (section, payload)
+    good = nw.write_naf(recs, raw_sections={"comments": "é\u20ac\U0001F600\x00y\x00".encode()})
+    assert Decoder(io.BytesIO(good), **({'_lib': emu})).decode_all_device().utf8_invalid == 0

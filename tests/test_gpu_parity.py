@@ -8,6 +8,7 @@ import io
 import numpy as np
 import pytest
 
+import cases
 import zstd_ref
 from conftest import golden_bytes
 from oracle import oracle
@@ -182,3 +183,51 @@ def test_block_range_sharding(lib):
     import cases
     cases.check_sharding(None, 40_000_001, True, worlds=(2, 8))
     cases.check_sharding(None, 3_000_001, False, worlds=(3,))
+
+
+GOLDEN_TEXT = [("LuxC", "LuxC.faa"), ("masked", "masked.fna"), ("phix", "phix.fastq")]
+
+
+@pytest.mark.parametrize("name,text", GOLDEN_TEXT)
+def test_text_output_equals_the_reference_fixture_texts(lib, name, text):
+    """nafgpu_format_device pinned on the source texts the reference's fixtures were made from."""
+    from nafcodec_amd.decoder import Decoder
+    want = golden_bytes(text)
+    if not want.endswith(b"\n"):
+        want += b"\n"                                   # masked.fna lacks the final newline
+    got = Decoder(io.BytesIO(golden_bytes(name + ".naf")), **({})).to_text()
+    assert got == want
+
+
+def test_text_output_matches_oracle_records(lib):
+    from nafcodec_amd.decoder import Decoder
+    for name, blob in cases.text_cases(scale=4):
+        assert Decoder(io.BytesIO(blob), **({})).to_text() == cases.oracle_text(blob), name
+    # field selection: no comments in the names, no quality -> FASTA of a FASTQ archive
+    name, blob = cases.text_cases(scale=1)[-1]
+    assert Decoder(io.BytesIO(blob), comment=False, quality=False, **({})).to_text() == \
+        cases.oracle_text(blob, {"comment": False, "quality": False})
+
+
+def test_device_string_tables_and_utf8_flags(lib):
+    """CStringReader on the device (offsets past each NUL) and the UTF-8 verdict per text section."""
+    import numpy as np
+    import naf_writer as nw
+    from nafcodec_amd.decoder import Decoder
+    from oracle import oracle
+    blob = golden_bytes("phix.naf")
+    d = Decoder(io.BytesIO(blob), **({}))
+    res = d.decode_all_device()
+    recs = list(oracle.Decoder(blob))
+    assert (res.n_ids, res.n_comments, res.utf8_invalid) == (len(recs), len(recs), 0)
+    ends = np.frombuffer(d.copy_to_host(res.d_id_end, 8 * res.n_ids), dtype=np.uint64)
+    assert list(ends) == list(np.cumsum([len(r.id.encode()) + 1 for r in recs]))
+    ends = np.frombuffer(d.copy_to_host(res.d_comment_end, 8 * res.n_comments), dtype=np.uint64)
+    assert list(ends) == list(np.cumsum([len(r.comment.encode()) + 1 for r in recs]))
+    recs = [{"id": "a", "comment": "x", "sequence": "ACGT"}, {"id": "b", "comment": "y", "sequence": "AC"}]
+    for section, bit, payload in (("ids", 0, b"a\xff\x00b\x00"), ("comments", 1, b"x\x00\xe0\x80\x80\x00"),
+                                  ("ids", 0, b"a\x00b\xc3\x00"), ("comments", 1, b"\xed\xa0\x80\x00y\x00")):
+        bad = nw.write_naf(recs, raw_sections={section: payload})
+        assert Decoder(io.BytesIO(bad), **({})).decode_all_device().utf8_invalid == 1 << bit, (section, payload)
+    good = nw.write_naf(recs, raw_sections={"comments": "é\u20ac\U0001F600\x00y\x00".encode()})
+    assert Decoder(io.BytesIO(good), **({})).decode_all_device().utf8_invalid == 0

@@ -829,10 +829,102 @@ __global__ __launch_bounds__(256) void k_fmt_sizes(FmtArgs a, uint64_t *sizes) {
 
 constexpr uint32_t kFmtChunk = 16u << 10;    // text bytes per workgroup step
 
+__device__ inline uint4 load16u(const uint8_t *p) {       // one global_load_dwordx4 at any alignment
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
+// one record's share [t0, t1) of a chunk, written by `nthr` threads (this one is number `me`):
+// 16-byte aligned granules as one uint4 store each -- a plain unaligned 16-byte copy inside a
+// sequence / quality line, two such loads merged around the line feed where a FASTA line ends --
+// and single characters for the header, the record's last line and the unaligned edges.
+__device__ inline void fmt_record_part(const FmtArgs &a, const FmtRec &r, uint8_t *dst, uint64_t t0, uint64_t t1, uint32_t me,
+                                       uint32_t nthr) {
+    const uint64_t size = r.hdr + r.body;
+    const uint64_t L = a.line_length ? a.line_length : r.n;        // characters per full line
+    const uint64_t Lp = L + 1;
+    auto char_at = [&](uint64_t t) -> uint32_t {
+        if (t < r.hdr) {
+            if (t == 0) return a.qual ? '@' : '>';
+            if (t <= r.id_len) return a.ids[r.id0 + t - 1];
+            if (t == r.hdr - 1) return '\n';
+            if (t == r.id_len + 1) return a.sep;
+            return a.com[r.com0 + t - r.id_len - 2];
+        }
+        const uint64_t q = t - r.hdr;
+        if (a.qual) {
+            if (q < r.n) return a.seq[r.s0 + q];
+            if (q == r.n) return '\n';
+            if (q == r.n + 1) return '+';
+            if (q == r.n + 2) return '\n';
+            if (q < 2 * r.n + 3) return a.qual[r.s0 + q - r.n - 3];
+            return '\n';
+        }
+        const uint64_t line = q / Lp, col = q - line * Lp;
+        if (col == L || q == r.body - 1) return '\n';
+        return a.seq[r.s0 + line * L + col];
+    };
+    const uint64_t mis = (16 - (reinterpret_cast<uintptr_t>(dst + t0) & 15)) & 15;
+    const uint64_t a0 = t0 + (mis < t1 - t0 ? mis : t1 - t0);
+    const uint64_t n_g = (t1 - a0) >> 4, tail0 = a0 + 16 * n_g;
+    for (uint64_t x = t0 + me; x < a0; x += nthr) dst[x] = static_cast<uint8_t>(char_at(x));
+    for (uint64_t x = tail0 + me; x < t1; x += nthr) dst[x] = static_cast<uint8_t>(char_at(x));
+    // line / column of the first body granule, once; the granules then work with 32-bit offsets from it
+    const uint64_t g_body = a0 >= r.hdr ? 0 : (r.hdr - a0 + 15) >> 4;     // first granule that starts inside the body
+    const uint64_t q0 = a0 + 16 * g_body - r.hdr;
+    const bool fasta_fast = !a.qual && L >= 16 && Lp < (1ull << 31);
+    const uint64_t line0 = fasta_fast ? q0 / Lp : 0;
+    const uint32_t col0 = fasta_fast ? static_cast<uint32_t>(q0 - line0 * Lp) : 0, Lp32 = static_cast<uint32_t>(Lp);
+    for (uint64_t g = me; g < n_g; g += nthr) {
+        const uint64_t t = a0 + 16 * g;
+        uint4 w;
+        bool done = false;
+        if (g >= g_body && t + 16 <= size) {
+            const uint64_t q = t - r.hdr;
+            if (a.qual) {
+                if (q + 16 <= r.n) {
+                    w = load16u(a.seq + r.s0 + q);
+                    done = true;
+                } else if (q >= r.n + 3 && q + 16 <= 2 * r.n + 3) {
+                    w = load16u(a.qual + r.s0 + q - r.n - 3);
+                    done = true;
+                }
+            } else if (fasta_fast && q + 16 <= r.body - 1) {     // at most one line feed inside, and not the record's last
+                const uint32_t cq = col0 + static_cast<uint32_t>(16 * (g - g_body));
+                const uint32_t dl = cq / Lp32, col = cq - dl * Lp32;
+                const uint8_t *src = a.seq + r.s0 + (line0 + dl) * L + col;
+                const uint32_t k = static_cast<uint32_t>(L) - col;       // the line feed is byte k of this granule (if k < 16)
+                if (k >= 16) {
+                    w = load16u(src);
+                } else {
+                    const uint4 p0 = load16u(src), p1 = load16u(src - 1);  // bytes after the line feed come from one byte earlier
+                    const uint32_t a0w[4] = {p0.x, p0.y, p0.z, p0.w}, a1w[4] = {p1.x, p1.y, p1.z, p1.w};
+                    uint32_t o[4];
+#pragma unroll
+                    for (uint32_t d = 0; d < 4; d++) {
+                        const uint32_t below = k <= 4 * d ? 0u : (k >= 4 * d + 4 ? 0xFFFFFFFFu : (1u << (8 * (k - 4 * d))) - 1u);
+                        const uint32_t at = (k >= 4 * d && k < 4 * d + 4) ? 0xFFu << (8 * (k - 4 * d)) : 0u;
+                        o[d] = (a0w[d] & below) | (0x0A0A0A0Au & at) | (a1w[d] & ~(below | at));
+                    }
+                    w = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+                done = true;
+            }
+        }
+        if (!done) {
+            uint32_t o[4] = {0, 0, 0, 0};
+            for (uint32_t i = 0; i < 16; i++) o[i >> 2] |= char_at(t + i) << (8 * (i & 3));
+            w = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        *reinterpret_cast<uint4 *>(dst + t) = w;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_fmt_write(FmtArgs a, const uint64_t *__restrict__ off, uint64_t n_text, uint8_t *text) {
     // A workgroup takes 16 KiB of text at a time: one binary search for the record its first byte
-    // belongs to, then record by record (uniformly) until the chunk is full; every thread produces
-    // four consecutive characters per step and stores them as one dword where it can.
+    // belongs to.  A chunk inside one long record is written by the whole workgroup; a chunk holding
+    // many short records (reads) is shared out record by record over the four waves.
     const uint32_t tid = threadIdx.x;
     const uint64_t n_chunks = (n_text + kFmtChunk - 1) / kFmtChunk;
     for (uint64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
@@ -845,68 +937,13 @@ __global__ __launch_bounds__(256) void k_fmt_write(FmtArgs a, const uint64_t *__
             else
                 hi = mid;
         }
-        for (uint64_t k = lo; k < a.n_rec && off[k] < c1; k++) {
+        const bool one = lo + 1 >= a.n_rec || off[lo + 1] >= c1;      // uniform
+        const uint32_t me = one ? tid : tid & 63, nthr = one ? 256 : 64;
+        for (uint64_t k = lo + (one ? 0 : tid >> 6); k < a.n_rec && off[k] < c1; k += one ? 1 : 4) {
             const FmtRec r = fmt_record(a, k);
             const uint64_t base = off[k], size = r.hdr + r.body;
-            const uint64_t t0 = c0 > base ? c0 - base : 0, t1 = c1 - base < size ? c1 - base : size;   // text range of this record in the chunk
-            const uint64_t Lp = a.line_length ? a.line_length + 1 : r.n + 1;
-            auto char_at = [&](uint64_t t) -> uint32_t {
-                if (t < r.hdr) {
-                    if (t == 0) return a.qual ? '@' : '>';
-                    if (t <= r.id_len) return a.ids[r.id0 + t - 1];
-                    if (t == r.hdr - 1) return '\n';
-                    if (t == r.id_len + 1) return a.sep;
-                    return a.com[r.com0 + t - r.id_len - 2];
-                }
-                const uint64_t q = t - r.hdr;
-                if (a.qual) {
-                    if (q < r.n) return a.seq[r.s0 + q];
-                    if (q == r.n) return '\n';
-                    if (q == r.n + 1) return '+';
-                    if (q == r.n + 2) return '\n';
-                    if (q < 2 * r.n + 3) return a.qual[r.s0 + q - r.n - 3];
-                    return '\n';
-                }
-                const uint64_t line = q / Lp, col = q - line * Lp;
-                if (col == Lp - 1 || q == r.body - 1) return '\n';
-                return a.seq[r.s0 + line * (Lp - 1) + col];
-            };
-            uint8_t *dst = text + base;
-            // head: up to the first 4-byte aligned address; then dwords; then the tail
-            const uint64_t a0 = (reinterpret_cast<uintptr_t>(dst + t0) & 3) ? ((t0 + 4 - (reinterpret_cast<uintptr_t>(dst + t0) & 3)) < t1
-                                                                                   ? t0 + 4 - (reinterpret_cast<uintptr_t>(dst + t0) & 3)
-                                                                                   : t1)
-                                                                            : t0;
-            if (tid < a0 - t0) dst[t0 + tid] = static_cast<uint8_t>(char_at(t0 + tid));
-            const uint64_t n_dw = (t1 - a0) >> 2;
-            for (uint64_t d = tid; d < n_dw; d += 256) {
-                const uint64_t t = a0 + 4 * d;
-                uint32_t w;
-                if (t >= r.hdr && !a.qual && t + 4 <= size) {      // FASTA body: one division per four characters
-                    const uint64_t q = t - r.hdr;
-                    const uint64_t line = q / Lp;
-                    uint64_t col = q - line * Lp;
-                    uint64_t src = r.s0 + line * (Lp - 1) + col;
-                    w = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        uint32_t c;
-                        if (col == Lp - 1 || q + j == r.body - 1) {
-                            c = '\n';
-                            col = 0;
-                        } else {
-                            c = a.seq[src++];
-                            col++;
-                        }
-                        w |= c << (8 * j);
-                    }
-                } else {
-                    w = char_at(t) | (char_at(t + 1) << 8) | (char_at(t + 2) << 16) | (char_at(t + 3) << 24);
-                }
-                *reinterpret_cast<uint32_t *>(dst + t) = w;
-            }
-            const uint64_t tail0 = a0 + 4 * n_dw;
-            if (tid < t1 - tail0) dst[tail0 + tid] = static_cast<uint8_t>(char_at(tail0 + tid));
+            const uint64_t t0 = c0 > base ? c0 - base : 0, t1 = c1 - base < size ? c1 - base : size;
+            if (t1 > t0) fmt_record_part(a, r, text + base, t0, t1, me, nthr);
         }
     }
 }

@@ -100,6 +100,23 @@ public:
         if (r.has_length) out.length = r.length;
         return out;
     }
+    // The whole archive as FASTA (FASTQ when it has qualities and `quality` is selected), formatted on
+    // the GPU from the decoded buffers (nafgpu_format_device) and copied to the host: what `unnaf` prints.
+    std::string to_text() {
+        nafgpu_text_result t;
+        if (nafgpu_format_device(d_, &t) != NAFGPU_OK) {
+            nafgpu_error e;
+            nafgpu_last_error(d_, &e);
+            throw Error(e);
+        }
+        std::string out(static_cast<size_t>(t.n_text), '\0');
+        if (t.n_text && nafgpu_copy_to_host(d_, t.d_text, t.n_text, out.data()) != NAFGPU_OK) {
+            nafgpu_error e;
+            nafgpu_last_error(d_, &e);
+            throw Error(e);
+        }
+        return out;
+    }
     nafgpu_decoder *raw() const { return d_; }
 
 private:

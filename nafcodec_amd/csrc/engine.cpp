@@ -137,17 +137,25 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
         return Failure::io(NAFGPU_IO_INVALID_DATA, "zstd: decoded size differs from the size recorded in the archive");
     out0_ = plan_.sharded ? plan_.shard_out0 : 0;
     out1_ = plan_.sharded ? plan_.shard_out1 : expect_size;
-    max_tbl_direct_ = max_tbl_lit_ = 0;
+    // four launch classes: {section output, literal buffer} x {8-byte tables, compact tables}; tasks are stored in that order
     n_direct_tasks_ = plan_.n_direct_tasks;
-    for (size_t i = 0; i < plan_.tasks.size(); i++) {
-        const HufTask &t = plan_.tasks[i];
-        uint32_t e = 0;
-        for (uint32_t k = 0; k < t.n_copies; k++) {
-            const HufTblCopy &c = plan_.tbl_copies[t.first_copy + k];
-            e = std::max(e, c.lds_off + c.n_entries);
+    class_first_[0] = 0;
+    class_count_[0] = plan_.n_direct_tasks - plan_.n_direct_compact;
+    class_first_[1] = class_count_[0];
+    class_count_[1] = plan_.n_direct_compact;
+    class_first_[2] = plan_.n_direct_tasks;
+    class_count_[2] = static_cast<uint32_t>(plan_.tasks.size()) - plan_.n_direct_tasks - plan_.n_lit_compact;
+    class_first_[3] = class_first_[2] + class_count_[2];
+    class_count_[3] = plan_.n_lit_compact;
+    for (int c = 0; c < 4; c++) {
+        class_max_tbl_[c] = 0;
+        for (uint32_t i = class_first_[c]; i < class_first_[c] + class_count_[c]; i++) {
+            const HufTask &t = plan_.tasks[i];
+            for (uint32_t k = 0; k < t.n_copies; k++) {
+                const HufTblCopy &cp = plan_.tbl_copies[t.first_copy + k];
+                class_max_tbl_[c] = std::max(class_max_tbl_[c], cp.lds_off + cp.n_entries);
+            }
         }
-        uint32_t &m = i < n_direct_tasks_ ? max_tbl_direct_ : max_tbl_lit_;
-        m = std::max(m, e);
     }
     bool ok = d_out_.alloc(static_cast<size_t>(out_bytes()) + 64) && d_status_.alloc(64) &&
               d_blk_size_.upload(plan_.blk_size.data(), n_blocks_ * sizeof(uint32_t), stream) &&
@@ -201,19 +209,13 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer) {
     launch_copy_fill(stream, d_src_, d_copies_.as<CopyTask>(), static_cast<uint32_t>(n_copies_),
                      d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(), ascii, t_char_, status);
     if (timer) timer->end(stream);
-    if (n_direct_tasks_) {                                   // streams of literal-only blocks: straight to the output
+    for (int c = 0; c < 4; c++) {        // classes 0/1: streams of literal-only blocks, straight to the output; 2/3: to the literal buffer
+        if (!class_count_[c]) continue;
         if (timer) timer->begin(stream, StageTimer::kHuf);
-        launch_huf_decode(stream, d_src_, d_tasks_.as<HufTask>(), n_direct_tasks_, d_tbl_copies_.as<HufTblCopy>(),
-                          d_streams_.as<HufStream>(), d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), out_base,
-                          d_lit_.bytes(), max_tbl_direct_, ascii, t_char_, status);
-        if (timer) timer->end(stream);
-    }
-    if (n_tasks_ > n_direct_tasks_) {                        // streams of blocks with sequences: to the literal buffer
-        if (timer) timer->begin(stream, StageTimer::kHuf);
-        launch_huf_decode(stream, d_src_, d_tasks_.as<HufTask>() + n_direct_tasks_,
-                          static_cast<uint32_t>(n_tasks_ - n_direct_tasks_), d_tbl_copies_.as<HufTblCopy>(),
-                          d_streams_.as<HufStream>(), d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), out_base,
-                          d_lit_.bytes(), max_tbl_lit_, false, t_char_, status);
+        launch_huf_decode(stream, d_src_, d_tasks_.as<HufTask>() + class_first_[c], class_count_[c],
+                          d_tbl_copies_.as<HufTblCopy>(), d_streams_.as<HufStream>(), d_pool_.as<uint16_t>(),
+                          d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(), class_max_tbl_[c], (c & 1) != 0, c < 2 && ascii,
+                          t_char_, status);
         if (timer) timer->end(stream);
     }
     if (n_seq_blocks_) {

@@ -112,7 +112,8 @@ private:
     uint64_t lz_residue_ = 0;
     uint64_t out0_ = 0, out1_ = 0;
     uint64_t expect_ = 0, n_blocks_ = 0, n_streams_ = 0, n_tasks_ = 0, n_copies_ = 0, n_seq_blocks_ = 0;
-    uint32_t max_tbl_direct_ = 0, max_tbl_lit_ = 0, n_direct_tasks_ = 0, t_char_ = 0;
+    uint32_t class_first_[4] = {0, 0, 0, 0}, class_count_[4] = {0, 0, 0, 0}, class_max_tbl_[4] = {0, 0, 0, 0};
+    uint32_t n_direct_tasks_ = 0, t_char_ = 0;
     const uint8_t *d_src_ = nullptr;
     float plan_ms_ = 0;
     bool ready_ = false;

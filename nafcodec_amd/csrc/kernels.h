@@ -67,10 +67,11 @@ void launch_copy_fill(hipStream_t stream, const uint8_t *src, const CopyTask *ta
                       uint32_t *status);
 
 // K1: Huffman literal streams, one lane per stream, one wave per task.
-// max_tbl_entries = largest staged-table footprint over the tasks (sizes the dynamic LDS).
+// max_tbl_entries = largest staged-table footprint over the tasks (sizes the dynamic LDS);
+// compact = the tasks use 4-byte table entries (plan.h: HufTask).
 void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *tasks, uint32_t n_tasks,
                        const HufTblCopy *copies, const HufStream *streams, const uint16_t *pool,
-                       const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t max_tbl_entries, bool ascii,
+                       const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t max_tbl_entries, bool compact, bool ascii,
                        uint32_t t_char, uint32_t *status);
 
 // K4: LZ77 sequence execution: repeat-offset chain, parallel literal scatter, multi-pass match

@@ -109,7 +109,7 @@ __device__ inline void huf_advance(HufLane &L, const uint8_t *ring_bytes, uint32
     L.nw = *reinterpret_cast<const uint32_t *>(ring_bytes + L.ra);
 }
 
-template <bool ASCII>
+template <bool ASCII, bool T4>
 __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ src, const HufTask *__restrict__ tasks,
                                                    const HufTblCopy *__restrict__ copies,
                                                    const HufStream *__restrict__ streams,
@@ -125,9 +125,14 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     __shared__ uint32_t s_q[64];       // row coordinate of the next write
     __shared__ uint32_t s_fl[64];      // row coordinate of the row's byte 0 (multiple of kUnit)
 
+    // compact tables (T4): characters of a packed byte, shared by all the trees of the task
+    __shared__ uint16_t s_lut[(T4 && ASCII) ? 256 : 2];
+
     if (status[0] != 0) return;
     const uint32_t lane = threadIdx.x;
     const HufTask task = tasks[blockIdx.x];
+    if (T4 && ASCII)
+        for (uint32_t i = lane; i < 256; i += 64) s_lut[i] = static_cast<uint16_t>(byte_chars(i, t_char));
 
     // ---- stage the task's tables: 2^W two-symbol entries with the output bytes baked in; W-bit
     // prefixes whose first code is longer than W bits point to a 2^(max_bits - W) entry sub-table
@@ -136,6 +141,7 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         const uint32_t mb = cp.bits & 0xFFu, W = cp.bits >> 8;
         const uint16_t *x1 = pool + cp.pool_off;           // 2^mb entries of len << 8 | sym
         uint2 *t = s_tbl + cp.lds_off;
+        uint32_t *t4 = reinterpret_cast<uint32_t *>(s_tbl) + cp.lds_off;   // compact format: sym1 | sym2 << 8 | bits << 16 | bits of sym1 << 20 | two << 24 | escape << 25
         const uint32_t mbx = mb > W ? mb : W;              // bits that index x1 (zero-extended if mb < W)
         uint32_t n_esc = 0;
         for (uint32_t i = lane; i < (1u << W); i += 64) {
@@ -152,14 +158,23 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
                 const uint32_t two = l1 + l2 <= W ? 1u : 0u;
                 const uint32_t o1 = ASCII ? byte_chars(e1 & 0xFFu, t_char) : (e1 & 0xFFu);
                 const uint32_t o2 = ASCII ? byte_chars(e2 & 0xFFu, t_char) : (e2 & 0xFFu);
-                t[i] = make_uint2(o1 | (o2 << 16), (two ? l1 + l2 : l1) | (((1u + two) * kOutB) << 8) | (l1 << 16) | (two << 24));
+                if (T4)
+                    t4[i] = (e1 & 0xFFu) | ((e2 & 0xFFu) << 8) | ((two ? l1 + l2 : l1) << 16) | (l1 << 20) | (two << 24);
+                else
+                    t[i] = make_uint2(o1 | (o2 << 16), (two ? l1 + l2 : l1) | (((1u + two) * kOutB) << 8) | (l1 << 16) | (two << 24));
             } else {
                 const uint32_t sub = (1u << W) + (rank << (mbx - W));
-                t[i] = make_uint2(sub, 1u << 25);
+                if (T4)
+                    t4[i] = sub | (1u << 25);
+                else
+                    t[i] = make_uint2(sub, 1u << 25);
                 for (uint32_t j = 0; j < (1u << (mbx - W)); j++) {
                     const uint32_t es = x1[(i << (mbx - W)) | j];
                     const uint32_t o = ASCII ? byte_chars(es & 0xFFu, t_char) : (es & 0xFFu);
-                    t[sub + j] = make_uint2(o, (es >> 8) | (kOutB << 8) | ((es >> 8) << 16));
+                    if (T4)
+                        t4[sub + j] = (es & 0xFFu) | ((es >> 8) << 16) | ((es >> 8) << 20);
+                    else
+                        t[sub + j] = make_uint2(o, (es >> 8) | (kOutB << 8) | ((es >> 8) << 16));
                 }
             }
         }
@@ -178,13 +193,24 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     // one table look-up on the next bits of the stream; rare long codes take a second, sub-table look-up
     // (tasks none of whose trees is deeper than W bits -- the common case -- run a copy of the loop without the test)
     const bool task_esc = __any(esc_bits != 0 ? 1 : 0) != 0;
+    const uint32_t *tbl4 = reinterpret_cast<const uint32_t *>(s_tbl) + st.tbl_lds;
     auto lookup = [&](auto esc) -> uint2 {
         const uint32_t peek = __builtin_amdgcn_alignbit(L.hi, L.lo, L.s);
-        uint2 e = tbl[peek >> sh];
-        if (decltype(esc)::value) {
-            if (e.y & (1u << 25)) e = tbl[e.x + ((peek >> sh2) & esc_mask)];
+        if (!T4) {
+            uint2 e = tbl[peek >> sh];
+            if (decltype(esc)::value) {
+                if (e.y & (1u << 25)) e = tbl[e.x + ((peek >> sh2) & esc_mask)];
+            }
+            return e;
         }
-        return e;
+        // compact entry -> the same {output bytes, bits | bytes << 8 | bits of the first symbol << 16 | two << 24}
+        uint32_t c = tbl4[peek >> sh];
+        if (decltype(esc)::value) {
+            if (c & (1u << 25)) c = tbl4[(c & 0xFFFFu) + ((peek >> sh2) & esc_mask)];
+        }
+        const uint32_t s1 = c & 0xFFu, s2 = (c >> 8) & 0xFFu, two = (c >> 24) & 1u;
+        const uint32_t x = ASCII ? (static_cast<uint32_t>(s_lut[s1]) | (static_cast<uint32_t>(s_lut[s2]) << 16)) : (s1 | (s2 << 16));
+        return make_uint2(x, ((c >> 16) & 15u) | (((1u + two) * kOutB) << 8) | (((c >> 20) & 15u) << 16) | (two << 24));
     };
     uintptr_t ptop = 0;                  // address of the 32-byte piece holding the stream's last byte
     uint32_t wp = 0;                     // 32-byte pieces landed in the ring
@@ -1843,24 +1869,31 @@ void launch_copy_fill(hipStream_t stream, const uint8_t *src, const CopyTask *ta
 
 void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *tasks, uint32_t n_tasks,
                        const HufTblCopy *copies, const HufStream *streams, const uint16_t *pool,
-                       const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t max_tbl_entries, bool ascii,
+                       const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t max_tbl_entries, bool compact, bool ascii,
                        uint32_t t_char, uint32_t *status) {
     if (!n_tasks) return;
     static const uint32_t lds_pad = [] {                  // occupancy experiments: extra dynamic LDS per workgroup
         const char *e = std::getenv("NAFGPU_K1_LDS_PAD");
         return e ? static_cast<uint32_t>(std::atoi(e)) : 0u;
     }();
-    const uint32_t lds = (((max_tbl_entries * 8u) + 15u) & ~15u) + lds_pad;
+    const uint32_t lds = (((max_tbl_entries * (compact ? 4u : 8u)) + 15u) & ~15u) + lds_pad;
     static const uint32_t dbg = [] {                     // timing ablations only; results are wrong when set
         const char *e = std::getenv("NAFGPU_K1_DEBUG");
         return e ? static_cast<uint32_t>(std::atoi(e)) : 0u;
     }();
-    if (ascii && !(dbg & 2u))
-        hipLaunchKernelGGL(k_huf_decode<true>, dim3(n_tasks), dim3(64), lds, stream, src, tasks, copies, streams, pool,
-                           blk_base, out, lit, t_char, dbg, status);
+    const bool a = ascii && !(dbg & 2u);
+#define NAFGPU_LAUNCH_HUF(A, T)                                                                                              \
+    hipLaunchKernelGGL((k_huf_decode<A, T>), dim3(n_tasks), dim3(64), lds, stream, src, tasks, copies, streams, pool, blk_base, \
+                       out, lit, t_char, dbg, status)
+    if (a && !compact)
+        NAFGPU_LAUNCH_HUF(true, false);
+    else if (a)
+        NAFGPU_LAUNCH_HUF(true, true);
+    else if (!compact)
+        NAFGPU_LAUNCH_HUF(false, false);
     else
-        hipLaunchKernelGGL(k_huf_decode<false>, dim3(n_tasks), dim3(64), lds, stream, src, tasks, copies, streams, pool,
-                           blk_base, out, lit, t_char, dbg, status);
+        NAFGPU_LAUNCH_HUF(false, true);
+#undef NAFGPU_LAUNCH_HUF
 }
 
 template <bool ASCII>

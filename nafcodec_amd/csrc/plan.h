@@ -8,7 +8,8 @@ namespace nafgpu {
 
 constexpr uint32_t kBlockMax = 128u << 10;   // zstd Block_Maximum_Size
 constexpr int kHufWave = 64;                 // one Huffman stream per lane, one wave per workgroup
-constexpr uint32_t kHufLdsEntries = 2048;    // 8-byte decode-table entries a wave task may stage in LDS
+constexpr uint32_t kHufLdsEntries = 2048;    // 8-byte decode-table entries a single-tree wave task may stage in LDS
+constexpr uint32_t kHufLdsEntries4 = 6144;   // 4-byte entries a task with several trees may stage (compact tables, see HufTask)
 constexpr uint32_t kHufTaskSpan = 1u << 30;   // a wave task's streams lie within this many bytes of input and of output
 constexpr uint32_t kSrcFrontPad = 512;       // bytes readable in front of any device source buffer (k_huf_decode: ring look-ahead + whole lines)
 constexpr uint32_t kSrcBackPad = 256;        // ... and behind it (k_huf_decode reads whole 128-byte lines)
@@ -33,7 +34,12 @@ struct HufTblCopy {      // build the two-symbol table of pool[pool_off ..) at L
     uint32_t bits;       // max_bits | W << 8
 };
 
-struct HufTask {         // one workgroup of k_huf_decode: <= 64 streams, tables <= kHufLdsEntries
+// One workgroup of k_huf_decode: <= 64 streams and the decode tables of their trees.  Tasks come in two
+// table formats, launched separately: 8-byte entries with the output characters baked in (one tree:
+// the fast path) and compact 4-byte entries {sym1, sym2, bits, bits of sym1, two} whose characters
+// come from a 512-byte look-up table shared by the wave (several trees: what counts there is LDS per
+// lane, because the lanes resident per CU set the throughput).
+struct HufTask {
     uint32_t first_stream, n_streams, first_copy, n_copies;
 };
 

@@ -681,6 +681,7 @@ struct Walker {
                 }
                 uint32_t W = 8;
                 std::vector<HufRef> distinct;
+                bool compact = false;
                 for (;;) {
                     distinct.clear();
                     for (size_t k = s; k < e; k++) {
@@ -688,11 +689,14 @@ struct Walker {
                         for (const HufRef &d : distinct) seen = seen || d.pool_off == stream_tbl[k].pool_off;
                         if (!seen) distinct.push_back(stream_tbl[k]);
                     }
+                    // several trees: compact 4-byte entries and a larger entry budget, so that the task keeps 64 lanes
+                    compact = distinct.size() > 1;
+                    const uint32_t budget = compact ? kHufLdsEntries4 : kHufLdsEntries;
                     bool fits = false;
                     for (W = 8; W >= 6; W--) {
                         uint32_t total = 0;
                         for (const HufRef &d : distinct) total += staged_entries(d, W);
-                        if (total <= kHufLdsEntries) {
+                        if (total <= budget) {
                             fits = true;
                             break;
                         }
@@ -721,6 +725,7 @@ struct Walker {
                     hs.flags = static_cast<uint8_t>((hs.flags & 0x0F) | (esc_bits << 4));
                 }
                 plan->tasks.push_back(task);
+                task_compact.push_back(compact ? 1 : 0);
                 s = e;
             }
         };
@@ -729,7 +734,18 @@ struct Walker {
         pack_group(0, first_lit);
         plan->n_direct_tasks = static_cast<uint32_t>(plan->tasks.size());
         pack_group(first_lit, plan->streams.size());
+        // inside each group: tasks with 8-byte tables first, compact ones last (the two are launched separately)
+        auto partition = [&](size_t t0, size_t t1) -> uint32_t {
+            std::vector<HufTask> a, b;
+            for (size_t t = t0; t < t1; t++) (task_compact[t] ? b : a).push_back(plan->tasks[t]);
+            std::copy(a.begin(), a.end(), plan->tasks.begin() + static_cast<std::ptrdiff_t>(t0));
+            std::copy(b.begin(), b.end(), plan->tasks.begin() + static_cast<std::ptrdiff_t>(t0 + a.size()));
+            return static_cast<uint32_t>(b.size());
+        };
+        plan->n_direct_compact = partition(0, plan->n_direct_tasks);
+        plan->n_lit_compact = partition(plan->n_direct_tasks, plan->tasks.size());
     }
+    std::vector<uint8_t> task_compact;   // per task (in packing order): compact tables?
 };
 
 }  // namespace

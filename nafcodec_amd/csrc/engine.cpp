@@ -249,7 +249,7 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer) {
         launch_lz_execute(stream, la, ascii);
         // What the fixed number of passes could not resolve (dependency chains as long as the frame:
         // quality strings, tandem repeats).  The host needs the count to size the scratch memory.
-        unsigned long long cnt[2] = {0, 0};
+        unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         uint32_t st_now = 1;
         lz_residue_ = 0;
         if (hip_ok(hipMemcpyAsync(cnt, la.counters, sizeof cnt, hipMemcpyDeviceToHost, stream)) &&
@@ -259,21 +259,28 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer) {
             lz_residue_ = n_pending;
             uint32_t *changed = reinterpret_cast<uint32_t *>(la.counters + 2);
             bool done = false;
-            if (d_pj_list_.alloc(n_pending * sizeof(uint64_t)) && d_pj_dist_.alloc(static_cast<size_t>(expect_) * sizeof(uint32_t) + 16)) {
+            // the passes' last pending list is exactly what is left (counters[3] names it); without the lists: collect from the flags
+            const uint64_t *plist = nullptr;
+            if (la.plist[0] && la.plist[1] && cnt[3] < 2 && cnt[4 + cnt[3]] == n_pending) plist = la.plist[cnt[3]];
+            if ((plist || d_pj_list_.alloc(n_pending * sizeof(uint64_t))) &&
+                d_pj_dist_.alloc(static_cast<size_t>(expect_) * sizeof(uint32_t) + 16)) {
                 uint32_t *D = d_pj_dist_.as<uint32_t>();
                 (void)hipMemsetAsync(D, 0, static_cast<size_t>(expect_) * sizeof(uint32_t), stream);
-                launch_pj_collect(stream, la, d_pj_list_.as<uint64_t>());
-                launch_pj_step(stream, la, ascii, d_pj_list_.as<uint64_t>(), n_pending, D, 0, changed);
+                if (!plist) {
+                    launch_pj_collect(stream, la, d_pj_list_.as<uint64_t>());
+                    plist = d_pj_list_.as<uint64_t>();
+                }
+                launch_pj_step(stream, la, ascii, plist, n_pending, D, 0, changed);
                 for (int it = 0; it < 64 && !done; it++) {           // chain length halves per step
                     (void)hipMemsetAsync(changed, 0, sizeof(uint32_t), stream);
-                    launch_pj_step(stream, la, ascii, d_pj_list_.as<uint64_t>(), n_pending, D, 1, changed);
+                    launch_pj_step(stream, la, ascii, plist, n_pending, D, 1, changed);
                     uint32_t ch = 1;
                     if (!hip_ok(hipMemcpyAsync(&ch, changed, sizeof ch, hipMemcpyDeviceToHost, stream)) ||
                         !hip_ok(hipStreamSynchronize(stream)))
                         break;
                     done = ch == 0;
                 }
-                if (done) launch_pj_step(stream, la, ascii, d_pj_list_.as<uint64_t>(), n_pending, D, 2, changed);
+                if (done) launch_pj_step(stream, la, ascii, plist, n_pending, D, 2, changed);
             }
             if (!done) launch_lz_ordered(stream, la, ascii);         // no scratch memory / no convergence: frame order
         }

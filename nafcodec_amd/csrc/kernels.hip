@@ -1323,12 +1323,14 @@ __global__ __launch_bounds__(256) void k_lz_match_pass(const SeqBlock *__restric
 // by link than to hand to the pointer-jumping stage, which is for chains as long as the frame.
 __global__ void k_lz_pass_ctl(unsigned long long *counters, uint32_t in, uint32_t out, uint32_t pass) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (counters[6]) return;                               // stopped earlier: counters[3] names the list that holds what is pending
     const unsigned long long now = counters[4 + in];       // pending before the coming pass
     const unsigned long long before = counters[7];         // pending before the previous pass
+    counters[3] = in;                                      // if the passes stop here, list `in` is the pending list
     if (pass >= 3 && now * 200 > before * 199) counters[6] = 1;
     if (now == 0) counters[6] = 1;
     counters[7] = now;
-    counters[4 + out] = 0;
+    if (!counters[6]) counters[4 + out] = 0;
 }
 
 // Passes after the first work from the list of matches that are still pending (entry = seq-block
@@ -1436,8 +1438,6 @@ __global__ __launch_bounds__(256) void k_pj_step(const uint64_t *__restrict__ li
                                                  uint8_t *out_bytes, uint32_t *changed) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
-    __shared__ uint32_t s_long[256];
-    __shared__ uint32_t s_nlong;
     const uint32_t tid = threadIdx.x;
     bool any_change = false;
     auto element = [&](uint64_t p, uint32_t off) {
@@ -1454,29 +1454,15 @@ __global__ __launch_bounds__(256) void k_pj_step(const uint64_t *__restrict__ li
             out[p] = out[p - D[p]];
         }
     };
-    for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * 256; base < n_list; base += static_cast<uint64_t>(gridDim.x) * 256) {
-        if (tid == 0) s_nlong = 0;
-        __syncthreads();
-        if (base + tid < n_list) {
-            const uint64_t g = list[base + tid];
-            const uint32_t ml = seqs[g].ml;
-            if (ml <= kLzShort) {
-                const uint64_t mpos = mdst[g];
-                const uint32_t off = roff[g];
-                for (uint32_t k = 0; k < ml; k++) element(mpos + k, off);
-            } else {
-                s_long[atomicAdd(&s_nlong, 1u)] = tid;
-            }
-        }
-        __syncthreads();
-        const uint32_t nl = s_nlong;
-        for (uint32_t j = 0; j < nl; j++) {
-            const uint64_t g = list[base + s_long[j]];
-            const uint32_t ml = seqs[g].ml, off = roff[g];
-            const uint64_t mpos = mdst[g];
-            for (uint32_t k = tid; k < ml; k += 256) element(mpos + k, off);
-        }
-        __syncthreads();
+    // sixteen lanes per match: consecutive lanes on consecutive elements (64-byte segments of D / out),
+    // sixteen matches per workgroup step; a long match is just more steps of its group
+    const uint32_t grp = tid >> 4, gl = tid & 15;
+    for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * 16; base < n_list; base += static_cast<uint64_t>(gridDim.x) * 16) {
+        if (base + grp >= n_list) continue;
+        const uint64_t g = list[base + grp] & ((1ull << 40) - 1ull);   // a pending-list entry also carries its block index
+        const uint32_t ml = seqs[g].ml, off = roff[g];
+        const uint64_t mpos = mdst[g];
+        for (uint32_t k = gl; k < ml; k += 16) element(mpos + k, off);
     }
     if (OP == kPjJump && any_change) *changed = 1;
 }
@@ -1933,6 +1919,8 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
                            a.plist[ol], cnt + ol, a.seqs, a.mdst, a.cidx, a.flags,
                            a.blk_pending, a.roff, a.counters, a.counters + 6, a.out, pass, a.status);
     }
+    // ran to the end: the last pass's output list is the pending list (counters[3]); harmless when stopped earlier
+    hipLaunchKernelGGL(k_lz_pass_ctl, dim3(1), dim3(1), 0, stream, a.counters, (kLzPasses & 1u) ^ 1u, kLzPasses & 1u, kLzPasses + 1);
 }
 
 void launch_lz_execute(hipStream_t stream, const LzArgs &a, bool ascii) {
@@ -1964,7 +1952,7 @@ void launch_pj_collect(hipStream_t stream, const LzArgs &a, uint64_t *list) {
 template <bool ASCII>
 static void pj_step(hipStream_t stream, const LzArgs &a, const uint64_t *list, uint64_t n_list, uint32_t *D, int op,
                     uint32_t *changed) {
-    uint64_t blocks = (n_list + 255) / 256;
+    uint64_t blocks = (n_list + 15) / 16;             // sixteen matches per workgroup step
     if (blocks > 256u * 16u) blocks = 256u * 16u;
     const dim3 grid(static_cast<uint32_t>(blocks));
     if (op == kPjInit)

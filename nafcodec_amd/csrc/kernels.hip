@@ -490,26 +490,6 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
 // ======================================================================================
 // K2  FSE sequence decode (App. B "Sequence decode loop")
 // ======================================================================================
-struct BackBits {
-    const uint8_t *p;     // first byte of the bitstream
-    int64_t pos;          // unread bits below the cursor (may go negative on corrupt input)
-    __device__ uint32_t read(uint32_t nb) {
-        pos -= nb;
-        if (nb == 0) return 0;
-        int64_t lo = pos;
-        uint32_t lsh = 0;
-        if (lo < 0) {                       // bits below the start read as zero
-            if (lo + static_cast<int64_t>(nb) <= 0) return 0;
-            lsh = static_cast<uint32_t>(-lo);
-            nb -= lsh;
-            lo = 0;
-        }
-        uint64_t v;
-        __builtin_memcpy(&v, p + (lo >> 3), 8);   // one unaligned 8-byte load; the source buffer is padded at the back
-        v >>= (lo & 7);
-        return static_cast<uint32_t>(v & ((1ull << nb) - 1)) << lsh;
-    }
-};
 
 __device__ inline uint32_t rep_minus_one(uint32_t r) {      // rep - 1 for a concrete offset or a token
     return r + ((r & kRepToken) ? 1u : 0xFFFFFFFFu);
@@ -524,15 +504,45 @@ __global__ __launch_bounds__(64) void k_seq_decode(const uint8_t *__restrict__ s
     const SeqBlock sb = blocks[b];
     const uint8_t *bits = src + sb.bits_off;
     const uint32_t lastb = bits[sb.bits_len - 1];   // host checked: non-zero
-    BackBits r{bits, static_cast<int64_t>(sb.bits_len - 1) * 8 + (31 - __clz(static_cast<int>(lastb | 1u)))};
+    // One 16-byte window per sequence: a sequence reads at most 31 + 16 + 16 extra bits and 9 + 9 + 8 state
+    // bits = 89, the window ending at the byte that holds the cursor has > 120 unread bits, and its
+    // address depends on the cursor alone -- so the window load and the three table look-ups of a
+    // sequence are issued together and the dependent chain per sequence is ONE memory latency
+    // (six dependent loads per sequence made this kernel the longest one on FASTQ archives).
+    // Bits below the stream's first bit are whatever precedes it in the archive (readable: kSrcFrontPad);
+    // a stream that reaches them has pos < 0 and is flagged.
+    struct Window {
+        const uint8_t *p;     // first byte of the bitstream
+        int64_t pos;          // unread bits below the cursor (negative: overrun)
+        uint64_t lo, hi;      // bytes [off, off + 16) of the stream, off = ceil(pos / 8) - 16
+        int64_t base;         // 8 * off
+        __device__ void load() {
+            const int64_t off = ((pos + 7) >> 3) - 16;
+            base = off * 8;
+            uint64_t w[2];
+            __builtin_memcpy(w, p + off, 16);
+            lo = w[0];
+            hi = w[1];
+        }
+        __device__ uint32_t read(uint32_t nb) {          // nb <= 31; the window holds the bits [pos - nb, pos)
+            pos -= nb;
+            const uint32_t a = static_cast<uint32_t>(pos - base) & 127u;   // bit index of the field's lowest bit inside the window
+            const uint64_t v = a >= 64 ? hi >> (a - 64) : ((lo >> a) | (a ? hi << (64 - a) : 0ull));
+            return static_cast<uint32_t>(v) & ((1u << nb) - 1u);
+        }
+    };
+    Window r{bits, static_cast<int64_t>(sb.bits_len - 1) * 8 + (31 - __clz(static_cast<int>(lastb | 1u))), 0, 0, 0};
     const SeqCell *tll = cells + sb.ll_tbl, *tof = cells + sb.of_tbl, *tml = cells + sb.ml_tbl;
+    r.load();
     uint32_t sll = r.read(sb.ll_al), sof = r.read(sb.of_al), sml = r.read(sb.ml_al);
     Seq *dst = seqs + sb.seq_first;
     uint64_t sum_ll = 0, sum_ml = 0;
     uint32_t r0 = kRepToken | (0u << 24), r1 = kRepToken | (1u << 24), r2 = kRepToken | (2u << 24);
     bool bad_off = false;
     for (uint32_t i = 0; i < sb.n_seq; i++) {
+        if (r.pos < 0) break;
         const SeqCell cl = tll[sll], co = tof[sof], cm = tml[sml];
+        r.load();
         Seq s;
         const uint32_t ofv = co.base_value + r.read(co.extra_bits);   // extra bits in the order OF, ML, LL
         s.ml = cm.base_value + r.read(cm.extra_bits);

@@ -1,6 +1,9 @@
 // engine.cpp -- see engine.h
 #include "engine.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <chrono>
 #include <cstring>
 
@@ -157,6 +160,10 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
             }
         }
     }
+    if (std::getenv("NAFGPU_DEBUG_PLAN"))
+        std::fprintf(stderr, "[nafgpu] section plan: %zu blocks, %zu streams, tasks {direct8 %u (tbl %u), direct4 %u (tbl %u), lit8 %u (tbl %u), lit4 %u (tbl %u)}, %zu seq blocks\n",
+                     n_blocks_, n_streams_, class_count_[0], class_max_tbl_[0], class_count_[1], class_max_tbl_[1], class_count_[2],
+                     class_max_tbl_[2], class_count_[3], class_max_tbl_[3], n_seq_blocks_);
     bool ok = d_out_.alloc(static_cast<size_t>(out_bytes()) + 64) && d_status_.alloc(64) &&
               d_blk_size_.upload(plan_.blk_size.data(), n_blocks_ * sizeof(uint32_t), stream) &&
               d_blk_base_.alloc((n_blocks_ + 1) * sizeof(uint64_t)) && d_scan_tmp_.alloc(scan_tmp_bytes(n_blocks_)) &&

@@ -180,6 +180,7 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         }
     }
 
+    if (dbg & 512u) return;                                // ablation: table staging only
     const bool have = lane < task.n_streams;
     HufStream st{};
     if (have) st = streams[task.first_stream + lane];

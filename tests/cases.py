@@ -178,6 +178,8 @@ def fuzz_cases(seed=1, n=120):
     seeds.append(nw.write_naf(make_records(rng, [40000]), level=1))
     dense = "".join(rng.choice(list("GGGGGGGJJJJF#"), 30000))
     seeds.append(nw.write_naf([{"id": "q", "sequence": dense}], sequence_type="text", level=3))
+    # three 128 KiB blocks with their own deep Huffman trees: compact decode tables with escape sub-tables
+    seeds.append(nw.write_naf(make_records(rng, [700000, 151], iupac=0.05), level=1))
     out = []
     for it in range(n):
         blob = bytearray(seeds[it % len(seeds)])

@@ -176,8 +176,7 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
               d_cells_.upload(plan_.fse_pool.data(), plan_.fse_pool.size() * sizeof(SeqCell), stream) &&
               d_lit_.alloc(static_cast<size_t>(plan_.lit_bytes) + 64) &&
               d_seqs_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(Seq) + 16) &&
-              d_mdst_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(uint64_t) + 16) &&
-              d_flags_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(uint32_t) + 16) &&
+              d_meta_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(SeqMeta) + 16) &&
               d_rep_final_.alloc(n_seq_blocks_ * 12 + 16) && d_rep_init_.alloc(n_seq_blocks_ * 12 + 16) &&
               d_rep_scratch_.alloc((n_seq_blocks_ / 64 + 1) * 24 + 16) &&
               d_lz_index_.alloc(n_seq_blocks_ && plan_.n_sequences < 0xFFFFFFFFull ? ((static_cast<size_t>(expect_size) >> 7) + 2) * 4 : 0) &&
@@ -245,8 +244,7 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer) {
         la.plist[1] = lists ? d_lz_list_[1].as<uint64_t>() : nullptr;
         la.cidx = plan_.n_sequences < 0xFFFFFFFFull ? d_lz_index_.as<uint32_t>() : nullptr;
         la.n_idx_chunks = (static_cast<uint64_t>(expect_) >> 7) + 2;
-        la.mdst = d_mdst_.as<uint64_t>();
-        la.flags = d_flags_.as<uint32_t>();
+        la.meta = d_meta_.as<SeqMeta>();
         la.blk_pending = d_blk_pending_.as<uint32_t>();
         la.out = out_base;
         la.t_char = t_char_;

@@ -88,8 +88,7 @@ struct LzArgs {
     uint32_t *rep_scratch;       // 6 words per chunk of 64 blocks (k_rep_partial / k_rep_scan)
     uint32_t *cidx;              // sequence index per 128 output elements (null: plain binary search)
     uint64_t n_idx_chunks;       // entries of cidx
-    uint64_t *mdst;              // per sequence: output position of its match
-    uint32_t *flags;             // per sequence: pass in which its match was completed (0 = pending)
+    SeqMeta *meta;               // per sequence: output position and length of its match, pass that completed it (0 = pending)
     uint32_t *blk_pending;       // per block: matches still pending
     uint32_t *roff;              // per sequence: resolved offset of a match that is still pending
     uint64_t *plist[2];          // two lists of pending matches (n_sequences entries each; null: block-wise passes only)

@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(256) void k_rep_apply(const SeqBlock *__restrict__ 
 template <bool ASCII>
 __global__ __launch_bounds__(256) void k_lz_literals(const SeqBlock *__restrict__ blocks, const Seq *__restrict__ seqs,
                                                      const uint8_t *__restrict__ lit, const uint64_t *__restrict__ blk_base,
-                                                     uint64_t *mdst, uint32_t *blk_pending, uint8_t *out_bytes, uint32_t t_char,
+                                                     SeqMeta *meta, uint32_t *blk_pending, uint8_t *out_bytes, uint32_t t_char,
                                                      const uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     __shared__ uint32_t s_long[256];
@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__(256) void k_lz_literals(const SeqBlock *__restrict_
         __syncthreads();
         if (s0 + tid < sb.n_seq) {
             const Seq q = sq[s0 + tid];
-            mdst[sb.seq_first + s0 + tid] = obase + q.opos + q.ll;   // where the match of this sequence starts
+            meta[sb.seq_first + s0 + tid] = SeqMeta{obase + q.opos + q.ll, q.ml, 0u};   // where the match of this sequence starts; pending
             if (q.ll <= kLzShort) {
                 for (uint32_t k = 0; k < q.ll; k++) put(out + q.opos + k, blit[q.lpos + k]);
             } else {
@@ -1192,15 +1192,15 @@ __global__ __launch_bounds__(256) void k_lz_literals(const SeqBlock *__restrict_
 // sequences per pending match and pass)
 constexpr uint32_t kLzIdxShift = 7;
 
-__global__ __launch_bounds__(256) void k_lz_index(const uint64_t *__restrict__ mdst, uint64_t n_seq, uint64_t n_chunks, uint32_t *cidx,
+__global__ __launch_bounds__(256) void k_lz_index(const SeqMeta *__restrict__ meta, uint64_t n_seq, uint64_t n_chunks, uint32_t *cidx,
                                                   const uint32_t *status) {
     if (status[0] != 0) return;
     for (uint64_t c = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; c < n_chunks; c += static_cast<uint64_t>(gridDim.x) * 256) {
         const uint64_t target = c << kLzIdxShift;
-        uint64_t a = 0, b = n_seq;                        // first g with mdst[g] >= target
+        uint64_t a = 0, b = n_seq;                        // first g with meta[g].pos >= target
         while (a < b) {
             const uint64_t mid = (a + b) >> 1;
-            if (mdst[mid] < target)
+            if (meta[mid].pos < target)
                 a = mid + 1;
             else
                 b = mid;
@@ -1210,38 +1210,39 @@ __global__ __launch_bounds__(256) void k_lz_index(const uint64_t *__restrict__ m
 }
 
 // Are all output bytes in [lo, hi) final for a reader in pass `pass`?  Bytes that no match writes
-// are literals (final since k_lz_literals / K1); bytes of match g are final once flags[g] holds an
+// are literals (final since k_lz_literals / K1); bytes of match g are final once meta[g].flag holds an
 // earlier pass number.  mdst[] (match start positions) is sorted: sequences are stored in frame order.
-__device__ inline bool lz_range_final(uint64_t lo, uint64_t hi, const uint64_t *mdst, const Seq *seqs, const uint32_t *flags,
-                                      const uint32_t *cidx, uint64_t g_self, uint32_t pass) {
+__device__ inline bool lz_range_final(uint64_t lo, uint64_t hi, const SeqMeta *meta, const uint32_t *cidx, uint64_t g_self,
+                                      uint32_t pass) {
     if (hi <= lo) return true;
     uint64_t g;
     if (cidx) {                                          // the sequence before the first one of lo's chunk may reach into the range
         const uint64_t f = cidx[lo >> kLzIdxShift];
         g = f ? f - 1 : 0;
     } else {
-        uint64_t a = 0, b = g_self;                      // last g < g_self with mdst[g] <= lo
+        uint64_t a = 0, b = g_self;                      // last g < g_self with meta[g].pos <= lo
         while (a < b) {
             const uint64_t mid = (a + b) >> 1;
-            if (mdst[mid] <= lo)
+            if (meta[mid].pos <= lo)
                 a = mid + 1;
             else
                 b = mid;
         }
         g = a ? a - 1 : 0;
     }
-    for (; g < g_self && mdst[g] < hi; g++) {
-        if (mdst[g] + seqs[g].ml <= lo) continue;        // ends before the range
-        const uint32_t f = flags[g];
-        if (f == 0 || f >= pass) return false;
+    for (; g < g_self; g++) {
+        const SeqMeta m = meta[g];                           // one 16-byte load: position, length and pass stamp of a producer
+        if (m.pos >= hi) break;
+        if (m.pos + m.ml <= lo) continue;                    // ends before the range
+        if (m.flag == 0 || m.flag >= pass) return false;
     }
     return true;
 }
 
 template <bool ASCII>
 __global__ __launch_bounds__(256) void k_lz_match_pass(const SeqBlock *__restrict__ blocks, uint32_t n_blocks,
-                                                       const Seq *__restrict__ seqs, const uint64_t *__restrict__ mdst,
-                                                       const uint32_t *__restrict__ cidx, uint32_t *flags, uint32_t *blk_pending,
+                                                       const Seq *__restrict__ seqs, SeqMeta *meta,
+                                                       const uint32_t *__restrict__ cidx, uint32_t *blk_pending,
                                                        uint32_t *roff, unsigned long long *remaining, const uint32_t *__restrict__ rep_init,
                                                        const uint64_t *__restrict__ blk_base, uint8_t *out_bytes, uint32_t pass,
                                                        uint64_t *plist, unsigned long long *pcount, uint32_t *status) {
@@ -1272,25 +1273,25 @@ __global__ __launch_bounds__(256) void k_lz_match_pass(const SeqBlock *__restric
             __syncthreads();
             const uint64_t g = sb.seq_first + s0 + tid;
             uint32_t my_slot = 0xFFFFFFFFu;                      // position in this step's part of the pending list
-            if (s0 + tid < sb.n_seq && flags[g] == 0) {
+            if (s0 + tid < sb.n_seq && meta[g].flag == 0) {
                 const Seq q = seqs[g];
                 bool bad = false;
                 const uint32_t off = rep_resolve(q.off, init, &bad);
-                const uint64_t mpos = mdst[g];
+                const uint64_t mpos = meta[g].pos;
                 if (bad || off > mpos - fstart) {                // reaches before the frame: corrupt
                     flag_error(status, kStBadOffset, sb.blk);
-                    flags[g] = pass;
+                    meta[g].flag = pass;
                     atomicAdd(&s_ndone, 1u);
                 } else {
                     const uint64_t src = mpos - off;
                     const uint64_t need_hi = src + q.ml < mpos ? src + q.ml : mpos;   // the rest is the match itself
                     roff[g] = off;                               // kept for the pointer-jumping stage
-                    if (lz_range_final(src, need_hi, mdst, seqs, flags, cidx, g, pass)) {
+                    if (lz_range_final(src, need_hi, meta, cidx, g, pass)) {
                         if (q.ml <= kLzShort) {
                             Elem *d = out + mpos;
                             const Elem *s = out + src;
                             for (uint32_t k = 0; k < q.ml; k++) d[k] = s[k];   // byte-serial: overlap allowed
-                            flags[g] = pass;
+                            meta[g].flag = pass;
                             atomicAdd(&s_ndone, 1u);
                         } else {
                             s_long[atomicAdd(&s_nlong, 1u)] = s0 + tid;
@@ -1307,14 +1308,14 @@ __global__ __launch_bounds__(256) void k_lz_match_pass(const SeqBlock *__restric
                 const Seq q = seqs[gi];
                 bool bad = false;
                 const uint32_t off = rep_resolve(q.off, init, &bad);
-                Elem *d = out + mdst[gi];
+                Elem *d = out + meta[gi].pos;
                 const Elem *s = d - off;
                 if (off >= q.ml) {
                     for (uint32_t k = tid; k < q.ml; k += 256) d[k] = s[k];
                 } else {
                     for (uint32_t k = tid; k < q.ml; k += 256) d[k] = s[k % off];   // overlapping: periodic
                 }
-                if (tid == 0) flags[gi] = pass;
+                if (tid == 0) meta[gi].flag = pass;
             }
             __syncthreads();
             if (tid == 0 && (s_ndone + nl)) {
@@ -1350,8 +1351,8 @@ __global__ void k_lz_pass_ctl(unsigned long long *counters, uint32_t in, uint32_
 template <bool ASCII>
 __global__ __launch_bounds__(256) void k_lz_match_list(const uint64_t *__restrict__ lin, const unsigned long long *__restrict__ nin,
                                                        uint64_t *lout, unsigned long long *nout, const Seq *__restrict__ seqs,
-                                                       const uint64_t *__restrict__ mdst, const uint32_t *__restrict__ cidx,
-                                                       uint32_t *flags, uint32_t *blk_pending, const uint32_t *__restrict__ roff,
+                                                       SeqMeta *meta, const uint32_t *__restrict__ cidx,
+                                                       uint32_t *blk_pending, const uint32_t *__restrict__ roff,
                                                        unsigned long long *remaining, const unsigned long long *stop,
                                                        uint8_t *out_bytes, uint32_t pass, const uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
@@ -1381,15 +1382,15 @@ __global__ __launch_bounds__(256) void k_lz_match_list(const uint64_t *__restric
             const uint64_t g = ent & ((1ull << 40) - 1ull);
             const Seq q = seqs[g];
             const uint32_t off = roff[g];                        // resolved in the first pass
-            const uint64_t mpos = mdst[g];
+            const uint64_t mpos = meta[g].pos;
             const uint64_t src = mpos - off;
             const uint64_t need_hi = src + q.ml < mpos ? src + q.ml : mpos;
-            if (lz_range_final(src, need_hi, mdst, seqs, flags, cidx, g, pass)) {
+            if (lz_range_final(src, need_hi, meta, cidx, g, pass)) {
                 if (q.ml <= kLzShort) {
                     Elem *d = out + mpos;
                     const Elem *sp = out + src;
                     for (uint32_t k = 0; k < q.ml; k++) d[k] = sp[k];   // element-serial: overlap allowed
-                    flags[g] = pass;
+                    meta[g].flag = pass;
                     atomicSub(&blk_pending[ent >> 40], 1u);
                     atomicAdd(&s_ndone, 1u);
                 } else {
@@ -1406,7 +1407,7 @@ __global__ __launch_bounds__(256) void k_lz_match_list(const uint64_t *__restric
             const uint64_t gi = e & ((1ull << 40) - 1ull);
             const Seq q = seqs[gi];
             const uint32_t off = roff[gi];
-            Elem *d = out + mdst[gi];
+            Elem *d = out + meta[gi].pos;
             const Elem *sp = d - off;
             if (off >= q.ml) {
                 for (uint32_t k = tid; k < q.ml; k += 256) d[k] = sp[k];
@@ -1414,7 +1415,7 @@ __global__ __launch_bounds__(256) void k_lz_match_list(const uint64_t *__restric
                 for (uint32_t k = tid; k < q.ml; k += 256) d[k] = sp[k % off];   // overlapping: periodic
             }
             if (tid == 0) {
-                flags[gi] = pass;
+                meta[gi].flag = pass;
                 atomicSub(&blk_pending[e >> 40], 1u);
             }
         }
@@ -1434,18 +1435,18 @@ __global__ __launch_bounds__(256) void k_lz_match_list(const uint64_t *__restric
 // match gets D[p] = distance to an element it is a copy of (initially the match offset; 0 for every
 // final element).  One jump step replaces D[p] by D[p] + D[p - D[p]] -- the chain above p halves --
 // so after ~log2(chain length) steps every pending element points at a final one and is copied.
-__global__ __launch_bounds__(256) void k_pj_collect(const uint32_t *__restrict__ flags, uint64_t n_sequences, uint64_t *list,
+__global__ __launch_bounds__(256) void k_pj_collect(const SeqMeta *__restrict__ meta, uint64_t n_sequences, uint64_t *list,
                                                     unsigned long long *count) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n_sequences; g += stride)
-        if (flags[g] == 0) list[atomicAdd(count, 1ull)] = g;
+        if (meta[g].flag == 0) list[atomicAdd(count, 1ull)] = g;
 }
 
 enum PjOp { kPjInit = 0, kPjJump = 1, kPjCopy = 2 };
 
 template <bool ASCII, int OP>
 __global__ __launch_bounds__(256) void k_pj_step(const uint64_t *__restrict__ list, uint64_t n_list, const Seq *__restrict__ seqs,
-                                                 const uint64_t *__restrict__ mdst, const uint32_t *__restrict__ roff, uint32_t *D,
+                                                 const SeqMeta *__restrict__ meta, const uint32_t *__restrict__ roff, uint32_t *D,
                                                  uint8_t *out_bytes, uint32_t *changed) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
@@ -1472,7 +1473,7 @@ __global__ __launch_bounds__(256) void k_pj_step(const uint64_t *__restrict__ li
         if (base + grp >= n_list) continue;
         const uint64_t g = list[base + grp] & ((1ull << 40) - 1ull);   // a pending-list entry also carries its block index
         const uint32_t ml = seqs[g].ml, off = roff[g];
-        const uint64_t mpos = mdst[g];
+        const uint64_t mpos = meta[g].pos;
         for (uint32_t k = gl; k < ml; k += 16) element(mpos + k, off);
     }
     if (OP == kPjJump && any_change) *changed = 1;
@@ -1480,8 +1481,8 @@ __global__ __launch_bounds__(256) void k_pj_step(const uint64_t *__restrict__ li
 
 template <bool ASCII>
 __global__ __launch_bounds__(256) void k_lz_matches_ordered(const SeqBlock *__restrict__ blocks, uint32_t n_blocks,
-                                                            const Seq *__restrict__ seqs, const uint64_t *__restrict__ mdst,
-                                                            const uint32_t *__restrict__ flags, const uint32_t *__restrict__ blk_pending,
+                                                            const Seq *__restrict__ seqs, SeqMeta *meta,
+                                                            const uint32_t *__restrict__ blk_pending,
                                                             const uint32_t *__restrict__ rep_init, const uint64_t *__restrict__ blk_base,
                                                             uint8_t *out_bytes, uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
@@ -1506,7 +1507,7 @@ __global__ __launch_bounds__(256) void k_lz_matches_ordered(const SeqBlock *__re
             // collect the batch's pending matches (flags are read 256 at a time), restore their order
             if (tid == 0) s_n = 0;
             __syncthreads();
-            if (s0 + tid < sb.n_seq && flags[sb.seq_first + s0 + tid] == 0) s_idx[atomicAdd(&s_n, 1u)] = s0 + tid;
+            if (s0 + tid < sb.n_seq && meta[sb.seq_first + s0 + tid].flag == 0) s_idx[atomicAdd(&s_n, 1u)] = s0 + tid;
             __syncthreads();
             const uint32_t n = s_n;
             if (n > 1) {
@@ -1525,7 +1526,7 @@ __global__ __launch_bounds__(256) void k_lz_matches_ordered(const SeqBlock *__re
                 const Seq q = seqs[g];
                 bool bad = false;
                 const uint32_t off = rep_resolve(q.off, init, &bad);
-                const uint64_t mpos = mdst[g];
+                const uint64_t mpos = meta[g].pos;
                 s_mpos[tid] = mpos;
                 s_ml[tid] = q.ml;
                 s_off[tid] = (bad || off > mpos - fstart) ? 0u : off;
@@ -1903,31 +1904,31 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
     hipLaunchKernelGGL(k_rep_apply, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, a.blocks, a.n_blocks, a.rep_final,
                        chunk_init, a.rep_init, a.status);
     hipLaunchKernelGGL(k_lz_literals<ASCII>, dim3(a.n_blocks), dim3(256), 0, stream, a.blocks, a.seqs, a.lit, a.blk_base,
-                       a.mdst, a.blk_pending, a.out, a.t_char, a.status);
+                       a.meta, a.blk_pending, a.out, a.t_char, a.status);
     if (a.cidx) {
         uint64_t ib = (a.n_idx_chunks + 255) / 256;
         if (ib > 256u * 16u) ib = 256u * 16u;
-        hipLaunchKernelGGL(k_lz_index, dim3(static_cast<uint32_t>(ib)), dim3(256), 0, stream, a.mdst, a.n_sequences, a.n_idx_chunks,
+        hipLaunchKernelGGL(k_lz_index, dim3(static_cast<uint32_t>(ib)), dim3(256), 0, stream, a.meta, a.n_sequences, a.n_idx_chunks,
                            a.cidx, a.status);
     }
     const uint32_t grid = a.n_blocks < 256u * 8u ? a.n_blocks : 256u * 8u;
     if (!a.plist[0] || !a.plist[1]) {                      // no memory for the pending lists: every pass walks the blocks
         for (uint32_t pass = 1; pass <= kLzPasses; pass++)
-            hipLaunchKernelGGL(k_lz_match_pass<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.mdst,
-                               a.cidx, a.flags, a.blk_pending, a.roff, a.counters, a.rep_init, a.blk_base, a.out, pass, nullptr,
+            hipLaunchKernelGGL(k_lz_match_pass<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.meta,
+                               a.cidx, a.blk_pending, a.roff, a.counters, a.rep_init, a.blk_base, a.out, pass, nullptr,
                                nullptr, a.status);
         return;
     }
     unsigned long long *cnt = a.counters + 4;              // lengths of the two pending lists
-    hipLaunchKernelGGL(k_lz_match_pass<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.mdst, a.cidx,
-                       a.flags, a.blk_pending, a.roff, a.counters, a.rep_init, a.blk_base, a.out, 1u, a.plist[0], cnt + 0, a.status);
+    hipLaunchKernelGGL(k_lz_match_pass<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.meta, a.cidx,
+                       a.blk_pending, a.roff, a.counters, a.rep_init, a.blk_base, a.out, 1u, a.plist[0], cnt + 0, a.status);
     uint64_t lgrid = (a.n_sequences + 255) / 256;
     if (lgrid > 256u * 8u) lgrid = 256u * 8u;
     for (uint32_t pass = 2; pass <= kLzPasses; pass++) {
         const uint32_t in = pass & 1u, ol = in ^ 1u;       // pass 2 reads list 0 and writes list 1, pass 3 the other way round
         hipLaunchKernelGGL(k_lz_pass_ctl, dim3(1), dim3(1), 0, stream, a.counters, in, ol, pass);
         hipLaunchKernelGGL(k_lz_match_list<ASCII>, dim3(static_cast<uint32_t>(lgrid)), dim3(256), 0, stream, a.plist[in], cnt + in,
-                           a.plist[ol], cnt + ol, a.seqs, a.mdst, a.cidx, a.flags,
+                           a.plist[ol], cnt + ol, a.seqs, a.meta, a.cidx,
                            a.blk_pending, a.roff, a.counters, a.counters + 6, a.out, pass, a.status);
     }
     // ran to the end: the last pass's output list is the pending list (counters[3]); harmless when stopped earlier
@@ -1936,7 +1937,6 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
 
 void launch_lz_execute(hipStream_t stream, const LzArgs &a, bool ascii) {
     if (!a.n_blocks) return;
-    (void)hipMemsetAsync(a.flags, 0, a.n_sequences * sizeof(uint32_t), stream);
     // remaining matches, pointer-jumping list length, [2] its `changed` flag, [4] [5] lengths of the two pending lists
     static const unsigned long long zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipMemcpyAsync(a.counters, zeros, sizeof zeros, hipMemcpyHostToDevice, stream);
@@ -1949,15 +1949,15 @@ void launch_lz_execute(hipStream_t stream, const LzArgs &a, bool ascii) {
 
 void launch_lz_ordered(hipStream_t stream, const LzArgs &a, bool ascii) {
     if (ascii)
-        hipLaunchKernelGGL(k_lz_matches_ordered<true>, dim3(1), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.mdst,
-                           a.flags, a.blk_pending, a.rep_init, a.blk_base, a.out, a.status);
+        hipLaunchKernelGGL(k_lz_matches_ordered<true>, dim3(1), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.meta,
+                           a.blk_pending, a.rep_init, a.blk_base, a.out, a.status);
     else
-        hipLaunchKernelGGL(k_lz_matches_ordered<false>, dim3(1), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.mdst,
-                           a.flags, a.blk_pending, a.rep_init, a.blk_base, a.out, a.status);
+        hipLaunchKernelGGL(k_lz_matches_ordered<false>, dim3(1), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.meta,
+                           a.blk_pending, a.rep_init, a.blk_base, a.out, a.status);
 }
 
 void launch_pj_collect(hipStream_t stream, const LzArgs &a, uint64_t *list) {
-    hipLaunchKernelGGL(k_pj_collect, dim3(256 * 8), dim3(256), 0, stream, a.flags, a.n_sequences, list, a.counters + 1);
+    hipLaunchKernelGGL(k_pj_collect, dim3(256 * 8), dim3(256), 0, stream, a.meta, a.n_sequences, list, a.counters + 1);
 }
 
 template <bool ASCII>
@@ -1967,11 +1967,11 @@ static void pj_step(hipStream_t stream, const LzArgs &a, const uint64_t *list, u
     if (blocks > 256u * 16u) blocks = 256u * 16u;
     const dim3 grid(static_cast<uint32_t>(blocks));
     if (op == kPjInit)
-        hipLaunchKernelGGL((k_pj_step<ASCII, kPjInit>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.mdst, a.roff, D, a.out, changed);
+        hipLaunchKernelGGL((k_pj_step<ASCII, kPjInit>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed);
     else if (op == kPjJump)
-        hipLaunchKernelGGL((k_pj_step<ASCII, kPjJump>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.mdst, a.roff, D, a.out, changed);
+        hipLaunchKernelGGL((k_pj_step<ASCII, kPjJump>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed);
     else
-        hipLaunchKernelGGL((k_pj_step<ASCII, kPjCopy>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.mdst, a.roff, D, a.out, changed);
+        hipLaunchKernelGGL((k_pj_step<ASCII, kPjCopy>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed);
 }
 
 void launch_pj_step(hipStream_t stream, const LzArgs &a, bool ascii, const uint64_t *list, uint64_t n_list, uint32_t *D, int op,

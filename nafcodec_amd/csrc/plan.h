@@ -83,6 +83,13 @@ struct Seq {             // one decoded sequence
     uint32_t lpos;       // position of its literals in the block's literal section
 };
 
+struct alignas(16) SeqMeta {   // what the match passes need to know about a sequence as a PRODUCER of bytes, in one 16-byte load
+    uint64_t pos;        // output position of its match (element index in the section)
+    uint32_t ml;
+    uint32_t flag;       // 0 = pending, else the pass that completed the match
+};
+static_assert(sizeof(SeqMeta) == 16, "SeqMeta layout");
+
 // Repeat offsets (App. B): a block starts from the three offsets its predecessor ends with, which
 // k_seq_decode does not know (blocks decode in parallel).  It tracks them symbolically instead:
 //   token = kRepToken | slot << 24 | d   means   (initial rep[slot]) - d

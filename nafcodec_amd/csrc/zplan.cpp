@@ -752,7 +752,7 @@ struct Walker {
 
 std::string build_zplan(const uint8_t *payload, size_t n, ZPlan *plan, bool *truncated, uint32_t shard_rank,
                         uint32_t shard_count) {
-    Walker w{payload, n, plan, {}, {}, {}};
+    Walker w{payload, n, plan, {}, {}, {}, {}};
     *truncated = false;
     if (n == 0) {
         *truncated = true;

@@ -194,7 +194,12 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
     return Failure();
 }
 
-void SectionJob::run(hipStream_t stream, StageTimer *timer) {
+SectionJob::~SectionJob() {
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
+}
+
+void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
     if (!ready_) return;
     uint32_t *status = d_status_.as<uint32_t>();
     (void)hipMemsetAsync(status, 0, 64, stream);
@@ -215,13 +220,35 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer) {
     launch_copy_fill(stream, d_src_, d_copies_.as<CopyTask>(), static_cast<uint32_t>(n_copies_),
                      d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(), ascii, t_char_, status);
     if (timer) timer->end(stream);
-    for (int c = 0; c < 4; c++) {        // classes 0/1: streams of literal-only blocks, straight to the output; 2/3: to the literal buffer
-        if (!class_count_[c]) continue;
+    // K1.  Classes 0/1: streams of literal-only blocks, straight to the output; 2/3: to the literal buffer.
+    // When both kinds exist (archives whose blocks carry a few LZ sequences) the literal-buffer tasks run
+    // on `aux` beside the direct ones, so the two launches share the chip instead of each ending in a
+    // half-empty tail; K4 then waits for both.  One timed span covers the phase.
+    auto launch_class = [&](int c, hipStream_t st) {
+        if (!class_count_[c]) return;
+        launch_huf_decode(st, d_src_, d_tasks_.as<HufTask>() + class_first_[c], class_count_[c], d_tbl_copies_.as<HufTblCopy>(),
+                          d_streams_.as<HufStream>(), d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(),
+                          class_max_tbl_[c], (c & 1) != 0, c < 2 && ascii, t_char_, status);
+    };
+    const bool have_direct = class_count_[0] + class_count_[1] > 0, have_lit = class_count_[2] + class_count_[3] > 0;
+    if (have_direct || have_lit) {
         if (timer) timer->begin(stream, StageTimer::kHuf);
-        launch_huf_decode(stream, d_src_, d_tasks_.as<HufTask>() + class_first_[c], class_count_[c],
-                          d_tbl_copies_.as<HufTblCopy>(), d_streams_.as<HufStream>(), d_pool_.as<uint16_t>(),
-                          d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(), class_max_tbl_[c], (c & 1) != 0, c < 2 && ascii,
-                          t_char_, status);
+        bool forked = false;
+        if (have_direct && have_lit && aux) {
+            if (!ev_fork_) (void)hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming);
+            if (!ev_join_) (void)hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming);
+            forked = ev_fork_ && ev_join_ && hip_ok(hipEventRecord(ev_fork_, stream)) && hip_ok(hipStreamWaitEvent(aux, ev_fork_, 0));
+        }
+        if (forked) {
+            launch_class(2, aux);
+            launch_class(3, aux);
+            (void)hipEventRecord(ev_join_, aux);
+            launch_class(0, stream);
+            launch_class(1, stream);
+            (void)hipStreamWaitEvent(stream, ev_join_, 0);
+        } else {
+            for (int c = 0; c < 4; c++) launch_class(c, stream);
+        }
         if (timer) timer->end(stream);
     }
     if (n_seq_blocks_) {
@@ -307,6 +334,7 @@ Failure SectionJob::check(hipStream_t stream) {
 
 // ------------------------------------------------------------------ ArchiveJob
 ArchiveJob::~ArchiveJob() {
+    if (aux_stream_) (void)hipStreamDestroy(aux_stream_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -325,6 +353,7 @@ Failure ArchiveJob::init(int device) {
     if (!stream_) {
         e = hipStreamCreate(&stream_);
         if (!hip_ok(e)) return dev_fail("hipStreamCreate", e);
+        if (!hip_ok(hipStreamCreate(&aux_stream_))) aux_stream_ = nullptr;   // optional: K1 then stays on one stream
     }
     return Failure();
 }
@@ -394,7 +423,7 @@ Failure ArchiveJob::decode() {
     (void)hipMemsetAsync(status, 0, 64, stream_);
     (void)hipMemsetAsync(totals, 0, 8 * sizeof(ScanTotals), stream_);
     timer_.mark_total_begin(stream_);
-    for (int s = 0; s < kNumSections; s++) job_[s].run(stream_, &timer_);
+    for (int s = 0; s < kNumSections; s++) job_[s].run(stream_, &timer_, aux_stream_);
     if (job_[kLengths].ready()) {                                  // LengthReader, reader.rs:48-67
         timer_.begin(stream_, StageTimer::kOther);
         launch_scan_runs_u32(stream_, job_[kLengths].out(), rec_cap_, d_rec_ends_.as<uint64_t>(), rec_cap_,

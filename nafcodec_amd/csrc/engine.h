@@ -77,6 +77,10 @@ private:
 // One Zstandard-compressed NAF section resident on the device.
 class SectionJob {
 public:
+    SectionJob() = default;
+    SectionJob(const SectionJob &) = delete;
+    SectionJob &operator=(const SectionJob &) = delete;
+    ~SectionJob();
     // Walks the payload on the host (zplan), allocates HBM, uploads the task lists.
     // d_payload points at the same bytes in device memory (>= 256 B readable in front, 64 behind).
     // ascii_t_char != 0: nucleotide sequence section -- every byte bound for the section output is
@@ -87,7 +91,8 @@ public:
     Failure prepare(const uint8_t *host_payload, size_t n, uint64_t expect_size, const uint8_t *d_payload,
                     hipStream_t stream, uint32_t ascii_t_char = 0, uint32_t shard_rank = 0, uint32_t shard_count = 1);
     // Enqueues the decode kernels.  Results: out() holds size() bytes once the stream is done.
-    void run(hipStream_t stream, StageTimer *timer);
+    // aux: a second stream (or null) on which the literal-buffer Huffman tasks run beside the direct ones
+    void run(hipStream_t stream, StageTimer *timer, hipStream_t aux = nullptr);
     // After synchronisation: device status -> Failure
     Failure check(hipStream_t stream);
 
@@ -114,6 +119,7 @@ private:
     uint64_t expect_ = 0, n_blocks_ = 0, n_streams_ = 0, n_tasks_ = 0, n_copies_ = 0, n_seq_blocks_ = 0;
     uint32_t class_first_[4] = {0, 0, 0, 0}, class_count_[4] = {0, 0, 0, 0}, class_max_tbl_[4] = {0, 0, 0, 0};
     uint32_t n_direct_tasks_ = 0, t_char_ = 0;
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;   // K1 on two streams (created on first use, destroyed with the job)
     const uint8_t *d_src_ = nullptr;
     float plan_ms_ = 0;
     bool ready_ = false;
@@ -176,7 +182,7 @@ public:
 
 private:
     int device_ = -1;
-    hipStream_t stream_ = nullptr;
+    hipStream_t stream_ = nullptr, aux_stream_ = nullptr;
     StageTimer timer_;
     StageTimes times_;
     nafgpu_header h_{};

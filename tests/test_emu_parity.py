@@ -116,7 +116,7 @@ bad += ["text:" + n for n, blob in cases.text_cases(1) if Decoder(io.BytesIO(blo
 print("BAD", bad)
 sys.exit(1 if bad else 0)
 """ % (ROOT, os.path.join(ROOT, "tests"), os.path.join(EMU_DIR, "libnafgpu_emu_asan.so"))
-    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:allocator_may_return_null=1")
     p = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
 

@@ -1012,6 +1012,23 @@ __global__ __launch_bounds__(256) void k_copy_fill(const uint8_t *__restrict__ s
     }
 }
 
+// nibble -> character through v_perm_b32 (shared by K4's literal copy and K5): four packed bytes -> eight characters
+__device__ inline uint32_t lut4(uint32_t nib, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
+    const uint32_t sel = nib & 0x07070707u;
+    const uint32_t lo = __builtin_amdgcn_perm(t1, t0, sel);
+    const uint32_t hi = __builtin_amdgcn_perm(t3, t2, sel);
+    const uint32_t m = ((nib >> 3) & 0x01010101u) * 0xFFu;
+    return (hi & m) | (lo & ~m);
+}
+
+__device__ inline void unpack_dword(uint32_t w, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t *o0,
+                                    uint32_t *o1) {
+    const uint32_t L = lut4(w & 0x0F0F0F0Fu, t0, t1, t2, t3);
+    const uint32_t H = lut4((w >> 4) & 0x0F0F0F0Fu, t0, t1, t2, t3);
+    *o0 = __builtin_amdgcn_perm(H, L, 0x05010400u);   // L0 H0 L1 H1
+    *o1 = __builtin_amdgcn_perm(H, L, 0x07030602u);   // L2 H2 L3 H3
+}
+
 // ======================================================================================
 // K4  LZ77 execution (App. B "Repeat offsets" + "Execute")
 // ======================================================================================
@@ -1142,6 +1159,39 @@ __global__ __launch_bounds__(256) void k_rep_apply(const SeqBlock *__restrict__ 
     if (bad) flag_error(status, kStBadOffset, 0xFFFFFFFEu);
 }
 
+// A long literal run (n packed bytes -> n output elements) copied by the whole workgroup: 16-byte aligned
+// stores -- eight source bytes expanded to sixteen characters, or sixteen bytes copied -- between a
+// scalar head and tail.  Blocks with only a few sequences (what real genomes give zstd level 1) are
+// almost all trailing literals, so this is a streaming copy.
+constexpr uint32_t kLzWide = 512;        // runs at least this long take the wide path
+
+template <bool ASCII>
+__device__ inline void lz_copy_wide(typename std::conditional<ASCII, uint16_t, uint8_t>::type *dst, const uint8_t *src, uint32_t n,
+                                    uint32_t me, uint32_t t_char) {
+    using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
+    constexpr uint32_t kPer = ASCII ? 8 : 16;              // elements per 16-byte store
+    const uint32_t t0 = 0x4B47002Du | (t_char << 8), t1 = 0x42535943u, t2 = 0x44525741u, t3 = 0x4E56484Du;   // "-TGKCYSBAWRDMHVN"
+    const uint32_t mis = static_cast<uint32_t>((16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15) / sizeof(Elem);
+    const uint32_t head = mis < n ? mis : n;
+    const uint32_t n_vec = (n - head) / kPer, tail0 = head + n_vec * kPer;
+    auto one = [&](uint32_t k) { dst[k] = ASCII ? static_cast<Elem>(byte_chars(src[k], t_char)) : static_cast<Elem>(src[k]); };
+    if (me < head) one(me);
+    if (tail0 + me < n) one(tail0 + me);
+    for (uint32_t v = me; v < n_vec; v += 256) {
+        const uint8_t *sp = src + head + v * kPer;
+        uint4 w;
+        if (ASCII) {
+            uint2 in;
+            __builtin_memcpy(&in, sp, 8);                  // one unaligned 8-byte load
+            unpack_dword(in.x, t0, t1, t2, t3, &w.x, &w.y);
+            unpack_dword(in.y, t0, t1, t2, t3, &w.z, &w.w);
+        } else {
+            __builtin_memcpy(&w, sp, 16);
+        }
+        *reinterpret_cast<uint4 *>(dst + head + v * kPer) = w;
+    }
+}
+
 template <bool ASCII>
 __global__ __launch_bounds__(256) void k_lz_literals(const SeqBlock *__restrict__ blocks, const Seq *__restrict__ seqs,
                                                      const uint8_t *__restrict__ lit, const uint64_t *__restrict__ blk_base,
@@ -1177,14 +1227,20 @@ __global__ __launch_bounds__(256) void k_lz_literals(const SeqBlock *__restrict_
         const uint32_t nl = s_nlong;
         for (uint32_t j = 0; j < nl; j++) {
             const Seq q = sq[s_long[j]];
-            for (uint32_t k = tid; k < q.ll; k += 256) put(out + q.opos + k, blit[q.lpos + k]);
+            if (q.ll >= kLzWide)
+                lz_copy_wide<ASCII>(out + q.opos, blit + q.lpos, q.ll, tid, t_char);
+            else
+                for (uint32_t k = tid; k < q.ll; k += 256) put(out + q.opos + k, blit[q.lpos + k]);
         }
         __syncthreads();
     }
     // literals after the last sequence run to the end of the block
     const Seq last = sq[sb.n_seq - 1];
     const uint32_t lused = last.lpos + last.ll, oend = last.opos + last.ll + last.ml;
-    for (uint32_t k = tid; k < sb.lit_size - lused; k += 256) put(out + oend + k, blit[lused + k]);
+    if (sb.lit_size - lused >= kLzWide)
+        lz_copy_wide<ASCII>(out + oend, blit + lused, sb.lit_size - lused, tid, t_char);
+    else
+        for (uint32_t k = tid; k < sb.lit_size - lused; k += 256) put(out + oend + k, blit[lused + k]);
 }
 
 // cidx[c] = first sequence whose match starts at or after output element c << kLzIdxShift: where the
@@ -1558,22 +1614,6 @@ __global__ __launch_bounds__(256) void k_lz_matches_ordered(const SeqBlock *__re
 // Byte b of the packed stream yields LUT[b & 15] then LUT[b >> 4]; records are contiguous in
 // nibble space, so record k is bases [end[k-1], end[k]) of this one flat array -- the odd-nibble
 // `cache` of reader.rs:92-94,138-143 is just an odd offset here.
-__device__ inline uint32_t lut4(uint32_t nib, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
-    const uint32_t sel = nib & 0x07070707u;
-    const uint32_t lo = __builtin_amdgcn_perm(t1, t0, sel);
-    const uint32_t hi = __builtin_amdgcn_perm(t3, t2, sel);
-    const uint32_t m = ((nib >> 3) & 0x01010101u) * 0xFFu;
-    return (hi & m) | (lo & ~m);
-}
-
-__device__ inline void unpack_dword(uint32_t w, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t *o0,
-                                    uint32_t *o1) {
-    const uint32_t L = lut4(w & 0x0F0F0F0Fu, t0, t1, t2, t3);
-    const uint32_t H = lut4((w >> 4) & 0x0F0F0F0Fu, t0, t1, t2, t3);
-    *o0 = __builtin_amdgcn_perm(H, L, 0x05010400u);   // L0 H0 L1 H1
-    *o1 = __builtin_amdgcn_perm(H, L, 0x07030602u);   // L2 H2 L3 H3
-}
-
 __global__ __launch_bounds__(256) void k_unpack4(const uint8_t *__restrict__ packed, uint64_t n_packed,
                                                  uint8_t *__restrict__ ascii, uint64_t n_bases, uint32_t t_char,
                                                  const uint32_t *status) {

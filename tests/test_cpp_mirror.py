@@ -1,0 +1,77 @@
+"""include/nafcodec.hpp (the C++ mirror of the reference's Decoder API) compiled and run for real:
+against the CPU harness build of the library here, against libnafgpu.so on a GPU box."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT, golden_bytes
+
+CSRC = os.path.join(ROOT, "nafcodec_amd", "csrc")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+PROGRAM = r"""
+#include <cstdio>
+#include <fstream>
+#include <iterator>
+#include "nafcodec.hpp"
+int main(int argc, char **argv) {
+    using namespace nafcodec;
+    try {
+        Decoder dec = DecoderBuilder().with_path(argv[1]);          // mod.rs:159-166
+        const Header h = dec.header();
+        std::printf("records %llu line %llu type %d remaining %zu\n", (unsigned long long)h.number_of_sequences(),
+                    (unsigned long long)h.line_length(), (int)h.sequence_type(), dec.len());
+        size_t n = 0, bases = 0;
+        std::string first;
+        while (auto rec = dec.next()) {                             // Iterator::next
+            if (n == 0) first = *rec->id;
+            bases += rec->sequence->size();
+            n++;
+        }
+        std::printf("iterated %zu bases %zu first %s\n", n, bases, first.c_str());
+        Decoder again = Decoder::from_path(argv[1]);
+        const std::string text = again.to_text();                   // FASTA / FASTQ built on the device
+        std::ifstream f(argv[2], std::ios::binary);
+        const std::string want((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        std::printf("text %s\n", text == want ? "equal" : "DIFFERENT");
+        try {
+            DecoderBuilder().with_path("/nonexistent.naf");
+            std::printf("no error?\n");
+        } catch (const Error &e) {
+            std::printf("open error io=%d\n", (int)e.is_io());
+        }
+    } catch (const Error &e) {
+        std::printf("Error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
+"""
+
+
+def build_and_run(tmp_path, libdir, libname, extra_env=None):
+    src = tmp_path / "mirror.cpp"
+    src.write_text(PROGRAM)
+    exe = tmp_path / "mirror"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-l:" + libname, "-Wl,-rpath," + libdir])
+    env = dict(os.environ, **(extra_env or {}))
+    out = subprocess.run([str(exe), os.path.join(GOLDEN, "phix.naf"), os.path.join(GOLDEN, "phix.fastq")],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == "records 42 line 301 type 0 remaining 42"
+    assert lines[1] == "iterated 42 bases 12436 first SRR1377138.1"
+    assert lines[2] == "text equal"
+    assert lines[3] == "open error io=1"
+
+
+def test_cpp_mirror_on_the_cpu_harness(tmp_path):
+    subprocess.check_call(["make", "-s", "-C", CSRC, "emu"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    build_and_run(tmp_path, os.path.join(ROOT, "tests", "emu", "_build"), "libnafgpu_emu.so")
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_on_the_gpu(tmp_path):
+    build_and_run(tmp_path, os.path.join(ROOT, "nafcodec_amd"), "libnafgpu.so")

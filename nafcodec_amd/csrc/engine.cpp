@@ -334,6 +334,8 @@ Failure SectionJob::check(hipStream_t stream) {
 
 // ------------------------------------------------------------------ ArchiveJob
 ArchiveJob::~ArchiveJob() {
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
     if (aux_stream_) (void)hipStreamDestroy(aux_stream_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -423,27 +425,47 @@ Failure ArchiveJob::decode() {
     (void)hipMemsetAsync(status, 0, 64, stream_);
     (void)hipMemsetAsync(totals, 0, 8 * sizeof(ScanTotals), stream_);
     timer_.mark_total_begin(stream_);
-    for (int s = 0; s < kNumSections; s++) job_[s].run(stream_, &timer_, aux_stream_);
-    if (job_[kLengths].ready()) {                                  // LengthReader, reader.rs:48-67
-        timer_.begin(stream_, StageTimer::kOther);
-        launch_scan_runs_u32(stream_, job_[kLengths].out(), rec_cap_, d_rec_ends_.as<uint64_t>(), rec_cap_,
-                             d_scan_tmp_.bytes(), &totals[0], status);
-        timer_.end(stream_);
+    // Sections in file order.  The record table (LengthReader) and the mask run table (MaskReader) only need
+    // the small Length / Mask sections, which come before the sequence: their scans run on the second stream
+    // beside the sequence decode and are joined before the mask is applied.
+    const bool want_mask = job_[kMask].ready() && job_[kSequence].ready() && job_[kLengths].ready();
+    for (int s = 0; s <= kMask; s++) job_[s].run(stream_, &timer_, aux_stream_);
+    bool scans_forked = false;
+    auto scans = [&](hipStream_t st) {
+        if (job_[kLengths].ready())                                // LengthReader, reader.rs:48-67
+            launch_scan_runs_u32(st, job_[kLengths].out(), rec_cap_, d_rec_ends_.as<uint64_t>(), rec_cap_, d_scan_tmp_.bytes(),
+                                 &totals[0], status);
+        if (want_mask)                                             // MaskReader, reader.rs:198-231
+            launch_scan_runs_u8(st, job_[kMask].out(), mask_cap_, d_mask_ends_.as<uint64_t>(), mask_cap_, d_scan_tmp_.bytes(),
+                                &totals[1], status);
+    };
+    if (aux_stream_ && job_[kSequence].ready()) {
+        if (!ev_fork_) (void)hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming);
+        if (!ev_join_) (void)hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming);
+        scans_forked = ev_fork_ && ev_join_ && hip_ok(hipEventRecord(ev_fork_, stream_)) &&
+                       hip_ok(hipStreamWaitEvent(aux_stream_, ev_fork_, 0));
     }
+    if (scans_forked) {
+        scans(aux_stream_);
+        (void)hipEventRecord(ev_join_, aux_stream_);
+    }
+    for (int s = kMask + 1; s < kNumSections; s++) job_[s].run(stream_, &timer_, aux_stream_);
+    timer_.begin(stream_, StageTimer::kOther);
+    if (scans_forked)
+        (void)hipStreamWaitEvent(stream_, ev_join_, 0);
+    else
+        scans(stream_);
     // (nucleotide sequence sections come out of their SectionJob already expanded to ASCII:
     //  SequenceReader::read_nucleotide, reader.rs:121-172, is fused into the zstd kernels)
-    if (job_[kMask].ready() && job_[kSequence].ready() && job_[kLengths].ready()) {   // mod.rs:386-388, 402-441
-        timer_.begin(stream_, StageTimer::kOther);
-        launch_scan_runs_u8(stream_, job_[kMask].out(), mask_cap_, d_mask_ends_.as<uint64_t>(), mask_cap_,
-                            d_scan_tmp_.bytes(), &totals[1], status);
+    if (want_mask) {                                               // mod.rs:386-388, 402-441
         const uint64_t mult = is_nuc_ ? 2 : 1;
         const uint64_t lo = job_[kSequence].shard_out0() * mult, hi = job_[kSequence].shard_out1() * mult;   // bases held here
         uint8_t *seq = job_[kSequence].out_mut() - lo;         // addressed by global base index
         const uint64_t n_all = is_nuc_ ? mask_total_bases_ : std::min<uint64_t>(mask_total_bases_, job_[kSequence].total_size());
         launch_mask_apply(stream_, seq, n_all, lo, hi, d_mask_ends_.as<uint64_t>(), &totals[1], d_rec_ends_.as<uint64_t>(),
                           &totals[0], mask_cap_, opt_.spec_mask ? 1 : 0, status);
-        timer_.end(stream_);
     }
+    timer_.end(stream_);
     // ids / comments: CStringReader (reader.rs:22-30) as a scan; UTF-8 validity of every text section
     // (into_string().expect at mod.rs:362,368; from_utf8 at reader.rs:108-109) as one flag word
     uint32_t *utf8 = status + 8;

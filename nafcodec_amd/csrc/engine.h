@@ -183,6 +183,7 @@ public:
 private:
     int device_ = -1;
     hipStream_t stream_ = nullptr, aux_stream_ = nullptr;
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;   // record / mask table scans beside the sequence decode
     StageTimer timer_;
     StageTimes times_;
     nafgpu_header h_{};

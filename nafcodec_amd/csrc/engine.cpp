@@ -295,24 +295,26 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
             const uint64_t *plist = nullptr;
             if (la.plist[0] && la.plist[1] && cnt[3] < 2 && cnt[4 + cnt[3]] == n_pending) plist = la.plist[cnt[3]];
             if ((plist || d_pj_list_.alloc(n_pending * sizeof(uint64_t))) &&
-                d_pj_dist_.alloc(static_cast<size_t>(expect_) * sizeof(uint32_t) + 16)) {
+                d_pj_dist_.alloc(static_cast<size_t>(expect_) * sizeof(uint32_t) + 16) && d_pj_stamp_.alloc(n_pending + 16)) {
                 uint32_t *D = d_pj_dist_.as<uint32_t>();
+                uint8_t *stamp = d_pj_stamp_.bytes();
                 (void)hipMemsetAsync(D, 0, static_cast<size_t>(expect_) * sizeof(uint32_t), stream);
+                (void)hipMemsetAsync(stamp, 0, n_pending, stream);
                 if (!plist) {
                     launch_pj_collect(stream, la, d_pj_list_.as<uint64_t>());
                     plist = d_pj_list_.as<uint64_t>();
                 }
-                launch_pj_step(stream, la, ascii, plist, n_pending, D, 0, changed);
+                launch_pj_step(stream, la, ascii, plist, n_pending, D, 0, changed, stamp, 0);
                 for (int it = 0; it < 64 && !done; it++) {           // chain length halves per step
                     (void)hipMemsetAsync(changed, 0, sizeof(uint32_t), stream);
-                    launch_pj_step(stream, la, ascii, plist, n_pending, D, 1, changed);
+                    launch_pj_step(stream, la, ascii, plist, n_pending, D, 1, changed, stamp, static_cast<uint32_t>(it) + 1);
                     uint32_t ch = 1;
                     if (!hip_ok(hipMemcpyAsync(&ch, changed, sizeof ch, hipMemcpyDeviceToHost, stream)) ||
                         !hip_ok(hipStreamSynchronize(stream)))
                         break;
                     done = ch == 0;
                 }
-                if (done) launch_pj_step(stream, la, ascii, plist, n_pending, D, 2, changed);
+                if (done) launch_pj_step(stream, la, ascii, plist, n_pending, D, 2, changed, stamp, 0);
             }
             if (!done) launch_lz_ordered(stream, la, ascii);         // no scratch memory / no convergence: frame order
         }

@@ -102,8 +102,9 @@ void launch_lz_execute(hipStream_t stream, const LzArgs &args, bool ascii);
 // what the passes left pending (args.counters[0] != 0):
 //   pointer jumping: collect the pending list, then op 0 (init D), op 1 (jump, repeat while *changed), op 2 (copy)
 void launch_pj_collect(hipStream_t stream, const LzArgs &args, uint64_t *list);
+// stamp: one byte per list entry (zeroed before the first jump step); step = 1, 2, ... for the jump steps
 void launch_pj_step(hipStream_t stream, const LzArgs &args, bool ascii, const uint64_t *list, uint64_t n_list, uint32_t *D,
-                    int op, uint32_t *changed);
+                    int op, uint32_t *changed, uint8_t *stamp, uint32_t step);
 //   or, without scratch memory for D: one workgroup in frame order
 void launch_lz_ordered(hipStream_t stream, const LzArgs &args, bool ascii);
 

@@ -1503,17 +1503,19 @@ enum PjOp { kPjInit = 0, kPjJump = 1, kPjCopy = 2 };
 template <bool ASCII, int OP>
 __global__ __launch_bounds__(256) void k_pj_step(const uint64_t *__restrict__ list, uint64_t n_list, const Seq *__restrict__ seqs,
                                                  const SeqMeta *__restrict__ meta, const uint32_t *__restrict__ roff, uint32_t *D,
-                                                 uint8_t *out_bytes, uint32_t *changed) {
+                                                 uint8_t *out_bytes, uint32_t *changed, uint8_t *stamp, uint32_t step) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
     const uint32_t tid = threadIdx.x;
     bool any_change = false;
+    bool unresolved = false;             // this lane saw an element whose source is still pending
     auto element = [&](uint64_t p, uint32_t off) {
         if (OP == kPjInit) {
             D[p] = off;
         } else if (OP == kPjJump) {
             const uint32_t d = D[p];
             const uint32_t da = D[p - d];
+            if (da != 0) unresolved = true;
             if (da != 0 && static_cast<uint64_t>(d) + da <= 0xFFFFFFFFull) {
                 D[p] = d + da;
                 any_change = true;
@@ -1527,10 +1529,16 @@ __global__ __launch_bounds__(256) void k_pj_step(const uint64_t *__restrict__ li
     const uint32_t grp = tid >> 4, gl = tid & 15;
     for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * 16; base < n_list; base += static_cast<uint64_t>(gridDim.x) * 16) {
         if (base + grp >= n_list) continue;
+        // A match all of whose elements already point at final bytes never changes again: a jump step
+        // stamps the matches that still have an unresolved element, the next step skips the others
+        // (most chains are short; only the longest need all the steps).
+        if (OP == kPjJump && step > 1 && stamp[base + grp] != static_cast<uint8_t>(step - 1)) continue;
         const uint64_t g = list[base + grp] & ((1ull << 40) - 1ull);   // a pending-list entry also carries its block index
         const uint32_t ml = seqs[g].ml, off = roff[g];
         const uint64_t mpos = meta[g].pos;
+        unresolved = false;
         for (uint32_t k = gl; k < ml; k += 16) element(mpos + k, off);
+        if (OP == kPjJump && unresolved) stamp[base + grp] = static_cast<uint8_t>(step);   // same value from every lane that writes
     }
     if (OP == kPjJump && any_change) *changed = 1;
 }
@@ -2002,25 +2010,25 @@ void launch_pj_collect(hipStream_t stream, const LzArgs &a, uint64_t *list) {
 
 template <bool ASCII>
 static void pj_step(hipStream_t stream, const LzArgs &a, const uint64_t *list, uint64_t n_list, uint32_t *D, int op,
-                    uint32_t *changed) {
+                    uint32_t *changed, uint8_t *stamp, uint32_t step) {
     uint64_t blocks = (n_list + 15) / 16;             // sixteen matches per workgroup step
     if (blocks > 256u * 16u) blocks = 256u * 16u;
     const dim3 grid(static_cast<uint32_t>(blocks));
     if (op == kPjInit)
-        hipLaunchKernelGGL((k_pj_step<ASCII, kPjInit>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed);
+        hipLaunchKernelGGL((k_pj_step<ASCII, kPjInit>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed, stamp, step);
     else if (op == kPjJump)
-        hipLaunchKernelGGL((k_pj_step<ASCII, kPjJump>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed);
+        hipLaunchKernelGGL((k_pj_step<ASCII, kPjJump>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed, stamp, step);
     else
-        hipLaunchKernelGGL((k_pj_step<ASCII, kPjCopy>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed);
+        hipLaunchKernelGGL((k_pj_step<ASCII, kPjCopy>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed, stamp, step);
 }
 
 void launch_pj_step(hipStream_t stream, const LzArgs &a, bool ascii, const uint64_t *list, uint64_t n_list, uint32_t *D, int op,
-                    uint32_t *changed) {
+                    uint32_t *changed, uint8_t *stamp, uint32_t step) {
     if (!n_list) return;
     if (ascii)
-        pj_step<true>(stream, a, list, n_list, D, op, changed);
+        pj_step<true>(stream, a, list, n_list, D, op, changed, stamp, step);
     else
-        pj_step<false>(stream, a, list, n_list, D, op, changed);
+        pj_step<false>(stream, a, list, n_list, D, op, changed, stamp, step);
 }
 
 void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed, uint8_t *ascii, uint64_t n_bases,

@@ -257,6 +257,7 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
         la.blocks = d_seq_blocks_.as<SeqBlock>();
         la.n_blocks = static_cast<uint32_t>(n_seq_blocks_);
         la.n_sequences = plan_.n_sequences;
+        la.mean_ml = plan_.n_sequences ? static_cast<uint32_t>((expect_ > plan_.known_out ? expect_ - plan_.known_out : 0) / plan_.n_sequences) : 0;   // known_out = everything but the match bytes
         la.seqs = d_seqs_.as<Seq>();
         la.lit = d_lit_.bytes();
         la.blk_base = d_blk_base_.as<uint64_t>();

@@ -80,6 +80,7 @@ struct LzArgs {
     const SeqBlock *blocks;
     uint32_t n_blocks;
     uint64_t n_sequences;
+    uint32_t mean_ml;            // mean match length of the section (lanes per match in the pointer-jumping steps)
     const Seq *seqs;
     const uint8_t *lit;
     const uint64_t *blk_base;

@@ -1500,7 +1500,7 @@ __global__ __launch_bounds__(256) void k_pj_collect(const SeqMeta *__restrict__ 
 
 enum PjOp { kPjInit = 0, kPjJump = 1, kPjCopy = 2 };
 
-template <bool ASCII, int OP>
+template <bool ASCII, int OP, int GL>
 __global__ __launch_bounds__(256) void k_pj_step(const uint64_t *__restrict__ list, uint64_t n_list, const Seq *__restrict__ seqs,
                                                  const SeqMeta *__restrict__ meta, const uint32_t *__restrict__ roff, uint32_t *D,
                                                  uint8_t *out_bytes, uint32_t *changed, uint8_t *stamp, uint32_t step) {
@@ -1524,10 +1524,11 @@ __global__ __launch_bounds__(256) void k_pj_step(const uint64_t *__restrict__ li
             out[p] = out[p - D[p]];
         }
     };
-    // sixteen lanes per match: consecutive lanes on consecutive elements (64-byte segments of D / out),
-    // sixteen matches per workgroup step; a long match is just more steps of its group
-    const uint32_t grp = tid >> 4, gl = tid & 15;
-    for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * 16; base < n_list; base += static_cast<uint64_t>(gridDim.x) * 16) {
+    // GL lanes per match (4, 8 or 16, by the section's mean match length): consecutive lanes on consecutive
+    // elements, 256 / GL matches per workgroup step; a long match is just more steps of its group
+    constexpr uint32_t kPer = 256 / GL;
+    const uint32_t grp = tid / GL, gl = tid % GL;
+    for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * kPer; base < n_list; base += static_cast<uint64_t>(gridDim.x) * kPer) {
         if (base + grp >= n_list) continue;
         // A match all of whose elements already point at final bytes never changes again: a jump step
         // stamps the matches that still have an unresolved element, the next step skips the others
@@ -1537,7 +1538,7 @@ __global__ __launch_bounds__(256) void k_pj_step(const uint64_t *__restrict__ li
         const uint32_t ml = seqs[g].ml, off = roff[g];
         const uint64_t mpos = meta[g].pos;
         unresolved = false;
-        for (uint32_t k = gl; k < ml; k += 16) element(mpos + k, off);
+        for (uint32_t k = gl; k < ml; k += GL) element(mpos + k, off);
         if (OP == kPjJump && unresolved) stamp[base + grp] = static_cast<uint8_t>(step);   // same value from every lane that writes
     }
     if (OP == kPjJump && any_change) *changed = 1;
@@ -2008,18 +2009,29 @@ void launch_pj_collect(hipStream_t stream, const LzArgs &a, uint64_t *list) {
     hipLaunchKernelGGL(k_pj_collect, dim3(256 * 8), dim3(256), 0, stream, a.meta, a.n_sequences, list, a.counters + 1);
 }
 
-template <bool ASCII>
-static void pj_step(hipStream_t stream, const LzArgs &a, const uint64_t *list, uint64_t n_list, uint32_t *D, int op,
-                    uint32_t *changed, uint8_t *stamp, uint32_t step) {
-    uint64_t blocks = (n_list + 15) / 16;             // sixteen matches per workgroup step
+template <bool ASCII, int GL>
+static void pj_step_gl(hipStream_t stream, const LzArgs &a, const uint64_t *list, uint64_t n_list, uint32_t *D, int op,
+                       uint32_t *changed, uint8_t *stamp, uint32_t step) {
+    uint64_t blocks = (n_list * GL + 255) / 256;
     if (blocks > 256u * 16u) blocks = 256u * 16u;
     const dim3 grid(static_cast<uint32_t>(blocks));
     if (op == kPjInit)
-        hipLaunchKernelGGL((k_pj_step<ASCII, kPjInit>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed, stamp, step);
+        hipLaunchKernelGGL((k_pj_step<ASCII, kPjInit, GL>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed, stamp, step);
     else if (op == kPjJump)
-        hipLaunchKernelGGL((k_pj_step<ASCII, kPjJump>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed, stamp, step);
+        hipLaunchKernelGGL((k_pj_step<ASCII, kPjJump, GL>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed, stamp, step);
     else
-        hipLaunchKernelGGL((k_pj_step<ASCII, kPjCopy>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed, stamp, step);
+        hipLaunchKernelGGL((k_pj_step<ASCII, kPjCopy, GL>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed, stamp, step);
+}
+
+template <bool ASCII>
+static void pj_step(hipStream_t stream, const LzArgs &a, const uint64_t *list, uint64_t n_list, uint32_t *D, int op,
+                    uint32_t *changed, uint8_t *stamp, uint32_t step) {
+    if (a.mean_ml <= 5)
+        pj_step_gl<ASCII, 4>(stream, a, list, n_list, D, op, changed, stamp, step);
+    else if (a.mean_ml <= 12)
+        pj_step_gl<ASCII, 8>(stream, a, list, n_list, D, op, changed, stamp, step);
+    else
+        pj_step_gl<ASCII, 16>(stream, a, list, n_list, D, op, changed, stamp, step);
 }
 
 void launch_pj_step(hipStream_t stream, const LzArgs &a, bool ascii, const uint64_t *list, uint64_t n_list, uint32_t *D, int op,

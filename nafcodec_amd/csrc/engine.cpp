@@ -295,29 +295,51 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
             // the passes' last pending list is exactly what is left (counters[3] names it); without the lists: collect from the flags
             const uint64_t *plist = nullptr;
             if (la.plist[0] && la.plist[1] && cnt[3] < 2 && cnt[4 + cnt[3]] == n_pending) plist = la.plist[cnt[3]];
-            if ((plist || d_pj_list_.alloc(n_pending * sizeof(uint64_t))) &&
-                d_pj_dist_.alloc(static_cast<size_t>(expect_) * sizeof(uint32_t) + 16) && d_pj_stamp_.alloc(n_pending + 16)) {
+            // A few pending LONG matches are a handful of chains of whole-block runs (a Length section of equal
+            // reads is one run per block, each waiting for the block before it): walking on pass by pass costs
+            // microseconds per link, pointer jumping would sweep their millions of elements a dozen times.
+            bool few = false;
+            // (long matches only: a chain of short ones is one link per pass -- thousands of launches -- while
+            //  pointer jumping sweeps its few elements in a dozen)
+            if (plist && n_pending <= lz_few_pending() && la.mean_ml >= 1024) {
+                uint32_t next_pass = lz_passes_done() + 1;
+                for (int batch = 0; batch < 256 && cnt[0] > 0 && cnt[0] <= lz_few_pending(); batch++) {
+                    const unsigned long long before = cnt[0];
+                    launch_lz_more_passes(stream, la, ascii, static_cast<uint32_t>(cnt[3]), next_pass, 64);
+                    next_pass += 64;
+                    if (!hip_ok(hipMemcpyAsync(cnt, la.counters, sizeof cnt, hipMemcpyDeviceToHost, stream)) ||
+                        !hip_ok(hipStreamSynchronize(stream)))
+                        break;
+                    if (cnt[0] == before) break;                   // no progress: leave it to the stage below
+                }
+                few = cnt[0] == 0;
+                lz_residue_ = n_pending;
+                plist = (cnt[3] < 2 && cnt[4 + cnt[3]] == cnt[0]) ? la.plist[cnt[3]] : nullptr;
+            }
+            const uint64_t n_left = cnt[0];
+            if (!few && n_left > 0 && (plist || d_pj_list_.alloc(n_left * sizeof(uint64_t))) &&
+                d_pj_dist_.alloc(static_cast<size_t>(expect_) * sizeof(uint32_t) + 16) && d_pj_stamp_.alloc(n_left + 16)) {
                 uint32_t *D = d_pj_dist_.as<uint32_t>();
                 uint8_t *stamp = d_pj_stamp_.bytes();
                 (void)hipMemsetAsync(D, 0, static_cast<size_t>(expect_) * sizeof(uint32_t), stream);
-                (void)hipMemsetAsync(stamp, 0, n_pending, stream);
+                (void)hipMemsetAsync(stamp, 0, n_left, stream);
                 if (!plist) {
                     launch_pj_collect(stream, la, d_pj_list_.as<uint64_t>());
                     plist = d_pj_list_.as<uint64_t>();
                 }
-                launch_pj_step(stream, la, ascii, plist, n_pending, D, 0, changed, stamp, 0);
+                launch_pj_step(stream, la, ascii, plist, n_left, D, 0, changed, stamp, 0);
                 for (int it = 0; it < 64 && !done; it++) {           // chain length halves per step
                     (void)hipMemsetAsync(changed, 0, sizeof(uint32_t), stream);
-                    launch_pj_step(stream, la, ascii, plist, n_pending, D, 1, changed, stamp, static_cast<uint32_t>(it) + 1);
+                    launch_pj_step(stream, la, ascii, plist, n_left, D, 1, changed, stamp, static_cast<uint32_t>(it) + 1);
                     uint32_t ch = 1;
                     if (!hip_ok(hipMemcpyAsync(&ch, changed, sizeof ch, hipMemcpyDeviceToHost, stream)) ||
                         !hip_ok(hipStreamSynchronize(stream)))
                         break;
                     done = ch == 0;
                 }
-                if (done) launch_pj_step(stream, la, ascii, plist, n_pending, D, 2, changed, stamp, 0);
+                if (done) launch_pj_step(stream, la, ascii, plist, n_left, D, 2, changed, stamp, 0);
             }
-            if (!done) launch_lz_ordered(stream, la, ascii);         // no scratch memory / no convergence: frame order
+            if (!done && !few) launch_lz_ordered(stream, la, ascii);   // no scratch memory / no convergence: frame order
         }
         if (timer) timer->end(stream);
     }

@@ -100,6 +100,11 @@ struct LzArgs {
 };
 // rep chain + literal scatter + the fixed number of match passes (asynchronous)
 void launch_lz_execute(hipStream_t stream, const LzArgs &args, bool ascii);
+// a short pending list (<= lz_few_pending() matches: a few long chains of long matches) is walked on, `n` more passes
+// at a time: cur = counters[3] (list that holds what is pending), first_pass = number of the next pass
+uint32_t lz_passes_done();
+uint32_t lz_few_pending();
+void launch_lz_more_passes(hipStream_t stream, const LzArgs &args, bool ascii, uint32_t cur, uint32_t first_pass, uint32_t n);
 // what the passes left pending (args.counters[0] != 0):
 //   pointer jumping: collect the pending list, then op 0 (init D), op 1 (jump, repeat while *changed), op 2 (copy)
 void launch_pj_collect(hipStream_t stream, const LzArgs &args, uint64_t *list);

@@ -1045,6 +1045,7 @@ __device__ inline void unpack_dword(uint32_t w, uint32_t t0, uint32_t t1, uint32
 // match of `ml` packed bytes at distance `off` copies ml 16-bit elements at distance off, and
 // literals are expanded while they are scattered.  The ASCII buffer itself is the LZ window.
 constexpr uint32_t kLzShort = 48;        // runs up to this many elements are copied by their own thread
+constexpr uint32_t kLzFewPending = 65536;   // lists this short keep being walked pass by pass (launch_lz_more_passes), never pointer-jumped
 constexpr uint32_t kLzPasses = 64;       // at most; the first walks every block, the others the list of what is still pending
 
 __device__ inline uint32_t rep_resolve(uint32_t tok, const uint32_t *init, bool *bad) {
@@ -1395,7 +1396,7 @@ __global__ void k_lz_pass_ctl(unsigned long long *counters, uint32_t in, uint32_
     const unsigned long long now = counters[4 + in];       // pending before the coming pass
     const unsigned long long before = counters[7];         // pending before the previous pass
     counters[3] = in;                                      // if the passes stop here, list `in` is the pending list
-    if (pass >= 3 && now * 200 > before * 199) counters[6] = 1;
+    if (now > kLzFewPending && pass >= 3 && now * 200 > before * 199) counters[6] = 1;   // (a short list is cheap to walk: keep going)
     if (now == 0) counters[6] = 1;
     counters[7] = now;
     if (!counters[6]) counters[4 + out] = 0;
@@ -1982,6 +1983,33 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
     }
     // ran to the end: the last pass's output list is the pending list (counters[3]); harmless when stopped earlier
     hipLaunchKernelGGL(k_lz_pass_ctl, dim3(1), dim3(1), 0, stream, a.counters, (kLzPasses & 1u) ^ 1u, kLzPasses & 1u, kLzPasses + 1);
+}
+
+template <bool ASCII>
+static void lz_more_passes(hipStream_t stream, const LzArgs &a, uint32_t cur, uint32_t first_pass, uint32_t n) {
+    unsigned long long *cnt = a.counters + 4;
+    uint64_t lgrid = (static_cast<uint64_t>(kLzFewPending) + 255) / 256;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t in = (cur + i) & 1u, ol = in ^ 1u;
+        hipLaunchKernelGGL(k_lz_pass_ctl, dim3(1), dim3(1), 0, stream, a.counters, in, ol, first_pass + i);
+        hipLaunchKernelGGL(k_lz_match_list<ASCII>, dim3(static_cast<uint32_t>(lgrid)), dim3(256), 0, stream, a.plist[in], cnt + in,
+                           a.plist[ol], cnt + ol, a.seqs, a.meta, a.cidx, a.blk_pending, a.roff, a.counters, a.counters + 6, a.out,
+                           first_pass + i, a.status);
+    }
+    hipLaunchKernelGGL(k_lz_pass_ctl, dim3(1), dim3(1), 0, stream, a.counters, (cur + n) & 1u, ((cur + n) & 1u) ^ 1u, first_pass + n);
+}
+
+uint32_t lz_passes_done() { return kLzPasses; }
+uint32_t lz_few_pending() {                               // NAFGPU_LZ_FEW_PENDING=0 sends every residue to pointer jumping (tests)
+    const char *e = std::getenv("NAFGPU_LZ_FEW_PENDING");  // read per call: a test switches it inside one process
+    return e ? static_cast<uint32_t>(std::atoi(e)) : kLzFewPending;
+}
+
+void launch_lz_more_passes(hipStream_t stream, const LzArgs &a, bool ascii, uint32_t cur, uint32_t first_pass, uint32_t n) {
+    if (ascii)
+        lz_more_passes<true>(stream, a, cur, first_pass, n);
+    else
+        lz_more_passes<false>(stream, a, cur, first_pass, n);
 }
 
 void launch_lz_execute(hipStream_t stream, const LzArgs &a, bool ascii) {

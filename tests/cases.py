@@ -260,6 +260,11 @@ def zstd_payload_cases(scale=1):
     for level, step in ((3, 97), (1, 211), (19, 151)):
         payload = b"".join(zstd_ref.compress_magicless(p, level, True, flush_every=step) for p in parts)
         out.append(("multi_frame_l%d_flush%d" % (level, step), payload, b"".join(parts)))
+    # the Length section of equal-length reads: one whole-block run per block, each copying from the block
+    # before it -- a chain of a few LONG matches, finished pass by pass (launch_lz_more_passes), not pointer-jumped
+    words = (151).to_bytes(4, "little") * (400000 * scale)
+    for level in (1, 3):
+        out.append(("equal_length_words_l%d" % level, zstd_ref.compress_magicless(words, level, True), words))
     return out
 
 

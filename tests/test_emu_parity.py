@@ -53,13 +53,19 @@ def test_fixtures_match_oracle(emu, name):
     assert cases.run_product(blob, {}, emu) == cases.run_oracle(blob, {})
 
 
-def test_pointer_jumping_stage_is_exercised(emu, all_cases):
+def test_pointer_jumping_stage_is_exercised(emu, all_cases, monkeypatch):
+    """Dense chains leave a residue after the passes.  A short residue is walked on pass by pass
+    (default), a long one is pointer-jumped; NAFGPU_LZ_FEW_PENDING=0 sends these small cases down the
+    pointer-jumping path too.  Both must agree with the oracle."""
     import io
     from nafcodec_amd.decoder import Decoder
-    for name, blob, opts in all_cases:
-        if name in ("text_dense_chains", "dna_dense_chains"):
-            res = Decoder(io.BytesIO(blob), _lib=emu).decode_all_device()
-            assert res.lz_residue_matches > 0, name
+    for few in ("65536", "0"):
+        monkeypatch.setenv("NAFGPU_LZ_FEW_PENDING", few)
+        for name, blob, opts in all_cases:
+            if name in ("text_dense_chains", "dna_dense_chains"):
+                res = Decoder(io.BytesIO(blob), _lib=emu).decode_all_device()
+                assert res.lz_residue_matches > 0, name
+                assert cases.run_product(blob, opts, emu) == cases.run_oracle(blob, opts), (name, few)
 
 
 def test_block_range_sharding(emu):

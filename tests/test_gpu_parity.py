@@ -157,17 +157,20 @@ def test_shared_cases_match_oracle(lib):
     assert not bad
 
 
-def test_pointer_jumping_stage_is_exercised(lib):
+def test_pointer_jumping_stage_is_exercised(lib, monkeypatch):
     """Dense short-offset chains must leave a residue after the fixed match passes (else this test
-    stopped covering the pointer-jumping stage) and still decode bit-exactly."""
+    stopped covering the stages behind them) and still decode bit-exactly -- through the pass-by-pass
+    continuation a short residue takes by default, and (NAFGPU_LZ_FEW_PENDING=0) through pointer jumping."""
     import cases
     import nafcodec_amd
-    for name, blob, opts in cases.build_cases(scale=4):
-        if name in ("text_dense_chains", "dna_dense_chains"):
+    todo = [c for c in cases.build_cases(scale=4) if c[0] in ("text_dense_chains", "dna_dense_chains")]
+    for few in ("65536", "0"):
+        monkeypatch.setenv("NAFGPU_LZ_FEW_PENDING", few)
+        for name, blob, opts in todo:
             dec = nafcodec_amd.Decoder(io.BytesIO(blob))
             res = dec.decode_all_device()
             assert res.lz_residue_matches > 0, name
-            assert cases.run_product(blob, opts) == cases.run_oracle(blob, opts)
+            assert cases.run_product(blob, opts) == cases.run_oracle(blob, opts), (name, few)
 
 
 def test_corrupted_archives_terminate_and_never_disagree_silently(lib):

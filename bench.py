@@ -43,12 +43,18 @@ def parse_args():
                     help="size of the CPU-baseline sample (0 = auto, about 15 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--rehearsal-lib", default="",
+                    help="tests only: run the control flow against another build of the library (the CPU harness); "
+                         "the line printed then carries no metric and no value")
     return ap.parse_args()
 
 
-def cpu_baseline(lib, n_bases_target, mask):
+def cpu_baseline(lib, n_bases_target, mask, device):
     """The oracle (kind "port": CPU restatement of the reference pipeline, one thread) timed on a
-    bounded sample of the same workload.  Returns the cpu_baseline JSON object."""
+    bounded sample of the same workload -- and used as the CHECKER of a GPU decode of that same sample:
+    the oracle's bases and record table (position-keyed checksums accumulated in C while it drains its
+    iterator) must equal what the HIP path produces from the same archive bytes.
+    Returns (cpu_baseline JSON object, bases checked against the oracle)."""
     from oracle import oracle
     # calibrate on a small sample, then size the real one for ~15 s of single-thread work
     probe_bases = 8_000_000
@@ -56,22 +62,49 @@ def cpu_baseline(lib, n_bases_target, mask):
     blob = ctypes.string_at(arc.bytes, arc.n)
     lib.c.nafgpu_synth_free(ctypes.byref(arc))
     t0 = time.perf_counter()
-    n = sum(len(r.sequence) for r in oracle.Decoder(blob, raw=True))
+    n = oracle.Decoder(blob).drain(want_hash=False).n_bases
     rate = n / (time.perf_counter() - t0)
-    sample = int(n_bases_target) if n_bases_target else int(min(max(rate * 15.0, probe_bases), 4e9))
+    sample = int(n_bases_target) if n_bases_target else int(min(max(rate * 12.0, probe_bases), 4e9))
     arc = lib.synth(sample, seed=0x4E4146, with_mask=mask)
-    blob = ctypes.string_at(arc.bytes, arc.n)
-    lib.c.nafgpu_synth_free(ctypes.byref(arc))
-    best = None
-    for _ in range(2):
-        t0 = time.perf_counter()
-        n = sum(len(r.sequence) for r in oracle.Decoder(blob, raw=True))
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    return {"value": round(n / best / 1e9, 4), "unit": "Gbases/s", "cores": 1, "kind": "port",
-            "sample": "%d bases (%.1f MB archive) of the same synthetic workload, CPU oracle "
-                      "(oracle/*.c: scalar zstd + reader.rs restatement), best of 2, host has %d cores"
-                      % (n, len(blob) / 1e6, os.cpu_count() or 0)}
+    try:
+        blob = ctypes.string_at(arc.bytes, arc.n)
+        best, want = None, None
+        for with_hash in (False, True):          # the second pass also accumulates the checker's checksums
+            t0 = time.perf_counter()
+            r = oracle.Decoder(blob).drain(want_hash=with_hash)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            want = r
+        n = want.n_bases
+        # the same archive through the HIP path
+        opts = _ffi_mod().Opts()
+        lib.c.nafgpu_opts_default(ctypes.byref(opts))
+        opts.device = device
+        h, err, res = ctypes.c_void_p(), _ffi_mod().Error(), _ffi_mod().DeviceResult()
+        if lib.c.nafgpu_open_bytes(blob, len(blob), ctypes.byref(opts), ctypes.byref(h), ctypes.byref(err)) != 0:
+            raise RuntimeError("open failed: %s" % err.message.decode())
+        try:
+            if lib.c.nafgpu_decode_all_device(h, ctypes.byref(res)) != 0:
+                lib.c.nafgpu_last_error(h, ctypes.byref(err))
+                raise RuntimeError("decode failed: %s" % err.message.decode())
+            hs, he = ctypes.c_uint64(), ctypes.c_uint64()
+            lib.c.nafgpu_hash64_device(h, res.d_sequence, res.n_bases, ctypes.byref(hs))
+            lib.c.nafgpu_hash64_device(h, res.d_record_end, 8 * res.n_records, ctypes.byref(he))
+            if (res.n_bases, res.n_records, hs.value, he.value) != (want.n_bases, want.n_records, want.seq_hash, want.ends_hash):
+                raise RuntimeError("GPU decode of the cpu_baseline sample differs from the oracle's output")
+        finally:
+            lib.c.nafgpu_close(h)
+    finally:
+        lib.c.nafgpu_synth_free(ctypes.byref(arc))
+    return ({"value": round(n / best / 1e9, 4), "unit": "Gbases/s", "cores": 1, "kind": "port",
+             "sample": "%d bases (%.1f MB archive) of the same synthetic workload, CPU oracle "
+                       "(oracle/*.c: scalar zstd + reader.rs restatement), best of 2, host has %d cores"
+                       % (n, len(blob) / 1e6, os.cpu_count() or 0)}, n)
+
+
+def _ffi_mod():
+    from nafcodec_amd import _ffi
+    return _ffi
 
 
 def committed_traffic(n_bases):
@@ -103,9 +136,13 @@ def main():
         args.gpus = world
 
     from nafcodec_amd import _ffi
-    # raises if libnafgpu.so is missing: no CPU fallback.  NAFGPU_LIB selects another BUILD OF THE SAME
-    # LIBRARY for A/B runs in one process environment (kernel variants); it is not a fallback path.
-    lib = _ffi.Library(os.environ["NAFGPU_LIB"]) if os.environ.get("NAFGPU_LIB") else _ffi.default()
+    # raises if libnafgpu.so is missing: no CPU fallback.  Nothing in the environment may redirect the
+    # measured path: the product library is the in-tree nafcodec_amd/libnafgpu.so, without debug switches.
+    for var in ("NAFGPU_LIB", "NAFGPU_K1_DEBUG", "NAFGPU_MASK_DEBUG", "NAFGPU_K1_LDS_PAD", "NAFGPU_PJ_MAX_DIST",
+                "NAFGPU_LZ_FEW_PENDING"):
+        if os.environ.get(var):
+            raise SystemExit("bench.py: %s is set; refusing to print a headline from a redirected or ablated build" % var)
+    lib = _ffi.Library(args.rehearsal_lib) if args.rehearsal_lib else _ffi.default()
     dist = torch = None
     tdev = "cpu"
     if world > 1:
@@ -231,7 +268,12 @@ def main():
                      "synth_s": round(t_gen, 1), "upload_s": round(t_upload, 2)},
         }
         if not args.no_cpu and world == 1:       # reported baseline, rank 0 at N=1 only
-            line["cpu_baseline"] = cpu_baseline(lib, args.cpu_sample_bases, args.mask)
+            line["cpu_baseline"], checked = cpu_baseline(lib, args.cpu_sample_bases, args.mask, device)
+            line["config"]["oracle_checked_bases"] = checked
+            line["config"]["workload"] += "; GPU decode of a %d-base archive of the same generator equals the CPU oracle's output" % checked
+        if args.rehearsal_lib:                   # control-flow rehearsal on the CPU harness: never a measurement
+            line.update({"metric": "REHEARSAL on %s -- not a measurement" % os.path.basename(args.rehearsal_lib),
+                         "value": None, "roofline": None})
         print(json.dumps(line), flush=True)
 
     lib.c.nafgpu_close(h)

@@ -250,8 +250,9 @@ typedef struct {
 int nafgpu_synth_write(const nafgpu_synth_spec *spec, nafgpu_synth_archive *out);
 void nafgpu_synth_free(nafgpu_synth_archive *a);
 
-/* order-sensitive 64-bit checksum used for full-size parity checks ("checksum of checksums"):
- * sum over 4 KiB chunks c of mix(c, sum_i (byte_i + 1) * (2 i + 1)) -- see hash64.h */
+/* order-sensitive 64-bit checksum used for full-size parity checks: sum over the 8-byte words w_j of
+ * mix64(w_j ^ (j + 1) * K) -- every word is mixed non-linearly with its position before it is added, so
+ * byte errors cannot cancel -- see hash64.h */
 uint64_t nafgpu_hash64_host(const uint8_t *p, uint64_t n);
 int nafgpu_hash64_device(const nafgpu_decoder *dec, const void *d_ptr, uint64_t n, uint64_t *out);
 /* same, for a buffer that starts at 4 KiB chunk `first_chunk` of a larger object: the values of

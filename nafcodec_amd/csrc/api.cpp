@@ -13,7 +13,10 @@
 #include <string>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include "../../include/nafgpu.h"
 #include "container.h"
@@ -69,45 +72,21 @@ private:
     uint8_t *buf_ = nullptr;
 };
 
-bool utf8_valid(const uint8_t *p, uint64_t n) {
-    uint64_t i = 0;
-    while (i < n) {
-        const uint8_t c = p[i];
-        if (c < 0x80) {
-            i++;
-            continue;
-        }
-        int extra;
-        uint32_t cp, min;
-        if ((c & 0xE0) == 0xC0) {
-            extra = 1; cp = c & 0x1F; min = 0x80;
-        } else if ((c & 0xF0) == 0xE0) {
-            extra = 2; cp = c & 0x0F; min = 0x800;
-        } else if ((c & 0xF8) == 0xF0) {
-            extra = 3; cp = c & 0x07; min = 0x10000;
-        } else {
-            return false;
-        }
-        if (i + uint64_t(extra) >= n) return false;
-        for (int k = 1; k <= extra; k++) {
-            if ((p[i + uint64_t(k)] & 0xC0) != 0x80) return false;
-            cp = (cp << 6) | (p[i + uint64_t(k)] & 0x3F);
-        }
-        if (cp < min || cp > 0x10FFFF || (cp >= 0xD800 && cp <= 0xDFFF)) return false;
-        i += uint64_t(extra) + 1;
-    }
-    return true;
-}
-
 }  // namespace
 
 struct nafgpu_decoder {
     nafgpu_opts opts{};
     nafgpu_header header{};
     SectionInfo sec[kNumSections];
-    std::vector<uint8_t> owned;          // archive bytes when we read them ourselves
+    // archive bytes: borrowed (open_bytes), a read-only file mapping (open_path: no copy, pages come in as the
+    // host walk and the uploads touch them) or an anonymous mapping filled from a reader (open_io)
+    void *map = nullptr;
+    size_t map_len = 0;
     const uint8_t *bytes = nullptr;
     size_t n_bytes = 0;
+    ~nafgpu_decoder() {
+        if (map) (void)munmap(map, map_len);
+    }
     ArchiveJob job;
     bool device_ready = false, decoded = false;
     Failure fatal;                       // device failure: every later call reports it
@@ -202,20 +181,29 @@ int cstring_next(const std::vector<uint8_t> &buf, uint64_t *pos, nafgpu_field *o
     return 1;
 }
 
-int open_common(std::unique_ptr<nafgpu_decoder> d, const nafgpu_opts *opts, nafgpu_decoder **out, nafgpu_error *err) {
+void set_opts(nafgpu_decoder *d, const nafgpu_opts *opts) {
     if (opts)
         d->opts = *opts;
     else
         nafgpu_opts_default(&d->opts);
     if (d->opts.shard_count <= 0) d->opts.shard_count = 1;
-    Failure f = parse_archive(d->bytes, d->n_bytes, &d->header, d->sec);
+}
+
+int open_common(std::unique_ptr<nafgpu_decoder> d, nafgpu_decoder **out, nafgpu_error *err, const NeedFn *need = nullptr) {
+    Failure f = parse_archive(d->bytes, d->n_bytes, &d->header, d->sec, need);
     if (!f.ok()) {
         f.to_c(err);
         return f.status;
     }
     const bool want[kNumSections] = {d->opts.id != 0, d->opts.comment != 0, true, d->opts.mask != 0,
                                      d->opts.sequence != 0, d->opts.quality != 0};
-    for (int s = 0; s < kNumSections; s++) d->use[s] = d->sec[s].present && want[s];
+    for (int s = 0; s < kNumSections; s++) {
+        d->use[s] = d->sec[s].present && want[s];
+        // the payloads of the selected sections (the reference seeks over the others, mod.rs:228)
+        if (need && d->use[s] && d->sec[s].offset < d->n_bytes)
+            (*need)(static_cast<size_t>(d->sec[s].offset),
+                    static_cast<size_t>(std::min<uint64_t>(d->sec[s].compressed_size, d->n_bytes - d->sec[s].offset)));
+    }
     *out = d.release();
     if (err) Failure().to_c(err);
     return NAFGPU_OK;
@@ -256,48 +244,81 @@ int nafgpu_open_bytes(const uint8_t *bytes, size_t n, const nafgpu_opts *opts, n
     if (!d) return NAFGPU_E_DEVICE;
     d->bytes = bytes;
     d->n_bytes = n;
-    return open_common(std::move(d), opts, out, err);
+    set_opts(d.get(), opts);
+    return open_common(std::move(d), out, err);
 }
 
 int nafgpu_open_path(const char *path, const nafgpu_opts *opts, nafgpu_decoder **out, nafgpu_error *err) {
     if (!out || !path) return NAFGPU_E_INVALID_ARG;
     std::unique_ptr<nafgpu_decoder> d(new (std::nothrow) nafgpu_decoder);
     if (!d) return NAFGPU_E_DEVICE;
-    FILE *fp = std::fopen(path, "rb");                             // File::open, mod.rs:163
-    if (!fp) {
+    const int fd = ::open(path, O_RDONLY | O_CLOEXEC);              // File::open, mod.rs:163
+    if (fd < 0) {
         Failure f = errno_failure(path, errno);
         f.to_c(err);
         return f.status;
     }
     struct stat stt;
-    if (fstat(fileno(fp), &stt) == 0 && S_ISDIR(stt.st_mode)) {
-        std::fclose(fp);
+    std::memset(&stt, 0, sizeof stt);
+    if (fstat(fd, &stt) != 0) {
+        Failure f = errno_failure(path, errno);
+        ::close(fd);
+        f.to_c(err);
+        return f.status;
+    }
+    if (S_ISDIR(stt.st_mode)) {
+        ::close(fd);
         Failure f = errno_failure(path, EISDIR);
         f.to_c(err);
         return f.status;
     }
-    // one bulk read replaces the IoSlice lock+seek+read refills (ioslice.rs:28-41)
-    std::vector<uint8_t> &buf = d->owned;
-    if (stt.st_size > 0) buf.reserve(static_cast<size_t>(stt.st_size));
-    uint8_t chunk[1 << 16];
-    for (;;) {
-        size_t got = std::fread(chunk, 1, sizeof chunk, fp);
-        if (got) buf.insert(buf.end(), chunk, chunk + got);
-        if (got < sizeof chunk) {
-            if (std::ferror(fp)) {
-                int e = errno;
-                std::fclose(fp);
-                Failure f = errno_failure(path, e);
+    // One read-only mapping replaces the IoSlice lock+seek+read refills (ioslice.rs:28-41): nothing is copied on
+    // the host; the frame walk touches a page per zstd block and the uploads stream the payloads to HBM.
+    // (Not a regular file -- a pipe, a character device: drain it through read().)
+    if (S_ISREG(stt.st_mode) && stt.st_size > 0) {
+        void *m = mmap(nullptr, static_cast<size_t>(stt.st_size), PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) {
+            Failure f = errno_failure(path, errno);
+            ::close(fd);
+            f.to_c(err);
+            return f.status;
+        }
+        (void)madvise(m, static_cast<size_t>(stt.st_size), MADV_SEQUENTIAL);
+        d->map = m;
+        d->map_len = static_cast<size_t>(stt.st_size);
+        d->bytes = static_cast<const uint8_t *>(m);
+        d->n_bytes = d->map_len;
+        ::close(fd);
+    } else if (!S_ISREG(stt.st_mode)) {
+        std::vector<uint8_t> buf;
+        uint8_t chunk[1 << 16];
+        for (;;) {
+            const ssize_t got = ::read(fd, chunk, sizeof chunk);
+            if (got < 0) {
+                if (errno == EINTR) continue;
+                Failure f = errno_failure(path, errno);
+                ::close(fd);
                 f.to_c(err);
                 return f.status;
             }
-            break;
+            if (got == 0) break;
+            buf.insert(buf.end(), chunk, chunk + got);
         }
+        ::close(fd);
+        if (!buf.empty()) {
+            void *m = mmap(nullptr, buf.size(), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (m == MAP_FAILED) return NAFGPU_E_DEVICE;
+            std::memcpy(m, buf.data(), buf.size());
+            d->map = m;
+            d->map_len = buf.size();
+            d->bytes = static_cast<const uint8_t *>(m);
+            d->n_bytes = buf.size();
+        }
+    } else {
+        ::close(fd);                                               // empty file: Io(UnexpectedEof) from the header parse
     }
-    std::fclose(fp);
-    d->bytes = buf.data();
-    d->n_bytes = buf.size();
-    return open_common(std::move(d), opts, out, err);
+    set_opts(d.get(), opts);
+    return open_common(std::move(d), out, err);
 }
 
 int nafgpu_open_io(nafgpu_read_fn read, nafgpu_seek_fn seek, void *ctx, const nafgpu_opts *opts, nafgpu_decoder **out,
@@ -305,22 +326,91 @@ int nafgpu_open_io(nafgpu_read_fn read, nafgpu_seek_fn seek, void *ctx, const na
     if (!out || !read) return NAFGPU_E_INVALID_ARG;
     std::unique_ptr<nafgpu_decoder> d(new (std::nothrow) nafgpu_decoder);
     if (!d) return NAFGPU_E_DEVICE;
-    (void)seek;   // the whole reader is drained front to back: no seeks are needed any more
-    std::vector<uint8_t> &buf = d->owned;
-    std::vector<uint8_t> chunk(1 << 20);
-    for (;;) {
-        int64_t got = read(ctx, chunk.data(), chunk.size());
-        if (got < 0) {
-            Failure f = errno_failure("read", static_cast<int>(-got));
-            f.to_c(err);
-            return f.status;
+    set_opts(d.get(), opts);
+    auto io_fail = [&](const char *what, int64_t rc) {
+        Failure f = errno_failure(what, static_cast<int>(-rc));
+        f.to_c(err);
+        return f.status;
+    };
+    // R: Read + Seek (mod.rs:169-172).  The archive starts at the reader's current position, as in the reference
+    // (fill_buf from wherever the reader stands).  With a working seek only the header, the section table and the
+    // payloads of the SELECTED sections are read -- with_reader seeks over the others (mod.rs:228) -- into an
+    // anonymous mapping as long as the archive (untouched pages cost nothing); without one the reader is drained.
+    int64_t pos0 = -1, end = -1;
+    if (seek) {
+        pos0 = seek(ctx, 0, SEEK_CUR);
+        if (pos0 >= 0) end = seek(ctx, 0, SEEK_END);
+        if (pos0 >= 0 && end >= pos0) {
+            const int64_t back = seek(ctx, pos0, SEEK_SET);
+            if (back < 0) return io_fail("seek", back);
+        } else {
+            pos0 = end = -1;                                       // not seekable after all: drain
         }
-        if (got == 0) break;
-        buf.insert(buf.end(), chunk.begin(), chunk.begin() + got);
     }
-    d->bytes = buf.data();
-    d->n_bytes = buf.size();
-    return open_common(std::move(d), opts, out, err);
+    if (pos0 < 0) {
+        std::vector<uint8_t> buf, chunk(1 << 20);
+        for (;;) {
+            const int64_t got = read(ctx, chunk.data(), chunk.size());
+            if (got < 0) return io_fail("read", got);
+            if (got == 0) break;
+            buf.insert(buf.end(), chunk.begin(), chunk.begin() + std::min<int64_t>(got, static_cast<int64_t>(chunk.size())));
+        }
+        if (!buf.empty()) {
+            void *m = mmap(nullptr, buf.size(), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (m == MAP_FAILED) return NAFGPU_E_DEVICE;
+            std::memcpy(m, buf.data(), buf.size());
+            d->map = m;
+            d->map_len = buf.size();
+            d->bytes = static_cast<const uint8_t *>(m);
+            d->n_bytes = buf.size();
+        }
+        return open_common(std::move(d), out, err);
+    }
+    const size_t total = static_cast<size_t>(end - pos0);
+    if (total == 0) return open_common(std::move(d), out, err);
+    void *m = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (m == MAP_FAILED) return NAFGPU_E_DEVICE;
+    d->map = m;
+    d->map_len = total;
+    d->bytes = static_cast<const uint8_t *>(m);
+    d->n_bytes = total;
+    // loaded state per 64 KiB chunk; a request loads every missing chunk it overlaps, one seek + reads per gap
+    constexpr size_t kChunk = size_t(64) << 10;
+    std::vector<uint8_t> have((total + kChunk - 1) / kChunk, 0);
+    int64_t io_rc = 0;                                             // first reader error (reported after the parse)
+    uint8_t *base = static_cast<uint8_t *>(m);
+    NeedFn need = [&](size_t off, size_t len) {
+        if (io_rc < 0 || len == 0 || off >= total) return;
+        const size_t c0 = off / kChunk, c1 = (std::min(off + len, total) - 1) / kChunk;
+        for (size_t c = c0; c <= c1; c++) {
+            if (have[c]) continue;
+            size_t ce = c;
+            while (ce + 1 <= c1 && !have[ce + 1]) ce++;
+            const size_t lo = c * kChunk, hi = std::min((ce + 1) * kChunk, total);
+            int64_t rc = seek(ctx, pos0 + static_cast<int64_t>(lo), SEEK_SET);
+            size_t at = lo;
+            while (rc >= 0 && at < hi) {
+                rc = read(ctx, base + at, hi - at);
+                if (rc == 0) break;                                // shorter than seek(End) promised: the rest reads as zeros
+                if (rc > 0) at += static_cast<size_t>(std::min<int64_t>(rc, static_cast<int64_t>(hi - at)));
+            }
+            if (rc < 0) {
+                io_rc = rc;
+                return;
+            }
+            for (size_t k = c; k <= ce; k++) have[k] = 1;
+            c = ce;
+        }
+    };
+    const int rc = open_common(std::move(d), out, err, &need);
+    if (io_rc < 0) {
+        if (rc == NAFGPU_OK) {
+            nafgpu_close(*out);
+            *out = nullptr;
+        }
+        return io_fail("read", io_rc);
+    }
+    return rc;
 }
 
 void nafgpu_get_header(const nafgpu_decoder *d, nafgpu_header *out) { *out = d->header; }

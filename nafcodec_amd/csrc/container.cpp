@@ -16,6 +16,37 @@ void Failure::to_c(nafgpu_error *e) const {
     e->message[sizeof(e->message) - 1] = 0;
 }
 
+// std::str::from_utf8 (reader.rs:108-109, parser.rs:133-137, mod.rs:362,368)
+bool utf8_valid(const uint8_t *p, uint64_t n) {
+    uint64_t i = 0;
+    while (i < n) {
+        const uint8_t c = p[i];
+        if (c < 0x80) {
+            i++;
+            continue;
+        }
+        int extra;
+        uint32_t cp, min;
+        if ((c & 0xE0) == 0xC0) {
+            extra = 1; cp = c & 0x1F; min = 0x80;
+        } else if ((c & 0xF0) == 0xE0) {
+            extra = 2; cp = c & 0x0F; min = 0x800;
+        } else if ((c & 0xF8) == 0xF0) {
+            extra = 3; cp = c & 0x07; min = 0x10000;
+        } else {
+            return false;
+        }
+        if (i + uint64_t(extra) >= n) return false;
+        for (int k = 1; k <= extra; k++) {
+            if ((p[i + uint64_t(k)] & 0xC0) != 0x80) return false;
+            cp = (cp << 6) | (p[i + uint64_t(k)] & 0x3F);
+        }
+        if (cp < min || cp > 0x10FFFF || (cp >= 0xD800 && cp <= 0xDFFF)) return false;
+        i += uint64_t(extra) + 1;
+    }
+    return true;
+}
+
 Failure parse_varint(const uint8_t *p, size_t n, uint64_t *value, size_t *used, bool *incomplete) {
     *incomplete = false;
     size_t k = 0;
@@ -73,9 +104,13 @@ Failure parse_header(const uint8_t *p, size_t n, nafgpu_header *h, size_t *used,
     return Failure();
 }
 
-Failure parse_archive(const uint8_t *p, size_t n, nafgpu_header *h, SectionInfo sec[kNumSections]) {
+Failure parse_archive(const uint8_t *p, size_t n, nafgpu_header *h, SectionInfo sec[kNumSections], const NeedFn *need) {
     size_t i = 0, u = 0;
     bool inc = false;
+    auto want = [&](size_t off, size_t len) {          // bytes about to be parsed (a lazily loaded source fetches them)
+        if (need && off < n) (*need)(off, len < n - off ? len : n - off);
+    };
+    want(0, 64);
     Failure f = parse_header(p, n, h, &i, &inc);
     if (!f.ok()) return f;
     // The reference hits `todo!()` (error.rs:50) when a title or size pair is cut short; we
@@ -83,15 +118,20 @@ Failure parse_archive(const uint8_t *p, size_t n, nafgpu_header *h, SectionInfo 
     auto cut = []() { return Failure::make(NAFGPU_E_PANIC, "archive ends inside a section header"); };
     if (h->flags & 0x40) {                                         // Title, mod.rs:191-196
         uint64_t tsize = 0;
+        want(i, 16);
         f = parse_varint(p + i, n - i, &tsize, &u, &inc);
         if (!f.ok()) return inc ? cut() : f;
         i += u;
         if (tsize > n - i) return cut();
+        want(i, static_cast<size_t>(tsize));
+        if (!utf8_valid(p + i, tsize))                             // map_res(take(size), from_utf8), parser.rs:133-137
+            return Failure::nom(NAFGPU_NOM_MAPRES, "title is not valid UTF-8");
         i += static_cast<size_t>(tsize);
     }
     for (int k = 0; k < kNumSections; k++) {                       // setup_block! x6, mod.rs:235-242
         if (!(h->flags & kSectionFlag[k])) continue;
         size_t at = i < n ? i : n;
+        want(at, 32);
         f = parse_varint(p + at, n - at, &sec[k].original_size, &u, &inc);
         if (!f.ok()) return inc ? cut() : f;
         i += u;

@@ -4,6 +4,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <string>
 
 #include "../../include/nafgpu.h"
@@ -37,11 +38,16 @@ struct Failure {                   // maps 1:1 onto nafgpu_error
     void to_c(nafgpu_error *e) const;
 };
 
+// what std::str::from_utf8 accepts
+bool utf8_valid(const uint8_t *p, uint64_t n);
 // parser::variable_u64 (parser.rs:27-48).  incomplete=true <=> nom::Err::Incomplete.
 Failure parse_varint(const uint8_t *p, size_t n, uint64_t *value, size_t *used, bool *incomplete);
 // parser::header (parser.rs:101-123)
 Failure parse_header(const uint8_t *p, size_t n, nafgpu_header *h, size_t *used, bool *incomplete);
-// header + optional title + the six (original_size, compressed_size) pairs (mod.rs:173-242)
-Failure parse_archive(const uint8_t *p, size_t n, nafgpu_header *h, SectionInfo sec[kNumSections]);
+// header + optional title + the six (original_size, compressed_size) pairs (mod.rs:173-242).
+// `need(offset, length)` is called before bytes are parsed: a source that loads lazily (a reader with
+// seek, nafgpu_open_io) fetches just those, as the reference reads the header and seeks over payloads.
+using NeedFn = std::function<void(size_t, size_t)>;
+Failure parse_archive(const uint8_t *p, size_t n, nafgpu_header *h, SectionInfo sec[kNumSections], const NeedFn *need = nullptr);
 
 }  // namespace nafgpu

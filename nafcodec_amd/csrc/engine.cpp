@@ -36,6 +36,12 @@ double now_ms() {
 }  // namespace
 
 // ------------------------------------------------------------------ DevBuf
+bool DevBuf::alloc_items(uint64_t count, uint64_t item_bytes, uint64_t extra_bytes) {
+    // sizes derived from untrusted header fields: refuse anything that does not fit 63 bits instead of wrapping
+    if (item_bytes && count > ((1ull << 62) - extra_bytes) / item_bytes) return false;
+    return alloc(static_cast<size_t>(count * item_bytes + extra_bytes));
+}
+
 bool DevBuf::alloc(size_t bytes) {
     if (ptr_ && bytes <= size_) return true;
     release();
@@ -136,7 +142,8 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
     n_tasks_ = plan_.tasks.size();
     n_copies_ = plan_.copies.size();
     n_seq_blocks_ = plan_.seq_blocks.size();
-    if (plan_.seq_blocks.empty() && plan_.known_out != expect_size)
+    if ((plan_.seq_blocks.empty() && plan_.known_out != expect_size) ||
+        expect_size > static_cast<uint64_t>(plan_.blk_size.size()) * kBlockMax)     // untrusted: no block decodes to more than 128 KiB
         return Failure::io(NAFGPU_IO_INVALID_DATA, "zstd: decoded size differs from the size recorded in the archive");
     out0_ = plan_.sharded ? plan_.shard_out0 : 0;
     out1_ = plan_.sharded ? plan_.shard_out1 : expect_size;
@@ -329,17 +336,23 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
                 }
                 launch_pj_step(stream, la, ascii, plist, n_left, D, 0, changed, stamp, 0);
                 for (int it = 0; it < 64 && !done; it++) {           // chain length halves per step
-                    (void)hipMemsetAsync(changed, 0, sizeof(uint32_t), stream);
+                    (void)hipMemsetAsync(changed, 0, 2 * sizeof(uint32_t), stream);
                     launch_pj_step(stream, la, ascii, plist, n_left, D, 1, changed, stamp, static_cast<uint32_t>(it) + 1);
-                    uint32_t ch = 1;
-                    if (!hip_ok(hipMemcpyAsync(&ch, changed, sizeof ch, hipMemcpyDeviceToHost, stream)) ||
+                    uint32_t ch[2] = {1, 0};                         // [0] a distance grew, [1] a distance could not grow (32-bit limit)
+                    if (!hip_ok(hipMemcpyAsync(ch, changed, sizeof ch, hipMemcpyDeviceToHost, stream)) ||
                         !hip_ok(hipStreamSynchronize(stream)))
                         break;
-                    done = ch == 0;
+                    // no change but an element still points at a pending one (a chain longer than 2^32 elements):
+                    // copying now would read bytes that are not final -- leave it to the frame-order fallback
+                    if (ch[0] == 0 && ch[1] != 0) break;
+                    done = ch[0] == 0;
                 }
                 if (done) launch_pj_step(stream, la, ascii, plist, n_left, D, 2, changed, stamp, 0);
             }
-            if (!done && !few) launch_lz_ordered(stream, la, ascii);   // no scratch memory / no convergence: frame order
+            if (!done && !few) {                                         // no scratch memory / no convergence: frame order
+                if (std::getenv("NAFGPU_DEBUG_PLAN")) std::fprintf(stderr, "[nafgpu] LZ residue of %llu matches finished in frame order\n", static_cast<unsigned long long>(n_left));
+                launch_lz_ordered(stream, la, ascii);
+            }
         }
         if (timer) timer->end(stream);
     }
@@ -423,20 +436,23 @@ Failure ArchiveJob::upload(const uint8_t *bytes, size_t n, const nafgpu_header &
     }
     // ---- derived tables
     bool ok = d_totals_.alloc(8 * sizeof(ScanTotals)) && d_status_.alloc(64) && d_hash_.alloc(16);
-    str_cap_ = h.number_of_sequences;                          // the iterator never hands out more strings than records
-    if (job_[kIds].ready()) ok = ok && d_id_ends_.alloc((str_cap_ + 1) * sizeof(uint64_t));
-    if (job_[kComments].ready()) ok = ok && d_com_ends_.alloc((str_cap_ + 1) * sizeof(uint64_t));
+    // The iterator never hands out more strings than records, and a section holds no more NULs than bytes:
+    // number_of_sequences is an untrusted varint (up to 2^64 - 1) and must not size anything on its own.
+    id_cap_ = job_[kIds].ready() ? std::min<uint64_t>(h.number_of_sequences, job_[kIds].size()) : 0;
+    com_cap_ = job_[kComments].ready() ? std::min<uint64_t>(h.number_of_sequences, job_[kComments].size()) : 0;
+    if (job_[kIds].ready()) ok = ok && d_id_ends_.alloc_items(id_cap_ + 1, sizeof(uint64_t));
+    if (job_[kComments].ready()) ok = ok && d_com_ends_.alloc_items(com_cap_ + 1, sizeof(uint64_t));
     if (job_[kLengths].ready()) {
         rec_cap_ = job_[kLengths].size() / 4;
-        ok = ok && d_rec_ends_.alloc((rec_cap_ + 1) * sizeof(uint64_t));
+        ok = ok && d_rec_ends_.alloc_items(rec_cap_ + 1, sizeof(uint64_t));
     }
     mask_total_bases_ = sec[kSequence].present ? sec[kSequence].original_size : 0;   // mod.rs:236,241,250
     if (job_[kMask].ready()) {
         mask_cap_ = job_[kMask].size();
-        ok = ok && d_mask_ends_.alloc((mask_cap_ + 1) * sizeof(uint64_t));
+        ok = ok && d_mask_ends_.alloc_items(mask_cap_ + 1, sizeof(uint64_t));
     }
     const uint64_t scan_max = std::max({rec_cap_, mask_cap_, static_cast<uint64_t>(job_[kIds].ready() ? job_[kIds].size() : 0),
-                                        static_cast<uint64_t>(job_[kComments].ready() ? job_[kComments].size() : 0), str_cap_});
+                                        static_cast<uint64_t>(job_[kComments].ready() ? job_[kComments].size() : 0)});
     ok = ok && d_scan_tmp_.alloc(scan_tmp_bytes(scan_max));
     if (!ok) return Failure::make(NAFGPU_E_DEVICE, "out of device memory");
     return Failure();
@@ -496,12 +512,12 @@ Failure ArchiveJob::decode() {
     uint32_t *utf8 = status + 8;
     timer_.begin(stream_, StageTimer::kOther);
     if (job_[kIds].ready()) {
-        launch_scan_nul(stream_, job_[kIds].out(), job_[kIds].size(), d_id_ends_.as<uint64_t>(), str_cap_, d_scan_tmp_.bytes(),
+        launch_scan_nul(stream_, job_[kIds].out(), job_[kIds].size(), d_id_ends_.as<uint64_t>(), id_cap_, d_scan_tmp_.bytes(),
                         &totals[2], status);
         launch_utf8_check(stream_, job_[kIds].out(), job_[kIds].size(), utf8, kIds);
     }
     if (job_[kComments].ready()) {
-        launch_scan_nul(stream_, job_[kComments].out(), job_[kComments].size(), d_com_ends_.as<uint64_t>(), str_cap_,
+        launch_scan_nul(stream_, job_[kComments].out(), job_[kComments].size(), d_com_ends_.as<uint64_t>(), com_cap_,
                         d_scan_tmp_.bytes(), &totals[3], status);
         launch_utf8_check(stream_, job_[kComments].out(), job_[kComments].size(), utf8, kComments);
     }

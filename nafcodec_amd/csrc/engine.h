@@ -32,6 +32,7 @@ public:
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     bool alloc(size_t bytes);                 // contents undefined
+    bool alloc_items(uint64_t count, uint64_t item_bytes, uint64_t extra_bytes = 0);   // count * item_bytes + extra_bytes, overflow-checked
     bool upload(const void *host, size_t bytes, hipStream_t stream);   // alloc + async H2D
     void release();
     template <class T>
@@ -170,8 +171,8 @@ public:
     // ids / comments split on NUL on the device (CStringReader): offsets just past each NUL; at most number_of_sequences strings
     const uint64_t *d_id_ends() const { return job_[kIds].ready() ? d_id_ends_.as<uint64_t>() : nullptr; }
     const uint64_t *d_com_ends() const { return job_[kComments].ready() ? d_com_ends_.as<uint64_t>() : nullptr; }
-    uint64_t n_ids() const { return std::min<uint64_t>(id_totals_.count, str_cap_); }
-    uint64_t n_comments() const { return std::min<uint64_t>(com_totals_.count, str_cap_); }
+    uint64_t n_ids() const { return std::min<uint64_t>(id_totals_.count, id_cap_); }
+    uint64_t n_comments() const { return std::min<uint64_t>(com_totals_.count, com_cap_); }
     // bit s set: section s (kIds, kComments, kSequence as text, kQuality) is not valid UTF-8 (Error::Utf8 in the reference)
     uint32_t utf8_invalid() const { return utf8_invalid_; }
     // FASTA (or FASTQ when `with_quality`) text of the first n_rec records, built on the device after decode()
@@ -194,7 +195,7 @@ private:
     Failure fail_[kNumSections];
     DevBuf d_rec_ends_, d_mask_ends_, d_scan_tmp_, d_totals_, d_status_, d_hash_;
     DevBuf d_id_ends_, d_com_ends_, d_fmt_sizes_, d_fmt_off_, d_text_;
-    uint64_t str_cap_ = 0;
+    uint64_t id_cap_ = 0, com_cap_ = 0;
     ScanTotals id_totals_{0, 0}, com_totals_{0, 0};
     uint32_t utf8_invalid_ = 0;
     uint64_t rec_cap_ = 0, mask_cap_ = 0, mask_total_bases_ = 0;

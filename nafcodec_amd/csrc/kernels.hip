@@ -1504,11 +1504,13 @@ enum PjOp { kPjInit = 0, kPjJump = 1, kPjCopy = 2 };
 template <bool ASCII, int OP, int GL>
 __global__ __launch_bounds__(256) void k_pj_step(const uint64_t *__restrict__ list, uint64_t n_list, const Seq *__restrict__ seqs,
                                                  const SeqMeta *__restrict__ meta, const uint32_t *__restrict__ roff, uint32_t *D,
-                                                 uint8_t *out_bytes, uint32_t *changed, uint8_t *stamp, uint32_t step) {
+                                                 uint8_t *out_bytes, uint32_t *changed, uint8_t *stamp, uint32_t step,
+                                                 uint32_t max_dist) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
     const uint32_t tid = threadIdx.x;
     bool any_change = false;
+    bool stuck = false;                  // an element still points at a pending one, but its distance would not fit 32 bits
     bool unresolved = false;             // this lane saw an element whose source is still pending
     auto element = [&](uint64_t p, uint32_t off) {
         if (OP == kPjInit) {
@@ -1517,9 +1519,11 @@ __global__ __launch_bounds__(256) void k_pj_step(const uint64_t *__restrict__ li
             const uint32_t d = D[p];
             const uint32_t da = D[p - d];
             if (da != 0) unresolved = true;
-            if (da != 0 && static_cast<uint64_t>(d) + da <= 0xFFFFFFFFull) {
+            if (da != 0 && static_cast<uint64_t>(d) + da <= max_dist) {
                 D[p] = d + da;
                 any_change = true;
+            } else if (da != 0) {
+                stuck = true;            // changed[1]: the host must not run the copy step (it falls back to frame order)
             }
         } else {
             out[p] = out[p - D[p]];
@@ -1542,7 +1546,8 @@ __global__ __launch_bounds__(256) void k_pj_step(const uint64_t *__restrict__ li
         for (uint32_t k = gl; k < ml; k += GL) element(mpos + k, off);
         if (OP == kPjJump && unresolved) stamp[base + grp] = static_cast<uint8_t>(step);   // same value from every lane that writes
     }
-    if (OP == kPjJump && any_change) *changed = 1;
+    if (OP == kPjJump && any_change) changed[0] = 1;
+    if (OP == kPjJump && stuck) changed[1] = 1;
 }
 
 template <bool ASCII>
@@ -1801,26 +1806,35 @@ __global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_b
 // ======================================================================================
 __global__ __launch_bounds__(256) void k_hash64(const uint8_t *__restrict__ p, uint64_t n, uint64_t first_chunk,
                                                 unsigned long long *result) {
+    // sum over the 8-byte words of hash_word(word, position): any split of the words over threads gives
+    // the same value.  Two words (16 bytes, any alignment) per thread and step.
     __shared__ uint64_t s_part[256];
-    const uint64_t n_chunks = (n + kHashChunk - 1) / kHashChunk;
+    const uint64_t w0 = first_chunk * (kHashChunk / 8), n_full = n / 8;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256 * 2;
     uint64_t acc = 0;
-    for (uint64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        const uint64_t lo = c * kHashChunk;
-        uint64_t s = 0;
-        for (uint32_t k = 0; k < kHashChunk / 256; k++) {
-            const uint64_t i = threadIdx.x + 256ull * k;
-            if (lo + i < n) s += (static_cast<uint64_t>(p[lo + i]) + 1) * (2 * i + 1);
+    for (uint64_t j = (static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x) * 2; j < n_full; j += stride) {
+        if (j + 1 < n_full) {
+            uint64_t w[2];
+            __builtin_memcpy(w, p + 8 * j, 16);
+            acc += hash_word(w[0], w0 + j) + hash_word(w[1], w0 + j + 1);
+        } else {
+            uint64_t w;
+            __builtin_memcpy(&w, p + 8 * j, 8);
+            acc += hash_word(w, w0 + j);
         }
-        s_part[threadIdx.x] = s;
-        __syncthreads();
-        for (uint32_t d = 128; d > 0; d >>= 1) {
-            if (threadIdx.x < d) s_part[threadIdx.x] += s_part[threadIdx.x + d];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) acc += hash_chunk_final(first_chunk + c, s_part[0]);
+    }
+    if ((n & 7) && blockIdx.x == 0 && threadIdx.x == 0) {  // last, zero-padded word
+        uint64_t w = 0;
+        for (uint32_t k = 0; k < (n & 7); k++) w |= static_cast<uint64_t>(p[8 * n_full + k]) << (8 * k);
+        acc += hash_word(w, w0 + n_full);
+    }
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) s_part[threadIdx.x] += s_part[threadIdx.x + d];
         __syncthreads();
     }
-    if (threadIdx.x == 0 && acc) atomicAdd(result, static_cast<unsigned long long>(acc));
+    if (threadIdx.x == 0 && s_part[0]) atomicAdd(result, static_cast<unsigned long long>(s_part[0]));
 }
 
 }  // namespace
@@ -2000,6 +2014,12 @@ static void lz_more_passes(hipStream_t stream, const LzArgs &a, uint32_t cur, ui
 }
 
 uint32_t lz_passes_done() { return kLzPasses; }
+// largest distance a pointer-jumping element may hold (32-bit D); NAFGPU_PJ_MAX_DIST lowers it so that a test can
+// reach the "chain longer than D can express" fallback on a small input
+static uint32_t pj_max_dist() {
+    const char *e = std::getenv("NAFGPU_PJ_MAX_DIST");     // read per call: a test switches it inside one process
+    return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : 0xFFFFFFFFu;
+}
 uint32_t lz_few_pending() {                               // NAFGPU_LZ_FEW_PENDING=0 sends every residue to pointer jumping (tests)
     const char *e = std::getenv("NAFGPU_LZ_FEW_PENDING");  // read per call: a test switches it inside one process
     return e ? static_cast<uint32_t>(std::atoi(e)) : kLzFewPending;
@@ -2043,12 +2063,13 @@ static void pj_step_gl(hipStream_t stream, const LzArgs &a, const uint64_t *list
     uint64_t blocks = (n_list * GL + 255) / 256;
     if (blocks > 256u * 16u) blocks = 256u * 16u;
     const dim3 grid(static_cast<uint32_t>(blocks));
+    const uint32_t max_dist = pj_max_dist();
     if (op == kPjInit)
-        hipLaunchKernelGGL((k_pj_step<ASCII, kPjInit, GL>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed, stamp, step);
+        hipLaunchKernelGGL((k_pj_step<ASCII, kPjInit, GL>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed, stamp, step, max_dist);
     else if (op == kPjJump)
-        hipLaunchKernelGGL((k_pj_step<ASCII, kPjJump, GL>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed, stamp, step);
+        hipLaunchKernelGGL((k_pj_step<ASCII, kPjJump, GL>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed, stamp, step, max_dist);
     else
-        hipLaunchKernelGGL((k_pj_step<ASCII, kPjCopy, GL>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed, stamp, step);
+        hipLaunchKernelGGL((k_pj_step<ASCII, kPjCopy, GL>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed, stamp, step, max_dist);
 }
 
 template <bool ASCII>
@@ -2100,9 +2121,9 @@ void launch_mask_apply(hipStream_t stream, uint8_t *ascii, uint64_t n_bases, uin
 
 void launch_hash64(hipStream_t stream, const uint8_t *p, uint64_t n, uint64_t first_chunk, unsigned long long *result) {
     if (!n) return;
-    uint64_t chunks = (n + kHashChunk - 1) / kHashChunk;
-    if (chunks > 256u * 32u) chunks = 256u * 32u;
-    hipLaunchKernelGGL(k_hash64, dim3(static_cast<uint32_t>(chunks)), dim3(256), 0, stream, p, n, first_chunk, result);
+    uint64_t blocks = (n + kHashChunk - 1) / kHashChunk;   // 4 KiB (two words per thread) per workgroup step
+    if (blocks > 256u * 32u) blocks = 256u * 32u;
+    hipLaunchKernelGGL(k_hash64, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, p, n, first_chunk, result);
 }
 
 }  // namespace nafgpu

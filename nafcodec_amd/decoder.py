@@ -60,17 +60,57 @@ class Decoder:
             path = os.fsencode(file)
             rc = self._lib.c.nafgpu_open_path(path, byref(opts), byref(h), byref(err))
         else:
-            # file-like: drained once through read(), like PyFileRead (pyfile.rs:88-187) but without seeks
-            self._keep = file.read()
-            if not isinstance(self._keep, (bytes, bytearray)):
-                raise TypeError("expected a binary file-like object")
-            self._keep = bytes(self._keep)
-            rc = self._lib.c.nafgpu_open_bytes(self._keep, len(self._keep), byref(opts), byref(h), byref(err))
+            rc = self._open_filelike(file, opts, h, err)
         if rc != _ffi.OK:
             _raise(err)
         self._h = h
         self._header = _ffi.Header()
         self._lib.c.nafgpu_get_header(self._h, byref(self._header))
+
+    def _open_filelike(self, file, opts, h, err):
+        """with_reader (mod.rs:169-256) over a Python file-like, as PyFileRead does (pyfile.rs:88-187): the
+        library calls back into `readinto` (or `read`) and `seek`; with a working seek it reads only the
+        header and the selected sections.  An exception raised by the file object is re-raised as it is."""
+        if not (hasattr(file, "readinto") or hasattr(file, "read")):
+            raise TypeError("expected a path or a binary file-like object")
+        pending = []                                       # exception raised inside a callback
+
+        def on_read(_ctx, buf, cap):
+            try:
+                cap = int(cap)
+                if hasattr(file, "readinto"):              # pyfile.rs:88-132
+                    view = (ctypes.c_uint8 * cap).from_address(ctypes.addressof(buf.contents))
+                    n = file.readinto(memoryview(view).cast("B"))
+                    return int(n or 0)
+                data = file.read(cap)                      # pyfile.rs:134-187
+                if not isinstance(data, (bytes, bytearray, memoryview)):
+                    raise TypeError("expected bytes from read(), found %s" % type(data).__name__)
+                if len(data) > cap:
+                    raise OSError(_errno.EIO, "read() returned more bytes than asked for")
+                ctypes.memmove(buf, bytes(data), len(data))
+                return len(data)
+            except BaseException as e:                     # noqa: BLE001 -- carried across the C boundary
+                pending.append(e)
+                return -(getattr(e, "errno", None) or _errno.EIO)
+
+        def on_seek(_ctx, offset, whence):
+            try:
+                return int(file.seek(int(offset), int(whence)))
+            except BaseException as e:                     # noqa: BLE001
+                pending.append(e)
+                return -(getattr(e, "errno", None) or _errno.ESPIPE)
+
+        seekable = hasattr(file, "seek")
+        try:
+            seekable = seekable and (file.seekable() if hasattr(file, "seekable") else True)
+        except Exception:
+            seekable = False
+        read_cb = _ffi.READ_FN(on_read)
+        seek_cb = _ffi.SEEK_FN(on_seek) if seekable else _ffi.SEEK_FN()
+        rc = self._lib.c.nafgpu_open_io(read_cb, seek_cb, None, byref(opts), byref(h), byref(err))
+        if pending and rc != _ffi.OK:
+            raise pending[0]
+        return rc
 
     # ---- iteration -----------------------------------------------------------------------
     def __iter__(self):

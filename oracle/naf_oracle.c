@@ -152,6 +152,8 @@ static uint64_t section_capacity(const no_decoder *d, int which, uint64_t origin
     return original_size;
 }
 
+static int utf8_valid(const uint8_t *p, uint64_t n);
+
 int no_open(const uint8_t *bytes, size_t n, const no_opts *opts, no_decoder **out, int *nom_code)
 {
     no_header h;
@@ -170,7 +172,12 @@ int no_open(const uint8_t *bytes, size_t n, const no_opts *opts, no_decoder **ou
         i += u;
         if (tsize > n - i)
             return NO_E_PANIC;
-        i += (size_t)tsize; /* UTF-8 validity of the title is not modelled */
+        if (!utf8_valid(bytes + i, tsize)) { /* map_res(take(size), from_utf8), parser.rs:133-137 */
+            if (nom_code)
+                *nom_code = NO_NOM_MAPRES;
+            return NO_E_NOM;
+        }
+        i += (size_t)tsize;
     }
     no_decoder *d = (no_decoder *)calloc(1, sizeof *d);
     if (!d)
@@ -571,4 +578,100 @@ size_t no_mask_units(const no_decoder *d, uint64_t *len, uint8_t *masked, size_t
         k++;
     }
     return k;
+}
+
+/* ---- whole-archive drain with checksums (checker for full-size GPU parity tests) --------
+ * Drains Decoder::next and accumulates, per field, the position-keyed checksum the product's
+ * hash64.h defines (restated here: the checker computes its own value):
+ *   H = sum over 8-byte little-endian words w_j of mix64(w_j ^ (j + 1) * K), last word zero-padded. */
+typedef struct {
+    uint64_t h, n;      /* running sum, bytes fed */
+    uint64_t word;      /* partial word */
+} hash_acc;
+
+static uint64_t drain_mix64(uint64_t x)
+{
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+
+static void hash_feed(hash_acc *a, const uint8_t *p, uint64_t n)
+{
+    uint64_t i = 0;
+    while (i < n && (a->n & 7)) { /* complete the partial word */
+        a->word |= (uint64_t)p[i++] << (8 * (a->n & 7));
+        a->n++;
+        if (!(a->n & 7)) {
+            a->h += drain_mix64(a->word ^ ((a->n / 8) * 0x9E3779B97F4A7C15ull));
+            a->word = 0;
+        }
+    }
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        a->n += 8;
+        a->h += drain_mix64(w ^ ((a->n / 8) * 0x9E3779B97F4A7C15ull));
+    }
+    for (; i < n; i++) {
+        a->word |= (uint64_t)p[i] << (8 * (a->n & 7));
+        a->n++;
+    }
+}
+
+static uint64_t hash_finish(const hash_acc *a)
+{
+    if (a->n & 7)
+        return a->h + drain_mix64(a->word ^ ((a->n / 8 + 1) * 0x9E3779B97F4A7C15ull));
+    return a->h;
+}
+
+int no_drain(no_decoder *d, int want_hash, no_drain_result *out)
+{
+    hash_acc seq = {0, 0, 0}, qual = {0, 0, 0}, ends = {0, 0, 0}, ids = {0, 0, 0}, com = {0, 0, 0};
+    uint64_t end = 0;
+    memset(out, 0, sizeof *out);
+    for (;;) {
+        no_record r;
+        int rc = no_next(d, &r);
+        if (rc == NO_END)
+            break;
+        if (rc != NO_OK)
+            return rc;
+        out->n_records++;
+        if (r.has_length) {
+            end += r.length;
+            if (want_hash)
+                hash_feed(&ends, (const uint8_t *)&end, 8);
+        }
+        if (r.sequence.present) {
+            out->n_bases += r.sequence.len;
+            if (want_hash)
+                hash_feed(&seq, r.sequence.ptr, r.sequence.len);
+        }
+        if (r.quality.present) {
+            out->n_quality += r.quality.len;
+            if (want_hash)
+                hash_feed(&qual, r.quality.ptr, r.quality.len);
+        }
+        if (want_hash && r.id.present) {
+            static const uint8_t nul = 0;
+            hash_feed(&ids, r.id.ptr, r.id.len);
+            hash_feed(&ids, &nul, 1);
+        }
+        if (want_hash && r.comment.present) {
+            static const uint8_t nul = 0;
+            hash_feed(&com, r.comment.ptr, r.comment.len);
+            hash_feed(&com, &nul, 1);
+        }
+    }
+    out->seq_hash = hash_finish(&seq);
+    out->qual_hash = hash_finish(&qual);
+    out->ends_hash = hash_finish(&ends);
+    out->ids_hash = hash_finish(&ids);
+    out->com_hash = hash_finish(&com);
+    return NO_OK;
 }

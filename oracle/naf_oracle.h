@@ -95,6 +95,15 @@ int no_section(const no_decoder *d, int which, const uint8_t **p, uint64_t *n, u
 /* the first `cap` mask units (reader.rs:198-231); returns count, sets masked[i] */
 size_t no_mask_units(const no_decoder *d, uint64_t *len, uint8_t *masked, size_t cap);
 
+/* Drains the iterator.  want_hash: also accumulate, per field, the position-keyed 64-bit checksum of
+ * the concatenated bytes (sequence after masking; quality; ids / comments each followed by NUL; the u64
+ * table of inclusive record ends) -- the checker's value for full-size GPU parity tests. */
+typedef struct {
+    uint64_t n_records, n_bases, n_quality;
+    uint64_t seq_hash, qual_hash, ends_hash, ids_hash, com_hash;
+} no_drain_result;
+int no_drain(no_decoder *d, int want_hash, no_drain_result *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,11 @@ class NoRecord(ctypes.Structure):
                 ("length", c_uint64), ("has_length", c_uint8)]
 
 
+class DrainResult(ctypes.Structure):
+    _fields_ = [(n, c_uint64) for n in ("n_records", "n_bases", "n_quality", "seq_hash", "qual_hash", "ends_hash",
+                                        "ids_hash", "com_hash")]
+
+
 _lib = None
 
 
@@ -69,6 +74,7 @@ def lib():
                                  POINTER(c_uint64), POINTER(c_uint64)]
         L.no_mask_units.restype = c_size_t
         L.no_mask_units.argtypes = [c_void_p, POINTER(c_uint64), POINTER(c_uint8), c_size_t]
+        L.no_drain.argtypes = [c_void_p, c_int, POINTER(DrainResult)]
         _lib = L
     return _lib
 
@@ -201,6 +207,15 @@ class Decoder:
             raise OracleError(rc)
         data = ctypes.string_at(p, n.value) if p.value and n.value else b""
         return data, o.value, c.value, off.value
+
+    def drain(self, want_hash=True):
+        """Drains the iterator in C (no Python objects per record) -> DrainResult with counts and, if asked,
+        the position-keyed checksums of the concatenated fields (the checker for full-size GPU parity)."""
+        out = DrainResult()
+        rc = lib().no_drain(self._h, int(want_hash), byref(out))
+        if rc != 0:
+            raise OracleError(rc)
+        return out
 
     def mask_units(self, cap=1 << 16):
         ln = (c_uint64 * cap)()

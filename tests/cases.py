@@ -66,6 +66,13 @@ def build_cases(scale=1):
     add("more_records_than_lengths", nw.write_naf(make_records(rng, [4, 5]), number_of_sequences=4))
     add("fewer_records_than_lengths", nw.write_naf(make_records(rng, [4, 5, 6]), number_of_sequences=2))
     add("checksum_frames", nw.write_naf(make_records(rng, [50000, 3]), level=3, zstd_kwargs={"checksum": True}))
+    # number_of_sequences is an untrusted varint: it must not size anything (ids/comment tables, scan scratch);
+    # the iterator keeps yielding (empty) records until it is reached, so only the first few are compared
+    huge = make_records(rng, [40, 50, 60])
+    add("huge_nseq_2p40", nw.write_naf(huge, number_of_sequences=1 << 40), _limit=6)
+    add("huge_nseq_u64max", nw.write_naf(huge, number_of_sequences=(1 << 64) - 1), _limit=6)
+    add("huge_nseq_no_names", nw.write_naf(huge, number_of_sequences=(1 << 64) - 1, ids=False, comments=False), _limit=6)
+    add("title_bad_utf8", nw.write_naf(huge, title=b"caf\xe9 \xff"))              # from_utf8 fails: Nom(MapRes), parser.rs:133-137
 
     # ---- mask ------------------------------------------------------------------------------
     recs = make_records(rng, [1550, 1800, 0, 700, 255, 510, 1000])
@@ -132,10 +139,14 @@ def run_oracle(blob, opts):
     from oracle import oracle
     kinds = {oracle.E_IO_EOF: "io:eof", oracle.E_IO_INVALID: "io:invalid", oracle.E_NOM: "nom", oracle.E_PANIC: "panic"}
     recs = []
+    opts = dict(opts)
+    limit = opts.pop("_limit", None)
     try:
         d = oracle.Decoder(blob, **opts)
         for r in d:
             recs.append(tuple(getattr(r, f) for f in FIELDS))
+            if limit is not None and len(recs) >= limit:
+                break
     except oracle.OracleError as e:
         return recs, kinds.get(e.kind, "other")
     except UnicodeDecodeError:
@@ -149,12 +160,15 @@ def run_product(blob, opts, lib=None):
     from nafcodec_amd.decoder import Decoder
     recs = []
     kw = dict(opts)
+    limit = kw.pop("_limit", None)
     if lib is not None:
         kw["_lib"] = lib
     try:
         d = Decoder(io.BytesIO(blob), **kw)
         for r in d:
             recs.append(tuple(getattr(r, f) for f in FIELDS))
+            if limit is not None and len(recs) >= limit:
+                break
     except EOFError:
         return recs, "io:eof"
     except ValueError:

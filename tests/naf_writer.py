@@ -116,7 +116,7 @@ def write_naf(records, *, sequence_type="dna", version=None, level=1, separator=
     out += varint(line_length)
     out += varint(len(records) if number_of_sequences is None else number_of_sequences)
     if title is not None:
-        t = title.encode()
+        t = title if isinstance(title, bytes) else title.encode()
         out += varint(len(t)) + t
     for orig, payload in sections:
         out += varint(orig) + varint(len(payload)) + payload

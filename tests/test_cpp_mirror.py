@@ -35,6 +35,32 @@ int main(int argc, char **argv) {
         std::ifstream f(argv[2], std::ios::binary);
         const std::string want((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
         std::printf("text %s\n", text == want ? "equal" : "DIFFERENT");
+        // with_reader (mod.rs:169-256): R: Read + Seek as two callbacks over a FILE*, sequence switched off
+        {
+            std::FILE *fp = std::fopen(argv[1], "rb");
+            struct Ctx { std::FILE *fp; unsigned long long read = 0; int seeks = 0; } ctx{fp};
+            auto rd = [](void *c, uint8_t *buf, uint64_t cap) -> int64_t {
+                Ctx *x = static_cast<Ctx *>(c);
+                const size_t got = std::fread(buf, 1, cap, x->fp);
+                x->read += got;
+                return std::ferror(x->fp) ? -5 : static_cast<int64_t>(got);
+            };
+            auto sk = [](void *c, int64_t off, int whence) -> int64_t {
+                Ctx *x = static_cast<Ctx *>(c);
+                x->seeks++;
+                if (std::fseek(x->fp, static_cast<long>(off), whence) != 0) return -29;
+                return std::ftell(x->fp);
+            };
+            Decoder r = DecoderBuilder().sequence(false).with_reader(rd, sk, &ctx);
+            size_t k = 0, with_seq = 0, lens = 0;
+            while (auto rec = r.next()) {
+                k++;
+                with_seq += rec->sequence.has_value();
+                lens += *rec->length;
+            }
+            std::printf("reader %zu records, %zu with sequence, lengths %zu, seeks>0 %d\n", k, with_seq, lens, ctx.seeks > 0);
+            std::fclose(fp);
+        }
         try {
             DecoderBuilder().with_path("/nonexistent.naf");
             std::printf("no error?\n");
@@ -64,7 +90,8 @@ def build_and_run(tmp_path, libdir, libname, extra_env=None):
     assert lines[0] == "records 42 line 301 type 0 remaining 42"
     assert lines[1] == "iterated 42 bases 12436 first SRR1377138.1"
     assert lines[2] == "text equal"
-    assert lines[3] == "open error io=1"
+    assert lines[3] == "reader 42 records, 0 with sequence, lengths 12436, seeks>0 1"
+    assert lines[4] == "open error io=1"
 
 
 def test_cpp_mirror_on_the_cpu_harness(tmp_path):

@@ -68,6 +68,18 @@ def test_pointer_jumping_stage_is_exercised(emu, all_cases, monkeypatch):
                 assert cases.run_product(blob, opts, emu) == cases.run_oracle(blob, opts), (name, few)
 
 
+def test_pointer_jumping_distance_limit_falls_back_to_frame_order(emu, all_cases, monkeypatch):
+    """D holds 32-bit distances: a chain longer than that cannot be jumped to its end.  With the limit lowered
+    to a few elements (NAFGPU_PJ_MAX_DIST) the jump steps stall with elements still pointing at pending bytes;
+    the copy step must then NOT run -- the section is finished in frame order -- and the bytes stay exact."""
+    monkeypatch.setenv("NAFGPU_LZ_FEW_PENDING", "0")
+    for limit in ("3", "64"):
+        monkeypatch.setenv("NAFGPU_PJ_MAX_DIST", limit)
+        for name, blob, opts in all_cases:
+            if name in ("text_dense_chains", "dna_dense_chains", "dna_homopolymer"):
+                assert cases.run_product(blob, opts, emu) == cases.run_oracle(blob, opts), (name, limit)
+
+
 def test_block_range_sharding(emu):
     cases.check_sharding(emu, 3_000_001, True)
     cases.check_sharding(emu, 1_500_000, False, worlds=(2, 8))

@@ -146,6 +146,45 @@ def test_synthetic_archive(lib, n_bases, mask, iupac):
         lib.c.nafgpu_synth_free(ctypes.byref(arc))
 
 
+def test_gigabase_archive_against_the_oracle(lib):
+    """Full-size parity pinned on the ORACLE, not on the writer: a 1.2 Gbase synthetic archive (with a Mask
+    section) is drained by the CPU oracle in C, which accumulates the position-keyed checksum of the
+    concatenated masked bases and of the u64 record-end table; the GPU decode must reproduce both."""
+    import nafcodec_amd
+    arc = lib.synth(1_200_000_003, seed=77, with_mask=True, iupac_permille=3)
+    try:
+        blob = ctypes.string_at(arc.bytes, arc.n)
+        want = oracle.Decoder(blob).drain()
+        dec = nafcodec_amd.Decoder(io.BytesIO(blob))
+        res = dec.decode_all_device()
+        assert (res.n_bases, res.n_records) == (want.n_bases, want.n_records) == (arc.n_bases, arc.n_records)
+        assert dec.hash_device(res.d_sequence, res.n_bases) == want.seq_hash == arc.seq_hash
+        assert dec.hash_device(res.d_record_end, 8 * res.n_records) == want.ends_hash == arc.offsets_hash
+    finally:
+        lib.c.nafgpu_synth_free(ctypes.byref(arc))
+
+
+def test_hash_sees_compensating_and_swapped_bytes(lib):
+    """The checksum mixes every 8-byte word with its position before adding: errors that a linear sum
+    would let cancel (+1 here, -1 there; two words swapped) change it."""
+    import nafcodec_amd
+    rng = np.random.default_rng(3)
+    a = bytearray(rng.integers(0, 256, 70001, dtype=np.uint8).tobytes())
+    h0 = lib.c.nafgpu_hash64_host(bytes(a), len(a))
+    b = bytearray(a); b[100] = (b[100] + 1) & 255; b[101] = (b[101] - 1) & 255
+    c = bytearray(a); c[8:16], c[4096:4104] = a[4096:4104], a[8:16]
+    d = bytearray(a); d[-1] ^= 1
+    assert len({h0, lib.c.nafgpu_hash64_host(bytes(b), len(b)), lib.c.nafgpu_hash64_host(bytes(c), len(c)),
+                lib.c.nafgpu_hash64_host(bytes(d), len(d))}) == 4
+    # device == host, at every alignment and tail length
+    blob = golden_bytes("phix.naf")
+    dec = nafcodec_amd.Decoder(io.BytesIO(blob))
+    res = dec.decode_all_device()
+    seq = dec.copy_to_host(res.d_sequence, res.n_bases)
+    for off, n in ((0, len(seq)), (1, 1000), (3, 8191), (8, 4096), (5, 7), (0, 0)):
+        assert dec.hash_device(res.d_sequence + off, n) == lib.c.nafgpu_hash64_host(seq[off:off + n], n), (off, n)
+
+
 def test_shared_cases_match_oracle(lib):
     """tests/cases.py at 4x the CPU-harness sizes: levels 1/3/19, RNA, protein, FASTQ, per-record
     flush, every mask shape incl. the record-end rule, field selection, malformed archives."""

@@ -13,12 +13,15 @@ import torch, torch.distributed as dist
 from nafcodec_amd.sharding import gather_placement
 dist.init_process_group("gloo")
 r, w = dist.get_rank(), dist.get_world_size()
-table = [(1000003, 500002, 17, 1), (2000000, 1000000, 5, 0), (7, 4, 1, 1)][:w]
+# per rank: bases, packed bytes, first record that starts in the shard, carry (shard begins inside a record)
+table = [(1000003, 500002, 0, 0), (2000000, 1000000, 17, 1), (7, 4, 22, 0)][:w]
+total_records = 23
 for _ in range(3):
-    p = gather_placement(dist, torch, *table[r], device="cpu")
+    p = gather_placement(dist, torch, *table[r], total_records, device="cpu")
 assert p.base_offset == sum(t[0] for t in table[:r]) and p.packed_offset == sum(t[1] for t in table[:r])
-assert p.record_offset == sum(t[2] for t in table[:r])
-assert (p.total_bases, p.total_packed, p.total_records) == tuple(sum(t[k] for t in table) for k in range(3))
+assert p.first_record == table[r][2] and p.first_records == [t[2] for t in table]
+assert p.n_owned_records == ((table[r + 1][2] if r + 1 < w else total_records) - table[r][2])
+assert (p.total_bases, p.total_packed, p.total_records) == (sum(t[0] for t in table), sum(t[1] for t in table), total_records)
 assert p.carries == [t[3] for t in table] and (p.rank, p.world) == (r, w)
 dist.barrier()
 dist.destroy_process_group()

@@ -147,30 +147,15 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
         return Failure::io(NAFGPU_IO_INVALID_DATA, "zstd: decoded size differs from the size recorded in the archive");
     out0_ = plan_.sharded ? plan_.shard_out0 : 0;
     out1_ = plan_.sharded ? plan_.shard_out1 : expect_size;
-    // four launch classes: {section output, literal buffer} x {8-byte tables, compact tables}; tasks are stored in that order
-    n_direct_tasks_ = plan_.n_direct_tasks;
-    class_first_[0] = 0;
-    class_count_[0] = plan_.n_direct_tasks - plan_.n_direct_compact;
-    class_first_[1] = class_count_[0];
-    class_count_[1] = plan_.n_direct_compact;
-    class_first_[2] = plan_.n_direct_tasks;
-    class_count_[2] = static_cast<uint32_t>(plan_.tasks.size()) - plan_.n_direct_tasks - plan_.n_lit_compact;
-    class_first_[3] = class_first_[2] + class_count_[2];
-    class_count_[3] = plan_.n_lit_compact;
-    for (int c = 0; c < 4; c++) {
-        class_max_tbl_[c] = 0;
-        for (uint32_t i = class_first_[c]; i < class_first_[c] + class_count_[c]; i++) {
-            const HufTask &t = plan_.tasks[i];
-            for (uint32_t k = 0; k < t.n_copies; k++) {
-                const HufTblCopy &cp = plan_.tbl_copies[t.first_copy + k];
-                class_max_tbl_[c] = std::max(class_max_tbl_[c], cp.lds_off + cp.n_entries);
-            }
-        }
+    classes_ = plan_.classes;                              // launch classes of the Huffman tasks (plan.h: HufClass)
+    if (std::getenv("NAFGPU_DEBUG_PLAN")) {
+        std::fprintf(stderr, "[nafgpu] section plan: %zu blocks, %zu streams, %zu seq blocks, %llu sequences, literal buffer %llu B; task classes:",
+                     n_blocks_, n_streams_, n_seq_blocks_, static_cast<unsigned long long>(plan_.n_sequences),
+                     static_cast<unsigned long long>(plan_.lit_bytes));
+        for (const HufClass &c : classes_)
+            std::fprintf(stderr, " {%u tasks, tbl %u, %s%s, lds %u B}", c.n_tasks, c.tbl, c.to_lit ? "lit" : "out", c.seg ? "+seg" : "", c.lds_bytes);
+        std::fprintf(stderr, "\n");
     }
-    if (std::getenv("NAFGPU_DEBUG_PLAN"))
-        std::fprintf(stderr, "[nafgpu] section plan: %zu blocks, %zu streams, tasks {direct8 %u (tbl %u), direct4 %u (tbl %u), lit8 %u (tbl %u), lit4 %u (tbl %u)}, %zu seq blocks\n",
-                     n_blocks_, n_streams_, class_count_[0], class_max_tbl_[0], class_count_[1], class_max_tbl_[1], class_count_[2],
-                     class_max_tbl_[2], class_count_[3], class_max_tbl_[3], n_seq_blocks_);
     bool ok = d_out_.alloc(static_cast<size_t>(out_bytes()) + 64) && d_status_.alloc(64) &&
               d_blk_size_.upload(plan_.blk_size.data(), n_blocks_ * sizeof(uint32_t), stream) &&
               d_blk_base_.alloc((n_blocks_ + 1) * sizeof(uint64_t)) && d_scan_tmp_.alloc(scan_tmp_bytes(n_blocks_)) &&
@@ -178,6 +163,7 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
               d_tasks_.upload(plan_.tasks.data(), n_tasks_ * sizeof(HufTask), stream) &&
               d_tbl_copies_.upload(plan_.tbl_copies.data(), plan_.tbl_copies.size() * sizeof(HufTblCopy), stream) &&
               d_pool_.upload(plan_.huf_pool.data(), plan_.huf_pool.size() * sizeof(uint16_t), stream) &&
+              d_dicts_.upload(plan_.dict_pool.data(), plan_.dict_pool.size(), stream) &&
               d_copies_.upload(plan_.copies.data(), n_copies_ * sizeof(CopyTask), stream) &&
               d_seq_blocks_.upload(plan_.seq_blocks.data(), n_seq_blocks_ * sizeof(SeqBlock), stream) &&
               d_cells_.upload(plan_.fse_pool.data(), plan_.fse_pool.size() * sizeof(SeqCell), stream) &&
@@ -227,17 +213,17 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
     launch_copy_fill(stream, d_src_, d_copies_.as<CopyTask>(), static_cast<uint32_t>(n_copies_),
                      d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(), ascii, t_char_, status);
     if (timer) timer->end(stream);
-    // K1.  Classes 0/1: streams of literal-only blocks, straight to the output; 2/3: to the literal buffer.
-    // When both kinds exist (archives whose blocks carry a few LZ sequences) the literal-buffer tasks run
-    // on `aux` beside the direct ones, so the two launches share the chip instead of each ending in a
-    // half-empty tail; K4 then waits for both.  One timed span covers the phase.
-    auto launch_class = [&](int c, hipStream_t st) {
-        if (!class_count_[c]) return;
-        launch_huf_decode(st, d_src_, d_tasks_.as<HufTask>() + class_first_[c], class_count_[c], d_tbl_copies_.as<HufTblCopy>(),
-                          d_streams_.as<HufStream>(), d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(),
-                          class_max_tbl_[c], (c & 1) != 0, c < 2 && ascii, t_char_, status);
+    // K1, one launch per class.  Streams that write the section output (blocks without sequences, and -- segment by
+    // segment -- blocks with a few) and streams that feed the literal buffer (blocks with many sequences).  When
+    // both kinds exist the literal-buffer classes run on `aux` beside the others, so the launches share the chip
+    // instead of each ending in a half-empty tail; K4 then waits for both.  One timed span covers the phase.
+    auto launch_class = [&](const HufClass &c, hipStream_t st) {
+        launch_huf_decode(st, d_src_, d_tasks_.as<HufTask>(), c, d_tbl_copies_.as<HufTblCopy>(), d_streams_.as<HufStream>(),
+                          d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(), d_seq_blocks_.as<SeqBlock>(),
+                          d_seqs_.as<Seq>(), d_dicts_.bytes(), ascii, t_char_, status);
     };
-    const bool have_direct = class_count_[0] + class_count_[1] > 0, have_lit = class_count_[2] + class_count_[3] > 0;
+    bool have_direct = false, have_lit = false;
+    for (const HufClass &c : classes_) (c.to_lit ? have_lit : have_direct) = true;
     if (have_direct || have_lit) {
         if (timer) timer->begin(stream, StageTimer::kHuf);
         bool forked = false;
@@ -247,14 +233,14 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
             forked = ev_fork_ && ev_join_ && hip_ok(hipEventRecord(ev_fork_, stream)) && hip_ok(hipStreamWaitEvent(aux, ev_fork_, 0));
         }
         if (forked) {
-            launch_class(2, aux);
-            launch_class(3, aux);
+            for (const HufClass &c : classes_)
+                if (c.to_lit) launch_class(c, aux);
             (void)hipEventRecord(ev_join_, aux);
-            launch_class(0, stream);
-            launch_class(1, stream);
+            for (const HufClass &c : classes_)
+                if (!c.to_lit) launch_class(c, stream);
             (void)hipStreamWaitEvent(stream, ev_join_, 0);
         } else {
-            for (int c = 0; c < 4; c++) launch_class(c, stream);
+            for (const HufClass &c : classes_) launch_class(c, stream);
         }
         if (timer) timer->end(stream);
     }

@@ -118,8 +118,8 @@ private:
     uint64_t lz_residue_ = 0;
     uint64_t out0_ = 0, out1_ = 0;
     uint64_t expect_ = 0, n_blocks_ = 0, n_streams_ = 0, n_tasks_ = 0, n_copies_ = 0, n_seq_blocks_ = 0;
-    uint32_t class_first_[4] = {0, 0, 0, 0}, class_count_[4] = {0, 0, 0, 0}, class_max_tbl_[4] = {0, 0, 0, 0};
-    uint32_t n_direct_tasks_ = 0, t_char_ = 0;
+    std::vector<HufClass> classes_;
+    uint32_t t_char_ = 0;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;   // K1 on two streams (created on first use, destroyed with the job)
     const uint8_t *d_src_ = nullptr;
     float plan_ms_ = 0;
@@ -128,7 +128,7 @@ private:
     DevBuf d_meta_, d_rep_final_, d_rep_init_, d_rep_scratch_, d_lz_index_, d_blk_pending_, d_roff_, d_counters_;
     DevBuf d_lz_list_[2];
     DevBuf d_pj_list_, d_pj_dist_, d_pj_stamp_;   // pointer-jumping scratch, allocated only when the passes leave a residue
-    DevBuf d_streams_, d_tasks_, d_tbl_copies_, d_pool_, d_copies_, d_seq_blocks_, d_cells_;
+    DevBuf d_streams_, d_tasks_, d_tbl_copies_, d_pool_, d_dicts_, d_copies_, d_seq_blocks_, d_cells_;
 };
 
 struct ArchiveOptions {

@@ -66,13 +66,14 @@ void launch_copy_fill(hipStream_t stream, const uint8_t *src, const CopyTask *ta
                       const uint64_t *blk_base, uint8_t *out, uint8_t *lit, bool ascii, uint32_t t_char,
                       uint32_t *status);
 
-// K1: Huffman literal streams, one lane per stream, one wave per task.
-// max_tbl_entries = largest staged-table footprint over the tasks (sizes the dynamic LDS);
-// compact = the tasks use 4-byte table entries (plan.h: HufTask).
-void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *tasks, uint32_t n_tasks,
+// K1: Huffman literal streams, one lane per stream, one wave per task.  One launch per class (plan.h:
+// HufClass): `tasks` is the section's whole task list, cls names the run to launch, its table format,
+// destination and whether the segment-aware variant is needed (streams of blocks with a few sequences:
+// seq_blocks / seqs are then read, so k_seq_decode must have run).
+void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *tasks, const HufClass &cls,
                        const HufTblCopy *copies, const HufStream *streams, const uint16_t *pool,
-                       const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t max_tbl_entries, bool compact, bool ascii,
-                       uint32_t t_char, uint32_t *status);
+                       const uint64_t *blk_base, uint8_t *out, uint8_t *lit, const SeqBlock *seq_blocks, const Seq *seqs,
+                       const uint8_t *dicts, bool ascii, uint32_t t_char, uint32_t *status);
 
 // K4: LZ77 sequence execution: repeat-offset chain, parallel literal scatter, multi-pass match
 // resolution over all blocks, ordered fallback

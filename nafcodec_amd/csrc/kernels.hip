@@ -23,7 +23,16 @@ namespace nafgpu {
 
 namespace {
 
+// Timing ablations (tools/ablate.sh builds experiment libraries with -DNAFGPU_ABLATE=<mask>; results are then
+// wrong by construction and no error is flagged).  The product is built without it: every `kAblate` test folds to nothing.
+#ifndef NAFGPU_ABLATE
+#define NAFGPU_ABLATE 0
+#endif
+constexpr uint32_t kAblate = NAFGPU_ABLATE;   // k_huf_decode: 1 no output stores, 2 no look-ups (rows fill instantly), 4 no input loads,
+                                              // 8 no table staging, 16 stores only to a small window, 32 no dictionary reads
+
 __device__ inline void flag_error(uint32_t *status, uint32_t code, uint32_t detail) {
+    if (kAblate) return;
     if (atomicCAS(&status[0], 0u, code) == 0u) status[1] = detail;
 }
 
@@ -33,12 +42,18 @@ __device__ inline void flag_error(uint32_t *status, uint32_t code, uint32_t deta
 // One wave per task, one lane per stream.  What bounds it on MI355X, in this order:
 // the HBM request pattern (610 k scattered input and output fronts), LDS capacity (which caps the
 // waves per CU) and the dependent chain of one look-up.  Hence:
-//   * two-symbol table with the OUTPUT baked in: while a task's Huffman tables are staged into
-//     LDS they are widened to W = max(max_bits, 8) index bits; a 64-bit entry holds the bytes to
-//     emit for the next one or two symbols (for DNA/RNA: the 2 x 2 IUPAC characters of the two
-//     packed bytes -- SequenceReader::read_nucleotide/decode, reader.rs:121-172, costs nothing per
-//     symbol and the 4-bit intermediate never reaches HBM), the bits consumed and the bytes produced.
-//     DNA codes are ~4 bits, so almost every look-up yields four bases.
+//   * two-symbol table: while a task's Huffman tables are staged into LDS they are widened to
+//     W = max(max_bits, 8) index bits and every entry describes the next one or two symbols.  Three
+//     entry formats (plan.h: HufTblKind), one kernel instantiation each:
+//       baked    8 bytes, the bytes to emit inside the entry (for DNA/RNA: the 2 x 2 IUPAC characters of
+//                the two packed bytes -- SequenceReader::read_nucleotide/decode, reader.rs:121-172, costs
+//                nothing per symbol and the 4-bit intermediate never reaches HBM).  Tasks with ONE tree.
+//       compact  4 bytes {sym1, sym2, bits, bits of sym1, two}; characters from a 512-byte table shared by the
+//                wave.  Tasks with several trees, one of them with more than 64 symbols.
+//       dict     2 bytes {index of sym1, index of sym2, bits - 1, two} into a per-tree dictionary of <= 64
+//                symbols holding their output bytes.  Tasks with several small-alphabet trees: what real
+//                genomes give (one tree per 128 KiB block, A C G T plus a few IUPAC codes).  Half the LDS
+//                of the compact format per tree: the lanes resident per CU set the throughput there.
 //   * bit window: {hi, lo, nw} are three consecutive 32-bit words of the backward stream,
 //     s = 32 - (bits of hi consumed) in [0, 31]; peek = v_alignbit_b32(hi, lo, s); consuming len
 //     bits is s -= len, a borrow meaning "advance one word", s &= 31.
@@ -47,18 +62,37 @@ __device__ inline void flag_error(uint32_t *status, uint32_t code, uint32_t deta
 //     positions is bank-conflict free), one 32-byte piece per round at most.  Invariant (a look-up
 //     consumes <= 11 bits, so a round <= 6 words, + 2 words of look-ahead): >= 9 staged words past
 //     the cursor after each service.  Each line of compressed input is requested exactly once.
-//   * output: each lane appends to its own 192-byte row in LDS whose byte 0 is 128-byte aligned
-//     in the destination (one unaligned ds_write_b32 per look-up, no wrap arithmetic).  Once per
-//     round the rows holding a complete 128-byte unit are listed (ballot + rank) and written out
-//     eight rows per buffer_store_dwordx4, eight lanes per row: every store instruction writes
-//     eight whole lines.  The row's owner moves its leftover (< 64 B) down.
+//   * output: each lane appends to its own row in LDS whose byte 0 is unit-aligned in the destination
+//     (one unaligned ds_write_b32 per look-up, no wrap arithmetic).  Once per round the rows holding a
+//     complete unit are listed (ballot + rank) and written out 16 bytes per lane, a unit per lane
+//     group: every store instruction writes whole 128-byte lines (baked tables: 128-byte units, eight
+//     rows per instruction) or whole 64-byte half lines (compact / dict tables, sixteen rows per
+//     instruction: 64 bytes less LDS per lane, where lanes per CU matter more than the store pattern).
+//     The row's owner moves its leftover (< 64 B) down.
 //   * a round is [flush what earlier rounds completed] -> [16 look-ups] -> [land the next piece].
+//   * SEG: streams of a block that has a few LZ sequences (plan.h: kDirectSeqMax) write their literals
+//     straight to their final positions: the stream's symbols are cut into segments by the block's
+//     decoded sequences (k_seq_decode ran before); at the end of a segment the lane drains its row
+//     byte-wise, like at the end of a stream, and re-bases it at the next literal run.  The literal
+//     buffer round trip (K1 -> lit -> k_lz_literals -> out) disappears for those blocks.
 // DESIGN.md section 4 has the measurements behind each of these choices.
 constexpr uint32_t kRingWords = 16;
-constexpr uint32_t kUnit = 128;          // output bytes flushed per row at a time: one whole 128-byte line
-constexpr uint32_t kOutPitch = 200;      // row pitch in bytes: kUnit + 64 used, 8-byte aligned rows, 50-dword stride (conflict-free b16 writes)
+template <int TBL>
+struct HufGeom {
+    static constexpr bool kBig = TBL == kTblBaked;       // (128-byte units for the other formats: measured, no faster; 4 KB more LDS per wave)
+    static constexpr uint32_t kUnit = kBig ? 128u : 64u;               // output bytes flushed per row at a time
+    static constexpr uint32_t kUnitShift = kBig ? 7u : 6u;
+    static constexpr uint32_t kPitch = kUnit + 64u + 8u;               // row pitch: unit + one round's worth + slack, 8-byte aligned, 2 (mod 32)-dword stride
+    static constexpr uint32_t kLanesPerRow = kUnit / 16u;              // lanes that store one row's unit
+    static constexpr uint32_t kRowsPerStore = 64u / kLanesPerRow;      // rows served by one store instruction
+    static constexpr uint32_t kStoreIters = 64u / kRowsPerStore;       // store instructions per flush at most
+};
 #ifndef NAFGPU_EMU
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// a volatile access that stays an LDS instruction (a volatile access through a generic pointer becomes flat_store)
+#define NAFGPU_LDS_VOLATILE(T, p) ((__attribute__((address_space(3))) volatile T *)(p))
+#else
+#define NAFGPU_LDS_VOLATILE(T, p) (reinterpret_cast<volatile T *>(p))
 #endif
 constexpr uint32_t kBufRange = 0x80000000u;   // bytes a wave's buffer descriptors cover
 constexpr uint32_t kBufOff = 0xFFFFFF00u;     // an offset outside that range: switches the lane off
@@ -73,13 +107,21 @@ __device__ inline void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// table entry (uint2):
+// baked table entry (uint2):
 //   .x  bytes to emit: first symbol in the low half, second symbol in the high half
 //       (ASCII: two characters per symbol; plain: one byte per symbol, in bits 0-7 and 16-23)
 //   .y  bits  0-7  bits consumed when everything the entry offers is taken
 //       bits  8-15 output bytes produced then
 //       bits 16-23 bits consumed by the first symbol alone (stream tail)
 //       bit  24    entry holds two symbols
+//       bit  25    escape: .x = first entry of the sub-table
+// compact entry (uint32): sym1 | sym2 << 8 | bits << 16 | bits of sym1 << 20 | two << 24 | escape << 25 (then bits 0-15: sub-table)
+// dict entry (uint16):    symbols (0, 1, 2) | index of sym1 << 2 | index of sym2 << 8 | bits << 12 (indices into the task's dictionary;
+//                         a second symbol is only taken when its index is < 16 -- the dictionary lists short codes first; the
+//                         fields sit where one AND / shift turns them into LDS byte offsets);
+//                         0 symbols / 0 bits marks an escape (sub-table number in bits 2-11): the cursor does not move on it, the
+//                         lane idles for the rest of its group of four look-ups and resolves it at the start of the next;
+//                         sub-table entries hold bits - W
 
 // "-TGKCYSBAWRDMHVN"[nib], with index 1 = t_char ('T' for DNA, 'U' for RNA)  (reader.rs:152-172)
 __device__ inline uint32_t nib_char(uint32_t nib, uint32_t t_char) {
@@ -109,40 +151,72 @@ __device__ inline void huf_advance(HufLane &L, const uint8_t *ring_bytes, uint32
     L.nw = *reinterpret_cast<const uint32_t *>(ring_bytes + L.ra);
 }
 
-template <bool ASCII, bool T4>
+struct HufLook {           // what one table look-up says about the next one or two symbols
+    uint32_t x;            // bytes to emit: first symbol in the low half, second in the high half
+    uint32_t bits;         // bits consumed when both are taken
+    uint32_t two;          // 1: the entry holds two symbols
+    uint32_t first;        // format-specific handle for "bits of the first symbol alone" (stream tail only)
+};
+
+template <bool ASCII, int TBL, bool SEG>
 __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ src, const HufTask *__restrict__ tasks,
                                                    const HufTblCopy *__restrict__ copies,
                                                    const HufStream *__restrict__ streams,
                                                    const uint16_t *__restrict__ pool,
                                                    const uint64_t *__restrict__ blk_base, uint8_t *out, uint8_t *lit,
-                                                   uint32_t t_char, uint32_t dbg, uint32_t *status) {
+                                                   const SeqBlock *__restrict__ sblocks, const Seq *__restrict__ seqs,
+                                                   const uint8_t *__restrict__ dicts, uint32_t t_char, uint32_t *status) {
+    using G = HufGeom<TBL>;
+    constexpr uint32_t kUnit = G::kUnit, kPitch = G::kPitch, kLanesPerRow = G::kLanesPerRow;
+    constexpr uint32_t kRowsPerStore = G::kRowsPerStore, kStoreIters = G::kStoreIters, kUnitShift = G::kUnitShift;
     constexpr uint32_t kOutB = ASCII ? 2 : 1;              // output bytes per symbol
     HIP_DYNAMIC_SHARED(uint2, s_tbl)
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[kRingWords * 64 * 4];
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[64 * kOutPitch];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[64 * kPitch];
     __shared__ __attribute__((aligned(16))) uint32_t s_cunit[64];   // per round: descriptors of the ready rows, compacted (see publish)
-    __shared__ uint32_t s_h[64];       // first row coordinate that belongs to this stream
+    __shared__ uint32_t s_h[64];       // first row coordinate that belongs to this stream (segment)
     __shared__ uint32_t s_q[64];       // row coordinate of the next write
     __shared__ uint32_t s_fl[64];      // row coordinate of the row's byte 0 (multiple of kUnit)
 
-    // compact tables (T4): characters of a packed byte, shared by all the trees of the task
-    __shared__ uint16_t s_lut[(T4 && ASCII) ? 256 : 2];
+    // compact tables: characters of a packed byte, shared by all the trees of the task
+    __shared__ uint16_t s_lut[(TBL == kTblCompact && ASCII) ? 256 : 2];
+    // dict tables: output bytes of the task's dictionary symbols (ASCII: two characters each), shared by all its trees
+    __shared__ uint32_t s_dict[TBL == kTblDict ? kHufDictSyms : 2];
 
     if (status[0] != 0) return;
     const uint32_t lane = threadIdx.x;
     const HufTask task = tasks[blockIdx.x];
-    if (T4 && ASCII)
+    if (TBL == kTblCompact && ASCII)
         for (uint32_t i = lane; i < 256; i += 64) s_lut[i] = static_cast<uint16_t>(byte_chars(i, t_char));
 
-    // ---- stage the task's tables: 2^W two-symbol entries with the output bytes baked in; W-bit
-    // prefixes whose first code is longer than W bits point to a 2^(max_bits - W) entry sub-table
-    for (uint32_t k = 0; k < task.n_copies; k++) {
+    // ---- stage the task's tables: 2^W two-symbol entries; W-bit prefixes whose first code is longer than
+    // W bits point to a 2^(max_bits - W) entry sub-table
+    if (TBL == kTblDict) {                                 // the task's dictionary and its inverse (in the still unused rows)
+        uint8_t *sc = s_out;
+        for (uint32_t i = lane; i < 256; i += 64) sc[i] = 0xFF;
+        wave_sync();
+        const uint32_t sym = lane < task.n_dict ? dicts[task.dict_off + lane] : 0u;
+        if (lane < task.n_dict) sc[sym] = static_cast<uint8_t>(lane);
+        s_dict[lane] = ASCII ? byte_chars(sym, t_char) : sym;
+        wave_sync();
+    }
+    bool all_pairs = true;                                 // every main entry of every table of the task holds two symbols (uniform)
+    for (uint32_t k = 0; k < ((kAblate & 8u) ? 0u : task.n_copies); k++) {
         const HufTblCopy cp = copies[task.first_copy + k];
         const uint32_t mb = cp.bits & 0xFFu, W = cp.bits >> 8;
         const uint16_t *x1 = pool + cp.pool_off;           // 2^mb entries of len << 8 | sym
         uint2 *t = s_tbl + cp.lds_off;
-        uint32_t *t4 = reinterpret_cast<uint32_t *>(s_tbl) + cp.lds_off;   // compact format: sym1 | sym2 << 8 | bits << 16 | bits of sym1 << 20 | two << 24 | escape << 25
+        uint32_t *t4 = reinterpret_cast<uint32_t *>(s_tbl) + cp.lds_off;
+        uint8_t *lenlut = reinterpret_cast<uint8_t *>(reinterpret_cast<uint16_t *>(s_tbl) + cp.lds_off);   // dict format: this tree's code length of
+        uint16_t *t2 = reinterpret_cast<uint16_t *>(s_tbl) + cp.lds_off + kHufDictSlots;                    //   each dictionary symbol, then the table
+        const uint8_t *sc_idx = s_out;                     // symbol -> dictionary index (staged once per task, below)
         const uint32_t mbx = mb > W ? mb : W;              // bits that index x1 (zero-extended if mb < W)
+        if (TBL == kTblDict) {
+            for (uint32_t i = lane; i < (1u << mb); i += 64) {
+                const uint32_t e = x1[i], len = e >> 8;
+                if ((i & ((1u << (mb - len)) - 1u)) == 0) lenlut[sc_idx[e & 0xFFu] & 63u] = static_cast<uint8_t>(len);   // first entry of each code
+            }
+        }
         uint32_t n_esc = 0;
         for (uint32_t i = lane; i < (1u << W); i += 64) {
             const uint32_t v = i << (32u - W);             // the W index bits, left-aligned
@@ -152,78 +226,136 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
             const unsigned long long m = __ballot(esc ? 1 : 0);
             const uint32_t rank = n_esc + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
             n_esc += static_cast<uint32_t>(__popcll(m));
+            const uint32_t e2_ = esc ? 0u : x1[(v << l1) >> (32u - mb)];
+            all_pairs = all_pairs && !__any((!esc && l1 + (e2_ >> 8) <= W) ? 0 : 1);
             if (!esc) {
-                const uint32_t e2 = x1[(v << l1) >> (32u - mb)];
+                const uint32_t e2 = e2_;
                 const uint32_t l2 = e2 >> 8;
                 const uint32_t two = l1 + l2 <= W ? 1u : 0u;
-                const uint32_t o1 = ASCII ? byte_chars(e1 & 0xFFu, t_char) : (e1 & 0xFFu);
-                const uint32_t o2 = ASCII ? byte_chars(e2 & 0xFFu, t_char) : (e2 & 0xFFu);
-                if (T4)
+                if (TBL == kTblDict) {
+                    const uint32_t i1 = sc_idx[e1 & 0xFFu] & 63u, i2 = sc_idx[e2 & 0xFFu];
+                    const bool pair = two && i2 < 16u;     // (the second index has four bits: short codes come first in the dictionary)
+                    t2[i] = static_cast<uint16_t>((pair ? 2u : 1u) | (i1 << 2) | ((pair ? i2 : 0u) << 8) | ((pair ? l1 + l2 : l1) << 12));
+                } else if (TBL == kTblCompact) {
                     t4[i] = (e1 & 0xFFu) | ((e2 & 0xFFu) << 8) | ((two ? l1 + l2 : l1) << 16) | (l1 << 20) | (two << 24);
-                else
+                } else {
+                    const uint32_t o1 = ASCII ? byte_chars(e1 & 0xFFu, t_char) : (e1 & 0xFFu);
+                    const uint32_t o2 = ASCII ? byte_chars(e2 & 0xFFu, t_char) : (e2 & 0xFFu);
                     t[i] = make_uint2(o1 | (o2 << 16), (two ? l1 + l2 : l1) | (((1u + two) * kOutB) << 8) | (l1 << 16) | (two << 24));
+                }
             } else {
                 const uint32_t sub = (1u << W) + (rank << (mbx - W));
-                if (T4)
+                if (TBL == kTblDict)
+                    t2[i] = static_cast<uint16_t>(rank << 2);
+                else if (TBL == kTblCompact)
                     t4[i] = sub | (1u << 25);
                 else
                     t[i] = make_uint2(sub, 1u << 25);
                 for (uint32_t j = 0; j < (1u << (mbx - W)); j++) {
                     const uint32_t es = x1[(i << (mbx - W)) | j];
-                    const uint32_t o = ASCII ? byte_chars(es & 0xFFu, t_char) : (es & 0xFFu);
-                    if (T4)
+                    if (TBL == kTblDict) {
+                        t2[sub + j] = static_cast<uint16_t>(1u | ((sc_idx[es & 0xFFu] & 63u) << 2) | (((es >> 8) - W) << 12));
+                    } else if (TBL == kTblCompact) {
                         t4[sub + j] = (es & 0xFFu) | ((es >> 8) << 16) | ((es >> 8) << 20);
-                    else
+                    } else {
+                        const uint32_t o = ASCII ? byte_chars(es & 0xFFu, t_char) : (es & 0xFFu);
                         t[sub + j] = make_uint2(o, (es >> 8) | (kOutB << 8) | ((es >> 8) << 16));
+                    }
                 }
             }
         }
     }
 
-    if (dbg & 512u) return;                                // ablation: table staging only
     const bool have = lane < task.n_streams;
     HufStream st{};
     if (have) st = streams[task.first_stream + lane];
-    const uint32_t sh = 32u - st.max_bits;                 // max_bits holds W here
+    const uint32_t W = st.max_bits;                        // max_bits holds W here
+    const uint32_t sh = 32u - W;
     const uint32_t esc_bits = st.flags >> 4;               // tree max_bits - W
     const uint32_t sh2 = sh - esc_bits, esc_mask = (1u << esc_bits) - 1u;
     const uint2 *tbl = s_tbl + st.tbl_lds;
-    uint8_t *const orow = s_out + lane * kOutPitch;
+    const uint32_t *tbl4 = reinterpret_cast<const uint32_t *>(s_tbl) + st.tbl_lds;
+    const uint8_t *lenlut = reinterpret_cast<const uint8_t *>(reinterpret_cast<const uint16_t *>(s_tbl) + st.tbl_lds);
+    const uint16_t *tbl2 = reinterpret_cast<const uint16_t *>(s_tbl) + st.tbl_lds + kHufDictSlots;
+    uint8_t *const orow = s_out + lane * kPitch;
 
     HufLane L{0, 0, 0, 31, 0};
     // one table look-up on the next bits of the stream; rare long codes take a second, sub-table look-up
     // (tasks none of whose trees is deeper than W bits -- the common case -- run a copy of the loop without the test)
     const bool task_esc = __any(esc_bits != 0 ? 1 : 0) != 0;
-    const uint32_t *tbl4 = reinterpret_cast<const uint32_t *>(s_tbl) + st.tbl_lds;
-    auto lookup = [&](auto esc) -> uint2 {
+    auto lookup = [&](auto esc) -> HufLook {
         const uint32_t peek = __builtin_amdgcn_alignbit(L.hi, L.lo, L.s);
-        if (!T4) {
+        if (TBL == kTblBaked) {
             uint2 e = tbl[peek >> sh];
             if (decltype(esc)::value) {
                 if (e.y & (1u << 25)) e = tbl[e.x + ((peek >> sh2) & esc_mask)];
             }
-            return e;
+            return HufLook{e.x, e.y & 0xFFu, (e.y >> 24) & 1u, (e.y >> 16) & 0xFFu};
         }
-        // compact entry -> the same {output bytes, bits | bytes << 8 | bits of the first symbol << 16 | two << 24}
-        uint32_t c = tbl4[peek >> sh];
-        if (decltype(esc)::value) {
-            if (c & (1u << 25)) c = tbl4[(c & 0xFFFFu) + ((peek >> sh2) & esc_mask)];
+        if (TBL == kTblCompact) {
+            uint32_t c = tbl4[peek >> sh];
+            if (decltype(esc)::value) {
+                if (c & (1u << 25)) c = tbl4[(c & 0xFFFFu) + ((peek >> sh2) & esc_mask)];
+            }
+            const uint32_t s1 = c & 0xFFu, s2 = (c >> 8) & 0xFFu;
+            const uint32_t x = ASCII ? (static_cast<uint32_t>(s_lut[s1]) | (static_cast<uint32_t>(s_lut[s2]) << 16)) : (s1 | (s2 << 16));
+            return HufLook{x, (c >> 16) & 15u, (c >> 24) & 1u, (c >> 20) & 15u};
         }
-        const uint32_t s1 = c & 0xFFu, s2 = (c >> 8) & 0xFFu, two = (c >> 24) & 1u;
-        const uint32_t x = ASCII ? (static_cast<uint32_t>(s_lut[s1]) | (static_cast<uint32_t>(s_lut[s2]) << 16)) : (s1 | (s2 << 16));
-        return make_uint2(x, ((c >> 16) & 15u) | (((1u + two) * kOutB) << 8) | (((c >> 20) & 15u) << 16) | (two << 24));
+        return HufLook{0, 0, 0, 0};                        // (dict tables have their own loop: decode_round_dict)
     };
+    // dict tables: the raw entry under the cursor is lane state (fetched one look-up ahead, see decode_round_dict)
+    uint32_t r = 0;
+    auto dict_fetch = [&]() -> uint32_t { return tbl2[__builtin_amdgcn_alignbit(L.hi, L.lo, L.s) >> sh]; };
     uintptr_t ptop = 0;                  // address of the 32-byte piece holding the stream's last byte
     uint32_t wp = 0;                     // 32-byte pieces landed in the ring
     uint32_t c0 = 1, rp0 = 0, bits_total = 0;
     bool bad = false;
     uint8_t *wa = orow;                  // next write address inside the row
-    uint32_t rbase = 0, end_abs = 0, h = 0;   // row coordinate of orow[0]; end and start of the stream in row coordinates
+    uint32_t rbase = 0, end_abs = 0, h = 0;   // row coordinate of orow[0]; end and start of the stream (segment) in row coordinates
     // A wave addresses memory through two buffer descriptors (input, output) whose bases are the
     // lowest address any of its lanes touches; lanes use 32-bit offsets, and an offset outside the
     // descriptor's range switches a lane off (store is dropped, no memory traffic).
     uint64_t my_dst = ~0ull;             // destination offset of row coordinate 0 (kUnit aligned)
     uint64_t my_low = ~0ull;             // lowest input address this lane may load (128-byte aligned)
+    // SEG: the stream's symbols are literals [lit0, lit0 + n_syms) of its block; sequence i of the block takes
+    // literals [lpos_i, lpos_i + ll_i) to output elements opos_i .. and is followed by ml_i match elements
+    const bool to_lit_lane = (st.flags & 1u) != 0;
+    const uint32_t sb_idx = SEG ? static_cast<uint32_t>(st.dst >> 32) : 0u;       // 1 + SeqBlock index, 0: block without sequences
+    const Seq *sq = nullptr;
+    uint32_t sq_n = 0, sq_i = 0;         // the block's sequences; the one whose literal run holds the cursor (sq_n: the run after the last)
+    uint32_t syms_after = 0;             // symbols of the stream that come after the current segment
+    uint64_t blk_out = 0;                // first output element of the block
+    if (SEG && have && sb_idx) {
+        const SeqBlock sb = sblocks[sb_idx - 1];
+        sq = seqs + sb.seq_first;
+        sq_n = sb.n_seq;
+    }
+    // where literal number `lc` of the block goes: sets the segment [lc, seg_end) and its first output element
+    auto segment_at = [&](uint32_t lc, uint32_t lit_end, uint32_t *seg_len) -> uint64_t {
+        uint32_t run_end = 0xFFFFFFFFu, out_el = lc;
+        if (sq_n) {
+            Seq q{};
+            bool in_run = false;
+            while (sq_i < sq_n) {                          // (runs of length 0 are stepped over)
+                q = sq[sq_i];
+                if (q.lpos + q.ll > lc) {
+                    in_run = true;
+                    break;
+                }
+                sq_i++;
+            }
+            if (in_run) {
+                run_end = q.lpos + q.ll;
+                out_el = q.opos + (lc - q.lpos);
+            } else {                                       // literals after the last sequence
+                const Seq last = sq[sq_n - 1];
+                out_el = last.opos + last.ll + last.ml + (lc - (last.lpos + last.ll));
+            }
+        }
+        const uint32_t seg_end = run_end < lit_end ? run_end : lit_end;
+        *seg_len = seg_end - lc;
+        return blk_out + out_el;
+    };
     if (have) {
         const uint8_t *lastp = src + st.src_end - 1;
         const uint32_t lastb = *lastp;
@@ -235,14 +367,39 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         rp0 = 7u - static_cast<uint32_t>((a >> 2) & 7u);
         c0 = (3u - static_cast<uint32_t>(a & 3u)) * 8u + (8u - hb);   // bits of the top word already "consumed"
         L.s = 32u - c0;
-        const uint64_t dstart = ((st.flags & 1) ? st.dst : blk_base[st.blk] + st.dst) * ((st.flags & 1) ? 1 : kOutB);
+        uint64_t dstart;
+        uint32_t seg_len = st.n_syms;
+        if (to_lit_lane) {
+            dstart = st.dst;
+        } else {
+            blk_out = blk_base[st.blk];
+            const uint32_t lit0 = static_cast<uint32_t>(st.dst);
+            if (SEG && sq_n) {
+                // first sequence whose literal run ends after lit0 (the runs are in literal order)
+                uint32_t lo = 0, hi = sq_n;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const Seq q = sq[mid];
+                    if (q.lpos + q.ll > lit0)
+                        hi = mid;
+                    else
+                        lo = mid + 1;
+                }
+                sq_i = lo;
+                dstart = segment_at(lit0, lit0 + st.n_syms, &seg_len) * kOutB;
+            } else {
+                dstart = (blk_out + lit0) * kOutB;
+            }
+        }
+        syms_after = st.n_syms - seg_len;
         h = static_cast<uint32_t>(dstart & (kUnit - 1));
-        end_abs = h + st.n_syms * ((st.flags & 1) ? 1 : kOutB);
+        end_abs = h + seg_len * (to_lit_lane ? 1 : kOutB);
         wa = orow + h;
         my_dst = dstart - h;
         // look-ahead of the ring (<= 96 bytes past the stream start), the rest of that line and the line requested after it: inside kSrcFrontPad
         my_low = (reinterpret_cast<uintptr_t>(src) + st.src_end - st.src_len - 384u) & ~static_cast<uint64_t>(127);
     }
+    wave_sync();                                           // (dict staging scratch is dead)
     s_h[lane] = h;
     {   // wave minima of my_dst / my_low through the (still unused) output rows
         uint64_t *scratch = reinterpret_cast<uint64_t *>(s_out);
@@ -267,13 +424,14 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     dbase = uniform64(dbase);
     sbase = uniform64(sbase);
     // pack_tasks keeps a task's streams within 1 GiB of input and of output; a lane that is not is a host bug
+    // (SEG: later segments of a stream lie inside the same 128 KiB block as its first one)
     const bool in_range = !have || (my_dst - dbase < kBufRange - (1u << 20) &&
                                     ptop - sbase < kBufRange - (1u << 20));
     if (__any(in_range ? 0 : 1)) {
         if (!in_range) flag_error(status, kStInternal, (my_dst - dbase < kBufRange - (1u << 20) ? 0u : 1u << 31) | (lane << 24) | (blockIdx.x & 0xFFFFFFu));
         return;
     }
-    const uint32_t dst_rel = have ? static_cast<uint32_t>(my_dst - dbase) : 0u;
+    uint32_t dst_rel = have ? static_cast<uint32_t>(my_dst - dbase) : 0u;
     const uint32_t src_rel = have ? static_cast<uint32_t>(ptop - sbase) : 0u;   // sbase is 128-byte aligned: offsets and addresses share their low 7 bits
     uint8_t *const obase = (to_lit ? lit : out) + dbase;
     const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(obase, 0, static_cast<int>(kBufRange), kBufWord3);
@@ -314,30 +472,37 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         load_line(src_rel & ~127u);
         land_piece();                                      // the ring holds two pieces
         land_piece();
-        const uint32_t *r = reinterpret_cast<const uint32_t *>(s_ring) + lane;
-        L.hi = r[rp0 * 64];
-        L.lo = r[(rp0 + 1) * 64];
-        L.nw = r[(rp0 + 2) * 64];
+        const uint32_t *rw = reinterpret_cast<const uint32_t *>(s_ring) + lane;
+        L.hi = rw[rp0 * 64];
+        L.lo = rw[(rp0 + 1) * 64];
+        L.nw = rw[(rp0 + 2) * 64];
         L.ra = ((rp0 + 2) << 8) | (lane << 2);
+        if (TBL == kTblDict) r = dict_fetch();
+        if (TBL == kTblCompact) r = tbl4[__builtin_amdgcn_alignbit(L.hi, L.lo, L.s) >> sh];
     }
     wave_sync();
 
-    // ---- flush: one 128-byte unit (a whole cache line / HBM burst pair) per ready row, 8 lanes per row.
-    // A round produces <= 64 bytes per row, so about half the rows are ready in any round: the owners
-    // compact their descriptors (position >> 7 | row | full) into a list, and store instruction k
-    // serves list entries 8 k .. 8 k + 7 -- every instruction writes eight whole 128-byte lines.
-    // The list is stored transposed (entry i at dword (i & 7) * 8 + (i >> 3)) so that the eight lanes
-    // of a group fetch their eight entries with two ds_read_b128.  The first and last unit of a stream
-    // (bytes of a neighbouring stream / not produced yet) are written byte-wise.
-    const uint32_t oct = lane & 7, grp = lane >> 3;
+    // ---- flush: one unit per ready row, 16 bytes per lane.  A round produces <= 64 bytes per row, so
+    // about half the rows (128-byte units) are ready in any round: the owners compact their
+    // descriptors (position >> kUnitShift << 7 | row << 1 | full) into a list, and store instruction k
+    // serves list entries kRowsPerStore k .. kRowsPerStore k + kRowsPerStore - 1 -- every instruction
+    // writes whole units.  The list is stored transposed (entry i at dword (i % kRowsPerStore) * kStoreIters
+    // + i / kRowsPerStore) so that the lanes of a group fetch their entries with one or two ds_read_b128.
+    // The first and last unit of a stream or segment (bytes of a neighbour / not produced yet) are
+    // written byte-wise.
+    const uint32_t oct = lane % kLanesPerRow, grp = lane / kLanesPerRow;
     uint32_t n_part = 0;                                   // set by publish: rows whose unit is incomplete (uniform)
-    auto publish = [&](bool final) -> uint32_t {           // returns the number of ready rows
+    bool took_partial = false;                             // set by publish: this lane's row goes out as an incomplete unit
+    auto publish = [&](bool lane_final) -> uint32_t {      // returns the number of ready rows
         const uint32_t avail = static_cast<uint32_t>(wa - orow);
-        const bool ready = have && (avail >= kUnit || (final && avail > 0));
+        const bool ready = have && (avail >= kUnit || (lane_final && avail > 0));
         const bool full = rbase >= h && avail >= kUnit;
         const unsigned long long m = __ballot(ready ? 1 : 0);
         const uint32_t rank = static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
-        if (ready) s_cunit[(rank & 7u) * 8u + (rank >> 3)] = (((dst_rel + rbase) >> 7) << 8) | (lane << 2) | (full ? 3u : 1u);
+        if (ready)
+            s_cunit[(rank % kRowsPerStore) * kStoreIters + (rank / kRowsPerStore)] =
+                (((dst_rel + rbase) >> kUnitShift) << 7) | (lane << 1) | (full ? 1u : 0u);
+        took_partial = ready && avail < kUnit;
         n_part = static_cast<uint32_t>(__popcll(__ballot(ready && !full ? 1 : 0)));
         if (n_part) {                                      // only the byte-wise path needs these
             s_q[lane] = rbase + avail;
@@ -346,39 +511,50 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         return static_cast<uint32_t>(__popcll(m));
     };
     auto flush = [&](uint32_t n_ready) {
-        const uint32_t wmask = (dbg & 64u) ? 0x1FFF80u : ~127u;   // ablation: all stores into a small window
-        const uint4 c0 = *reinterpret_cast<const uint4 *>(&s_cunit[grp * 8]);
-        const uint4 c1 = *reinterpret_cast<const uint4 *>(&s_cunit[grp * 8 + 4]);
-        const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-        if (n_part && !(dbg & 1u)) {                       // first / last unit of a stream: byte-wise, rare
+        uint32_t c[kStoreIters];
+        {
+            const uint4 c0v = *reinterpret_cast<const uint4 *>(&s_cunit[grp * kStoreIters]);
+            c[0] = c0v.x;
+            c[1] = c0v.y;
+            c[2] = c0v.z;
+            c[3] = c0v.w;
+            if constexpr (kStoreIters == 8) {
+                const uint4 c1v = *reinterpret_cast<const uint4 *>(&s_cunit[grp * kStoreIters + 4]);
+                c[kStoreIters - 4] = c1v.x;
+                c[kStoreIters - 3] = c1v.y;
+                c[kStoreIters - 2] = c1v.z;
+                c[kStoreIters - 1] = c1v.w;
+            }
+        }
+        if (n_part) {                                      // first / last unit of a stream or segment: byte-wise, rare
 #pragma unroll 1
-            for (uint32_t k = 0; 8 * k < n_ready; k++) {
-                const uint32_t ck = s_cunit[grp * 8 + k];
-                if (8 * k + grp >= n_ready || (ck & 3u) != 1u) continue;
-                const uint32_t row = (ck >> 2) & 63u, pos = (ck >> 8) << 7;
+            for (uint32_t k = 0; kRowsPerStore * k < n_ready; k++) {
+                const uint32_t ck = s_cunit[grp * kStoreIters + k];
+                if (kRowsPerStore * k + grp >= n_ready || (ck & 1u)) continue;
+                const uint32_t row = (ck >> 1) & 63u, pos = (ck >> 7) << kUnitShift;
                 const uint32_t rfl = s_fl[row], rq = s_q[row], rh = s_h[row];
                 const uint32_t lo_x = rfl + 16 * oct, hi_x = lo_x + 16;
                 const uint32_t v_lo = lo_x > rh ? lo_x : rh, v_hi = hi_x < rq ? hi_x : rq;
                 uint8_t *d = obase + pos + 16 * oct;
-                const uint8_t *rowp = s_out + row * kOutPitch + 16 * oct;
+                const uint8_t *rowp = s_out + row * kPitch + 16 * oct;
 #pragma clang loop vectorize(disable) unroll(disable)
                 for (uint32_t x = v_lo; x < v_hi; x++) d[x - lo_x] = rowp[x - lo_x];
             }
         }
-        uint2 w[8][2];                                     // all LDS reads first: the stores then go out back to back
+        uint2 w[kStoreIters][2];                           // all LDS reads first: the stores then go out back to back
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) {
-            if (8 * k >= n_ready) break;                   // uniform
-            const uint8_t *rowp = s_out + ((c[k] >> 2) & 63u) * kOutPitch + 16 * oct;
+        for (uint32_t k = 0; k < kStoreIters; k++) {
+            if (kRowsPerStore * k >= n_ready) break;       // uniform
+            const uint8_t *rowp = s_out + ((c[k] >> 1) & 63u) * kPitch + 16 * oct;
             w[k][0] = *reinterpret_cast<const uint2 *>(rowp);
             w[k][1] = *reinterpret_cast<const uint2 *>(rowp + 8);
         }
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) {
-            if (8 * k >= n_ready) break;                   // uniform
-            const uint32_t pos = (c[k] >> 8) << 7;
-            const bool on = 8 * k + grp < n_ready && (c[k] & 3u) == 3u && !(dbg & 1u);
-            const uint32_t voff = on ? (pos & wmask) + 16 * oct : kBufOff;
+        for (uint32_t k = 0; k < kStoreIters; k++) {
+            if (kRowsPerStore * k >= n_ready) break;       // uniform
+            const uint32_t pos = (c[k] >> 7) << kUnitShift;
+            const bool on = kRowsPerStore * k + grp < n_ready && (c[k] & 1u) && !(kAblate & 1u);
+            const uint32_t voff = on ? ((kAblate & 16u) ? (pos & 0x1FFFC0u) : pos) + 16 * oct : kBufOff;
             u32x4 v;
             v[0] = w[k][0].x;
             v[1] = w[k][0].y;
@@ -387,50 +563,175 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
             __builtin_amdgcn_raw_buffer_store_b128(v, rs_dst, voff, 0, 0);
         }
     };
+    // ---- a look-up's bytes into the row.  A row position is only 2-byte (ASCII) / 1-byte aligned, and an LDS store must
+    // not straddle a dword: ONE 4-byte store at a 2-byte aligned address costs 56 cycles per wave-instruction on
+    // gfx950 against 6.5 for an aligned one and 11.5 for a 2-byte store (tools/ldsbench.hip) -- and hipcc fuses
+    // adjacent narrow stores into exactly the straddling kind.  So: TWO narrow stores, kept apart on purpose
+    // (volatile, LDS address space).  (Measured and dropped: two aligned dwords per look-up through ds_write2_b32
+    // with the two characters below the position carried in a register -- 10 LDS cycles instead of 20, but the
+    // 13 extra VALU instructions per look-up cost more than they saved.)
+    // nsym = symbols the caller takes (0: none -- the bytes land beyond the row's content and are overwritten).
+    auto put_adv = [&](uint32_t x, uint32_t nsym) {
+        if (ASCII) {
+            NAFGPU_LDS_VOLATILE(uint16_t, wa)[0] = static_cast<uint16_t>(x);
+            NAFGPU_LDS_VOLATILE(uint16_t, wa)[1] = static_cast<uint16_t>(x >> 16);
+        } else {
+            NAFGPU_LDS_VOLATILE(uint8_t, wa)[0] = static_cast<uint8_t>(x);
+            NAFGPU_LDS_VOLATILE(uint8_t, wa)[1] = static_cast<uint8_t>(x >> 16);
+        }
+        wa += nsym * kOutB;
+    };
 
-    // One round = [request the next 32-byte input pair unless one is still waiting for room] ->
-    // [flush the units the previous rounds completed] -> [16 look-ups] -> [land the pair if it fits].
-    // The loads are requested before the flush, so they are older than the round's stores in the
-    // in-order VM counter and have the whole round to arrive.
+    // One round = [flush the units the previous rounds completed] -> [16 look-ups] -> [land the next
+    // 32-byte piece if the ring has room].  The line loads are requested a round or two before their
+    // first piece is needed, so they are older than the round's stores in the in-order VM counter.
     auto decode_round = [&](auto esc) {
         const uint32_t pos = rbase + static_cast<uint32_t>(wa - orow);
-        if (dbg & 4u) {                                    // ablation: no decode, rows fill instantly
+        if (kAblate & 2u) {
             if (pos < end_abs) wa += (end_abs - pos < 64u ? end_abs - pos : 64u);
-        } else if (pos + 32 * kOutB <= end_abs) {          // 16 look-ups cannot overrun the stream
+            return;
+        }
+        // (wave-wide votes stay outside divergent code: every lane of the wave takes part)
+        const bool dword_round = ASCII && TBL == kTblBaked && all_pairs &&
+                                 !__any((pos < end_abs && (static_cast<uint32_t>(wa - orow) & 2u)) ? 1 : 0);
+        if (pos + 32 * kOutB <= end_abs) {                 // 16 look-ups cannot overrun the stream (segment)
+            if (dword_round) {
+                // every entry of the task's table holds two symbols (codes of 4 bits or less: uniform ACGT) and every
+                // lane stands on a dword boundary: each look-up is one aligned 4-byte store, nothing to carry
 #pragma unroll
-            for (uint32_t k = 0; k < 16; k++) {
-                const uint2 e = lookup(esc);
-                if (ASCII) {
-                    reinterpret_cast<uint16_t *>(wa)[0] = static_cast<uint16_t>(e.x);
-                    reinterpret_cast<uint16_t *>(wa)[1] = static_cast<uint16_t>(e.x >> 16);
-                } else {
-                    wa[0] = static_cast<uint8_t>(e.x);
-                    wa[1] = static_cast<uint8_t>(e.x >> 16);
+                for (uint32_t k = 0; k < 16; k++) {
+                    const HufLook e = lookup(esc);
+                    *reinterpret_cast<uint32_t *>(wa) = e.x;
+                    wa += 4;
+                    huf_advance(L, s_ring, e.bits);
                 }
-                wa += (e.y >> 8) & 0xFFu;
-                huf_advance(L, s_ring, e.y & 0xFFu);
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++) {
+                    const HufLook e = lookup(esc);
+                    put_adv(e.x, 1u + e.two);
+                    huf_advance(L, s_ring, e.bits);
+                }
             }
-        } else if (pos < end_abs) {                        // tail of the stream: never take more than is left
+        } else if (pos < end_abs) {                        // tail of the stream (segment): never take more than is left
 #pragma unroll 4
             for (uint32_t k = 0; k < 16; k++) {
-                const uint2 e = lookup(esc);
+                const HufLook e = lookup(esc);
                 const uint32_t left = end_abs - (rbase + static_cast<uint32_t>(wa - orow));   // bytes
-                const bool two = ((e.y >> 24) & 1u) && left >= 2 * kOutB;
-                if (ASCII) {
-                    reinterpret_cast<uint16_t *>(wa)[0] = static_cast<uint16_t>(e.x);
-                    reinterpret_cast<uint16_t *>(wa)[1] = static_cast<uint16_t>(e.x >> 16);
-                } else {
-                    wa[0] = static_cast<uint8_t>(e.x);
-                    wa[1] = static_cast<uint8_t>(e.x >> 16);
+                const bool two = e.two && left >= 2 * kOutB;
+                put_adv(e.x, left == 0 ? 0u : (two ? 2u : 1u));
+                huf_advance(L, s_ring, left == 0 ? 0u : (two ? e.bits : e.first));
+            }
+        }
+    };
+    // compact tables, the same pipelining as the dict tables below: `r` is the entry under the cursor, fetched by the
+    // look-up before; the next table read is issued BEFORE the two character reads of this one.
+    auto compact_fetch = [&]() -> uint32_t { return tbl4[__builtin_amdgcn_alignbit(L.hi, L.lo, L.s) >> sh]; };
+    auto compact_chars = [&](uint32_t c) -> uint32_t {
+        const uint32_t s1 = c & 0xFFu, s2 = (c >> 8) & 0xFFu;
+        return ASCII ? (static_cast<uint32_t>(s_lut[s1]) | (static_cast<uint32_t>(s_lut[s2]) << 16)) : (s1 | (s2 << 16));
+    };
+    auto decode_round_compact = [&](auto esc) {
+        const uint32_t pos = rbase + static_cast<uint32_t>(wa - orow);
+        if (kAblate & 2u) {
+            if (pos < end_abs) wa += (end_abs - pos < 64u ? end_abs - pos : 64u);
+            return;
+        }
+        auto entry = [&]() -> uint32_t {                   // the entry under the cursor, long codes resolved through their sub-table
+            uint32_t c = r;
+            if (decltype(esc)::value) {
+                if (c & (1u << 25)) c = tbl4[(c & 0xFFFFu) + ((__builtin_amdgcn_alignbit(L.hi, L.lo, L.s) >> sh2) & esc_mask)];
+            }
+            return c;
+        };
+        if (pos + 32 * kOutB <= end_abs) {                 // 16 look-ups cannot overrun the stream (segment)
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint32_t c = entry();
+                huf_advance(L, s_ring, (c >> 16) & 15u);
+                r = compact_fetch();
+                put_adv(compact_chars(c), 1u + ((c >> 24) & 1u));
+            }
+        } else if (pos < end_abs) {                        // tail of the stream (segment): never take more than is left
+#pragma unroll 4
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint32_t c = entry();
+                const uint32_t left = end_abs - (rbase + static_cast<uint32_t>(wa - orow));   // bytes
+                const bool two = ((c >> 24) & 1u) && left >= 2 * kOutB;
+                huf_advance(L, s_ring, left == 0 ? 0u : (two ? (c >> 16) & 15u : (c >> 20) & 15u));
+                r = compact_fetch();
+                put_adv(compact_chars(c), left == 0 ? 0u : (two ? 2u : 1u));
+            }
+        }
+    };
+    // dict tables.  The entry under the cursor (`r`) was fetched by the look-up before: a look-up extracts its
+    // fields, moves the bit window, ISSUES the next table read and the two dictionary reads together, and only
+    // then writes its characters -- one LDS latency per look-up on the dependent chain instead of two.  An escape
+    // entry has 0 symbols / 0 bits: the lane stays on it (no branch in the loop) and resolves it before the
+    // next round's look-ups with one sub-table read.
+    const uint8_t *const dict_bytes = reinterpret_cast<const uint8_t *>(s_dict);
+    auto resolve_escape = [&]() {                          // r is an escape entry: one symbol through its sub-table
+        const uint32_t peek = __builtin_amdgcn_alignbit(L.hi, L.lo, L.s);
+        const uint32_t c = tbl2[(1u << W) + (((r >> 2) & 0x3FFu) << esc_bits) + ((peek >> sh2) & esc_mask)];
+        put_adv(*reinterpret_cast<const uint32_t *>(dict_bytes + (c & 0xFCu)), 1u);
+        huf_advance(L, s_ring, (c >> 12) + W);
+        r = dict_fetch();
+    };
+    // A round is four groups of four look-ups.  A group whose four look-ups cannot overrun the stream (segment)
+    // runs them without any test; an escape met in a group is resolved IN PLACE OF the next group's first look-up (so a
+    // round never produces more than 16 x 2 symbols, which is what the row -- unit + 64 bytes -- is sized for); the last
+    // few symbols of a stream (segment) go one careful step at a time.
+    auto decode_round_dict = [&]() {
+        if (kAblate & 2u) {
+            const uint32_t pos = rbase + static_cast<uint32_t>(wa - orow);
+            if (pos < end_abs) wa += (end_abs - pos < 64u ? end_abs - pos : 64u);
+            return;
+        }
+        auto step = [&]() {                                // one look-up: see above
+            const uint32_t c = r;
+            const uint32_t *a1 = reinterpret_cast<const uint32_t *>(dict_bytes + (c & 0xFCu));
+            const uint32_t *a2 = reinterpret_cast<const uint32_t *>(dict_bytes + ((c >> 6) & 0x3Cu));
+            huf_advance(L, s_ring, c >> 12);
+            r = dict_fetch();
+            const uint32_t x = (kAblate & 32u) ? c : (*a1 | (*a2 << 16));
+            put_adv(x, c & 3u);
+        };
+#pragma unroll
+        for (uint32_t g = 0; g < 4; g++) {
+            const uint32_t pos = rbase + static_cast<uint32_t>(wa - orow);
+            if (pos + 8 * kOutB <= end_abs) {              // four look-ups cannot overrun the stream (segment)
+                if (task_esc && (r & 3u) == 0)
+                    resolve_escape();
+                else
+                    step();
+                step();
+                step();
+                step();
+            } else if (pos < end_abs) {                    // never take more than is left
+#pragma unroll 1
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t left = end_abs - (rbase + static_cast<uint32_t>(wa - orow));   // bytes
+                    if (left != 0 && (r & 3u) == 0) {
+                        resolve_escape();
+                    } else {
+                        const uint32_t c = r;
+                        const bool two = (c & 3u) == 2u && left >= 2 * kOutB;
+                        const uint32_t bits = (c & 3u) == 2u && !two ? static_cast<uint32_t>(lenlut[(c >> 2) & 63u]) : c >> 12;
+                        put_adv(*reinterpret_cast<const uint32_t *>(dict_bytes + (c & 0xFCu)) |
+                                    (*reinterpret_cast<const uint32_t *>(dict_bytes + ((c >> 6) & 0x3Cu)) << 16),
+                                left == 0 ? 0u : (two ? 2u : 1u));
+                        huf_advance(L, s_ring, left == 0 ? 0u : bits);
+                        r = dict_fetch();
+                    }
                 }
-                wa += left == 0 ? 0u : (two ? 2 * kOutB : kOutB);
-                huf_advance(L, s_ring, left == 0 ? 0u : (two ? e.y & 0xFFu : (e.y >> 16) & 0xFFu));
             }
         }
     };
     int any = 1;
     while (any) {
-        const uint32_t n_ready = publish(false);
+        // SEG: a lane whose segment is complete drains its row (whole units first, then the incomplete one) ...
+        const bool seg_done = SEG && rbase + static_cast<uint32_t>(wa - orow) == end_abs && syms_after != 0;
+        const uint32_t n_ready = publish(seg_done);
         wave_sync();
         flush(n_ready);
         wave_sync();
@@ -450,21 +751,39 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
             *reinterpret_cast<uint2 *>(orow + 56) = m7;
             wa -= kUnit;
             rbase += kUnit;
+        } else if (SEG && took_partial) {                  // the incomplete last unit of the segment went out: the row is empty
+            rbase += static_cast<uint32_t>(wa - orow);
+            wa = orow;
         }
-        if (task_esc) decode_round(std::true_type{});
+        if (SEG && seg_done && wa == orow) {               // ... and re-bases it where the next literal run goes
+            uint32_t seg_len = 0;
+            const uint32_t lit_end = static_cast<uint32_t>(st.dst) + st.n_syms;
+            const uint64_t dstart = segment_at(lit_end - syms_after, lit_end, &seg_len) * kOutB;
+            syms_after -= seg_len;
+            h = static_cast<uint32_t>(dstart & (kUnit - 1));
+            dst_rel = static_cast<uint32_t>(dstart - h - dbase);
+            rbase = 0;
+            wa = orow + h;
+            end_abs = h + seg_len * kOutB;
+            s_h[lane] = h;
+        }
+        if (TBL == kTblDict) decode_round_dict();
+        else if (TBL == kTblCompact && task_esc) decode_round_compact(std::true_type{});
+        else if (TBL == kTblCompact) decode_round_compact(std::false_type{});
+        else if (task_esc) decode_round(std::true_type{});
         else decode_round(std::false_type{});
-        // ---- land the pair requested at the top of the round, if the ring has room for it.
+        // ---- land the next piece, if the ring has room for it.
         // d = words between the oldest ring slot and the cursor; staged past the cursor = 16 - d;
         // 8 words fit once d >= 8.  A round uses <= 6 words + 2 of look-ahead, and d >= 8 whenever
         // fewer than 9 are staged, so the cursor never outruns the ring.
         {
             const uint32_t rp_mod = ((L.ra >> 8) - 2u) & 15u;
             const uint32_t d = (rp_mod - 8u * wp) & 15u;
-            if (have && d >= 8u && !(dbg & 32u)) land_piece();
+            if (have && d >= 8u && !(kAblate & 4u)) land_piece();
         }
-        any = __any(rbase + static_cast<uint32_t>(wa - orow) < end_abs ? 1 : 0);
+        any = __any((rbase + static_cast<uint32_t>(wa - orow) < end_abs || (SEG && syms_after != 0)) ? 1 : 0);
     }
-    for (uint32_t t = 0; t < 2; t++) {                     // at most 127 + 64 bytes are left in a row
+    for (uint32_t t = 0; t < 2; t++) {                     // at most kUnit - 1 + 64 bytes are left in a row
         const uint32_t n_ready = publish(true);
         wave_sync();
         flush(n_ready);
@@ -479,7 +798,7 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
             wa = orow;
         }
     }
-    if (have && !(dbg & 36u)) {
+    if (have && !(kAblate & 6u)) {
         // words advanced: the ring holds absolute words [8 wp - 16, 8 wp)
         const uint32_t rp_mod = ((L.ra >> 8) - 2u) & 15u;
         const uint32_t rp_abs = 8u * wp - 16u + ((rp_mod - 8u * wp) & 15u);
@@ -1212,6 +1531,13 @@ __global__ __launch_bounds__(256) void k_lz_literals(const SeqBlock *__restrict_
     const Seq *sq = seqs + sb.seq_first;
     if (tid == 0) blk_pending[blockIdx.x] = sb.n_seq;
     auto put = [&](Elem *d, uint8_t b) { *d = ASCII ? static_cast<Elem>(byte_chars(b, t_char)) : static_cast<Elem>(b); };
+    if (sb.direct) {                                       // k_huf_decode put the literals in place: only the match table is left to do
+        for (uint32_t s = tid; s < sb.n_seq; s += 256) {
+            const Seq q = sq[s];
+            meta[sb.seq_first + s] = SeqMeta{obase + q.opos + q.ll, q.ml, 0u};
+        }
+        return;
+    }
     for (uint32_t s0 = 0; s0 < sb.n_seq; s0 += 256) {
         if (tid == 0) s_nlong = 0;
         __syncthreads();
@@ -1929,32 +2255,35 @@ void launch_copy_fill(hipStream_t stream, const uint8_t *src, const CopyTask *ta
                            status);
 }
 
-void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *tasks, uint32_t n_tasks,
+void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *tasks, const HufClass &cls,
                        const HufTblCopy *copies, const HufStream *streams, const uint16_t *pool,
-                       const uint64_t *blk_base, uint8_t *out, uint8_t *lit, uint32_t max_tbl_entries, bool compact, bool ascii,
-                       uint32_t t_char, uint32_t *status) {
-    if (!n_tasks) return;
-    static const uint32_t lds_pad = [] {                  // occupancy experiments: extra dynamic LDS per workgroup
-        const char *e = std::getenv("NAFGPU_K1_LDS_PAD");
-        return e ? static_cast<uint32_t>(std::atoi(e)) : 0u;
-    }();
-    const uint32_t lds = (((max_tbl_entries * (compact ? 4u : 8u)) + 15u) & ~15u) + lds_pad;
-    static const uint32_t dbg = [] {                     // timing ablations only; results are wrong when set
-        const char *e = std::getenv("NAFGPU_K1_DEBUG");
-        return e ? static_cast<uint32_t>(std::atoi(e)) : 0u;
-    }();
-    const bool a = ascii && !(dbg & 2u);
-#define NAFGPU_LAUNCH_HUF(A, T)                                                                                              \
-    hipLaunchKernelGGL((k_huf_decode<A, T>), dim3(n_tasks), dim3(64), lds, stream, src, tasks, copies, streams, pool, blk_base, \
-                       out, lit, t_char, dbg, status)
-    if (a && !compact)
-        NAFGPU_LAUNCH_HUF(true, false);
-    else if (a)
-        NAFGPU_LAUNCH_HUF(true, true);
-    else if (!compact)
-        NAFGPU_LAUNCH_HUF(false, false);
+                       const uint64_t *blk_base, uint8_t *out, uint8_t *lit, const SeqBlock *seq_blocks, const Seq *seqs,
+                       const uint8_t *dicts, bool ascii, uint32_t t_char, uint32_t *status) {
+    if (!cls.n_tasks) return;
+    const uint32_t lds = (cls.lds_bytes + 15u) & ~15u;
+    const bool a = ascii && !cls.to_lit;                   // the literal buffer always holds packed bytes
+    const HufTask *t0 = tasks + cls.first_task;
+#define NAFGPU_LAUNCH_HUF(A, T, S)                                                                                            \
+    hipLaunchKernelGGL((k_huf_decode<A, T, S>), dim3(cls.n_tasks), dim3(64), lds, stream, src, t0, copies, streams, pool,     \
+                       blk_base, out, lit, seq_blocks, seqs, dicts, t_char, status)
+#define NAFGPU_LAUNCH_HUF_T(T)                       \
+    do {                                             \
+        if (a && cls.seg)                            \
+            NAFGPU_LAUNCH_HUF(true, T, true);        \
+        else if (a)                                  \
+            NAFGPU_LAUNCH_HUF(true, T, false);       \
+        else if (cls.seg)                            \
+            NAFGPU_LAUNCH_HUF(false, T, true);       \
+        else                                         \
+            NAFGPU_LAUNCH_HUF(false, T, false);      \
+    } while (0)
+    if (cls.tbl == kTblBaked)
+        NAFGPU_LAUNCH_HUF_T(kTblBaked);
+    else if (cls.tbl == kTblCompact)
+        NAFGPU_LAUNCH_HUF_T(kTblCompact);
     else
-        NAFGPU_LAUNCH_HUF(false, true);
+        NAFGPU_LAUNCH_HUF_T(kTblDict);
+#undef NAFGPU_LAUNCH_HUF_T
 #undef NAFGPU_LAUNCH_HUF
 }
 

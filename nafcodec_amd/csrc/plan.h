@@ -10,6 +10,11 @@ constexpr uint32_t kBlockMax = 128u << 10;   // zstd Block_Maximum_Size
 constexpr int kHufWave = 64;                 // one Huffman stream per lane, one wave per workgroup
 constexpr uint32_t kHufLdsEntries = 2048;    // 8-byte decode-table entries a single-tree wave task may stage in LDS
 constexpr uint32_t kHufLdsEntries4 = 6144;   // 4-byte entries a task with several trees may stage (compact tables, see HufTask)
+constexpr uint32_t kHufLdsSlots2 = 5632;     // 2-byte slots a task of small-alphabet trees may stage (dictionary tables, see HufTask)
+constexpr uint32_t kHufDictSyms = 64;        // most symbols the trees of a task may use between them to take the dictionary format
+constexpr uint32_t kHufDictSlots = 32;       // 2-byte slots in front of a dictionary table: the tree's code length of each of the 64 dictionary symbols
+constexpr uint32_t kDirectSeqMax = 64;       // blocks with at most this many LZ sequences have their Huffman literals written straight
+                                             // to their final positions by k_huf_decode (segment by segment); more: literal buffer + K4
 constexpr uint32_t kHufTaskSpan = 1u << 30;   // a wave task's streams lie within this many bytes of input and of output
 constexpr uint32_t kSrcFrontPad = 512;       // bytes readable in front of any device source buffer (k_huf_decode: ring look-ahead + whole lines)
 constexpr uint32_t kSrcBackPad = 256;        // ... and behind it (k_huf_decode reads whole 128-byte lines)
@@ -17,13 +22,16 @@ constexpr uint32_t kSrcBackPad = 256;        // ... and behind it (k_huf_decode 
 // One Huffman-coded literal stream = one lane of k_huf_decode.
 struct alignas(16) HufStream {
     uint64_t src_end;    // offset one past the stream's last byte, from the section payload base
-    uint64_t dst;        // flags&1: absolute offset in the literal buffer; else offset inside block `blk`
+    uint64_t dst;        // flags&1: absolute offset in the literal buffer; else bits 0-31: index of the stream's first literal in the
+                         // block's literal section (= offset inside block `blk` when the block has no sequences), bits 32-63:
+                         // 1 + index of the block's SeqBlock when its literals are interleaved with matches (flags&2), else 0
     uint32_t src_len;    // bytes in the stream (>= 1)
     uint32_t n_syms;     // symbols to regenerate
     uint32_t blk;        // zstd block index (for blk_base[])
     uint16_t tbl_lds;    // first entry of this stream's table inside the task's LDS table area
     uint8_t max_bits;    // index width W of the staged table (6..8, chosen per task by the host)
-    uint8_t flags;       // bit0: write to the literal buffer (block has sequences); bits 4-7: tree max_bits - W (0 = no escapes)
+    uint8_t flags;       // bit0: write to the literal buffer (block has many sequences); bit1: block has a few sequences, the
+                         // literals go to their final positions segment by segment; bits 4-7: tree max_bits - W (0 = no escapes)
 };
 static_assert(sizeof(HufStream) == 32, "HufStream layout");
 
@@ -31,16 +39,34 @@ struct HufTblCopy {      // build the two-symbol table of pool[pool_off ..) at L
     uint32_t pool_off;   // 2^max_bits single-symbol entries (len << 8 | sym) in the pool
     uint32_t lds_off;    // first staged entry (8-byte entries)
     uint32_t n_entries;  // 2^W main entries + one 2^(max_bits - W) sub-table per escaping prefix
+                         // (kTblDict: lds_off and n_entries count 2-byte slots and include the kHufDictSlots in front)
     uint32_t bits;       // max_bits | W << 8
 };
 
-// One workgroup of k_huf_decode: <= 64 streams and the decode tables of their trees.  Tasks come in two
-// table formats, launched separately: 8-byte entries with the output characters baked in (one tree:
-// the fast path) and compact 4-byte entries {sym1, sym2, bits, bits of sym1, two} whose characters
-// come from a 512-byte look-up table shared by the wave (several trees: what counts there is LDS per
-// lane, because the lanes resident per CU set the throughput).
+// One workgroup of k_huf_decode: <= 64 streams and the decode tables of their trees.  Tasks come in three
+// table formats, launched separately:
+//   kTblBaked   8-byte entries with the output characters baked in (one tree per task: the fast path)
+//   kTblCompact 4-byte entries {sym1, sym2, bits, bits of sym1, two} whose characters come from a 512-byte
+//               look-up table shared by the wave (several trees, some with more than kHufDictSyms symbols)
+//   kTblDict    2-byte entries {symbols, bits, index of sym1, index of sym2} into ONE dictionary of
+//               <= kHufDictSyms symbols shared by the trees of the task (several small-alphabet trees -- what
+//               real genomes give: what counts there is LDS per lane, because the lanes resident per CU set
+//               the throughput; and a dictionary shared by the wave is read conflict-free -- the few hot
+//               symbols are broadcast)
+enum HufTblKind : uint32_t { kTblBaked = 0, kTblCompact = 1, kTblDict = 2 };
 struct HufTask {
     uint32_t first_stream, n_streams, first_copy, n_copies;
+    uint32_t dict_off;       // kTblDict: first of the task's kHufDictSyms dictionary symbols in the dictionary pool (short codes first)
+    uint32_t n_dict;         // symbols in it
+    uint32_t pad[2];
+};
+// A run of tasks launched together: same table format, same destination, same kernel variant.
+struct HufClass {
+    uint32_t first_task, n_tasks;
+    uint32_t tbl;            // HufTblKind
+    uint32_t to_lit;         // streams feed the literal buffer (never expanded to ASCII)
+    uint32_t seg;            // some stream is interleaved with matches (flags&2): the segment-aware kernel variant
+    uint32_t lds_bytes;      // dynamic LDS: the largest staged-table footprint over the tasks
 };
 
 struct CopyTask {        // Raw/RLE blocks and Raw/RLE literal sections
@@ -70,7 +96,8 @@ struct SeqBlock {        // one compressed block with nbSeq > 0
     uint32_t blk;
     uint32_t lit_size;
     uint32_t frame_first_blk;          // first block of the frame this block belongs to
-    uint8_t ll_al, of_al, ml_al, pad;
+    uint8_t ll_al, of_al, ml_al;
+    uint8_t direct;                    // 1: k_huf_decode already put the literals at their final positions (<= kDirectSeqMax sequences)
     uint32_t pad2;
 };
 static_assert(sizeof(SeqBlock) == 64, "SeqBlock layout");

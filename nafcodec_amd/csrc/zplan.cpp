@@ -2,6 +2,7 @@
 #include "zplan.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace nafgpu {
@@ -216,6 +217,7 @@ bool append_seq_table(ZPlan *plan, SeqKind kind, const FseStates &t, TableRef *r
 // ---------------------------------------------------------------- Huffman (App. B "Huffman tree description")
 struct HufRef {
     uint32_t pool_off = 0;
+    uint16_t n_syms = 0;       // symbols with a code
     uint8_t max_bits = 0;
     bool valid = false;
 };
@@ -308,6 +310,8 @@ long read_huf_table(const uint8_t *src, size_t n, ZPlan *plan, HufRef *ref, Fail
     ref->pool_off = static_cast<uint32_t>(plan->huf_pool.size());
     ref->max_bits = static_cast<uint8_t>(max_bits);
     ref->valid = true;
+    ref->n_syms = 0;
+    for (int i = 0; i < nw; i++) ref->n_syms += w[i] != 0;
     plan->huf_pool.resize(plan->huf_pool.size() + size);
     uint16_t *tbl = plan->huf_pool.data() + ref->pool_off;
     uint32_t pos = 0;
@@ -468,9 +472,14 @@ struct Walker {
             nseq = static_cast<size_t>(p[j + 1]) + (static_cast<size_t>(p[j + 2]) << 8) + 0x7F00;
             j += 3;
         }
-        const bool to_lit = nseq > 0;
+        // A block with a few sequences and Huffman-coded literals (what real genomes give zstd level 1): the literal
+        // streams go straight to their final positions, segment by segment (k_huf_decode reads the block's decoded
+        // sequences); with many sequences the literals take the literal buffer and K4 scatters them.
+        const bool seg = nseq > 0 && nseq <= kDirectSeqMax && type >= 2;
+        const bool to_lit = nseq > 0 && !seg;
         const uint64_t lit_base = plan->lit_bytes;  // literal-buffer offset when to_lit
-        const uint8_t lflag = to_lit ? 1 : 0;
+        const uint8_t lflag = to_lit ? 1 : (seg ? 2 : 0);
+        const uint64_t seg_tag = seg ? (static_cast<uint64_t>(plan->seq_blocks.size()) + 1) << 32 : 0;
         // ---- literals tasks
         if (type == 0) {
             if (regen) plan->copies.push_back(CopyTask{lit_at, to_lit ? lit_base : 0, uint32_t(regen), blk, lflag, 0});
@@ -505,7 +514,7 @@ struct Walker {
                 counts[0] = counts[1] = counts[2] = q;
                 counts[3] = regen - 3 * q;
             }
-            uint64_t dst = to_lit ? lit_base : 0;
+            uint64_t dst = to_lit ? lit_base : seg_tag;
             for (int s = 0; s < nstreams; s++) {
                 if (sizes[s] == 0) return bad("empty Huffman stream");
                 t += sizes[s];
@@ -550,11 +559,12 @@ struct Walker {
         sb.blk = blk;
         sb.lit_size = static_cast<uint32_t>(regen);
         sb.lit_off = lit_base;
+        sb.direct = seg ? 1 : 0;
         sb.seq_first = plan->n_sequences;
         sb.frame_first_blk = frame_first_blk;
         plan->seq_blocks.push_back(sb);
         plan->n_sequences += nseq;
-        plan->lit_bytes += (regen + 15) & ~size_t(15);       // keep each block's literals 16-B aligned
+        if (to_lit) plan->lit_bytes += (regen + 15) & ~size_t(15);       // keep each block's literals 16-B aligned
         plan->blk_size.push_back(static_cast<uint32_t>(regen));   // + match bytes, added on the device
         plan->known_out += regen;
         return true;
@@ -631,10 +641,12 @@ struct Walker {
         return true;
     }
 
-    // Greedy packing of streams into wave tasks: <= 64 lanes, decode tables <= kHufLdsEntries.
-    // Streams that write the section output directly come first, those that feed the literal
-    // buffer of a block with sequences second: the two groups are launched separately (the
-    // first one may expand 4-bit codes to ASCII on the fly, the second never does).
+    // Greedy packing of streams into wave tasks: <= 64 lanes whose decode tables fit the LDS budget of
+    // their table format.  Streams that write the section output (directly, or segment by segment
+    // around the matches of a block with a few sequences) come first, those that feed the literal
+    // buffer of a block with many sequences second: the two groups never share a task (the first
+    // may expand 4-bit codes to ASCII on the fly, the second never does).  Tasks are then grouped
+    // into launch classes (table format x destination x segment-aware kernel).
     void pack_tasks() {
         {   // stable partition by destination
             std::vector<HufStream> ordered;
@@ -652,7 +664,7 @@ struct Walker {
         }
         // Every table of a task is staged with the same index width W (8, 7 or 6 bits): 2^W
         // two-symbol entries plus, for codes longer than W bits, one 2^(max_bits - W) entry
-        // sub-table per escaping W-bit prefix.  The widest W whose tables fit kHufLdsEntries wins,
+        // sub-table per escaping W-bit prefix.  The widest W whose tables fit the budget wins,
         // so archives where every block brings its own (possibly 11-bit) tree still fill 64 lanes.
         auto staged_entries = [&](const HufRef &t, uint32_t W) -> uint32_t {
             if (t.max_bits <= W) return 1u << W;
@@ -662,6 +674,12 @@ struct Walker {
                 if ((x1[p << (t.max_bits - W)] >> 8) > W) esc++;
             return (1u << W) + (esc << (t.max_bits - W));
         };
+        struct Packed {
+            HufTask task;
+            uint32_t key;        // to_lit << 3 | tbl << 1 | seg
+            uint32_t lds_bytes;
+        };
+        std::vector<Packed> packed;
         auto pack_group = [&](size_t g0, size_t g1) {
             size_t s = g0;
             while (s < g1) {
@@ -679,9 +697,10 @@ struct Walker {
                         break;
                     }
                 }
-                uint32_t W = 8;
+                uint32_t W = 8, kind = kTblBaked;
                 std::vector<HufRef> distinct;
-                bool compact = false;
+                uint8_t min_len[256];                      // shortest code of every symbol over the task's trees (0xFF: unused)
+                uint32_t n_union = 0;
                 for (;;) {
                     distinct.clear();
                     for (size_t k = s; k < e; k++) {
@@ -689,13 +708,33 @@ struct Walker {
                         for (const HufRef &d : distinct) seen = seen || d.pool_off == stream_tbl[k].pool_off;
                         if (!seen) distinct.push_back(stream_tbl[k]);
                     }
-                    // several trees: compact 4-byte entries and a larger entry budget, so that the task keeps 64 lanes
-                    compact = distinct.size() > 1;
-                    const uint32_t budget = compact ? kHufLdsEntries4 : kHufLdsEntries;
+                    // the symbols the trees use between them: few enough for one shared dictionary?
+                    bool small = distinct.size() > 1;
+                    std::memset(min_len, 0xFF, sizeof min_len);
+                    n_union = 0;
+                    for (size_t d = 0; small && d < distinct.size(); d++) {
+                        if (distinct[d].n_syms > kHufDictSyms) {
+                            small = false;
+                            break;
+                        }
+                        const uint16_t *x1 = plan->huf_pool.data() + distinct[d].pool_off;
+                        for (uint32_t i = 0; i < (1u << distinct[d].max_bits);) {
+                            const uint32_t sym = x1[i] & 0xFFu, len = x1[i] >> 8;
+                            if (min_len[sym] == 0xFF) n_union++;
+                            if (len < min_len[sym]) min_len[sym] = static_cast<uint8_t>(len);
+                            i += 1u << (distinct[d].max_bits - len);       // a code of `len` bits fills that many entries
+                        }
+                        small = n_union <= kHufDictSyms;
+                    }
+                    // several trees: 2-byte dictionary entries (small alphabets) or compact 4-byte entries, and a
+                    // larger budget, so that the task keeps 64 lanes
+                    kind = distinct.size() == 1 ? kTblBaked : (small ? kTblDict : kTblCompact);
+                    const uint32_t budget = kind == kTblBaked ? kHufLdsEntries : (kind == kTblDict ? kHufLdsSlots2 : kHufLdsEntries4);
+                    const uint32_t per_tree = kind == kTblDict ? kHufDictSlots : 0;
                     bool fits = false;
                     for (W = 8; W >= 6; W--) {
                         uint32_t total = 0;
-                        for (const HufRef &d : distinct) total += staged_entries(d, W);
+                        for (const HufRef &d : distinct) total += per_tree + staged_entries(d, W);
                         if (total <= budget) {
                             fits = true;
                             break;
@@ -705,16 +744,28 @@ struct Walker {
                     e = s + (e - s + 1) / 2;                 // too many distinct deep trees: take fewer streams
                 }
                 if (W < 6) W = 6;
+                const uint32_t per_tree = kind == kTblDict ? kHufDictSlots : 0;
                 HufTask task{static_cast<uint32_t>(s), static_cast<uint32_t>(e - s),
-                             static_cast<uint32_t>(plan->tbl_copies.size()), static_cast<uint32_t>(distinct.size())};
+                             static_cast<uint32_t>(plan->tbl_copies.size()), static_cast<uint32_t>(distinct.size()), 0, 0, {0, 0}};
+                if (kind == kTblDict) {                    // the task's dictionary: symbols by shortest code, then by value
+                    task.dict_off = static_cast<uint32_t>(plan->dict_pool.size());
+                    task.n_dict = n_union;
+                    std::vector<uint32_t> order;
+                    for (uint32_t sym = 0; sym < 256; sym++)
+                        if (min_len[sym] != 0xFF) order.push_back((static_cast<uint32_t>(min_len[sym]) << 8) | sym);
+                    std::sort(order.begin(), order.end());
+                    for (uint32_t k = 0; k < kHufDictSyms; k++)
+                        plan->dict_pool.push_back(k < order.size() ? static_cast<uint8_t>(order[k] & 0xFFu) : 0);
+                }
                 uint32_t lds_used = 0;
                 std::vector<uint32_t> lds_of(distinct.size());
                 for (size_t d = 0; d < distinct.size(); d++) {
-                    const uint32_t n = staged_entries(distinct[d], W);
+                    const uint32_t n = per_tree + staged_entries(distinct[d], W);
                     lds_of[d] = lds_used;
                     plan->tbl_copies.push_back(HufTblCopy{distinct[d].pool_off, lds_used, n, distinct[d].max_bits | (W << 8)});
                     lds_used += n;
                 }
+                bool seg = false;
                 for (size_t k = s; k < e; k++) {
                     size_t d = 0;
                     while (distinct[d].pool_off != stream_tbl[k].pool_off) d++;
@@ -723,29 +774,32 @@ struct Walker {
                     hs.max_bits = static_cast<uint8_t>(W);
                     const uint32_t esc_bits = stream_tbl[k].max_bits > W ? stream_tbl[k].max_bits - W : 0;
                     hs.flags = static_cast<uint8_t>((hs.flags & 0x0F) | (esc_bits << 4));
+                    seg = seg || (hs.flags & 2);
                 }
-                plan->tasks.push_back(task);
-                task_compact.push_back(compact ? 1 : 0);
+                const uint32_t to_lit = plan->streams[s].flags & 1u;
+                const uint32_t entry_bytes = kind == kTblBaked ? 8u : (kind == kTblDict ? 2u : 4u);
+                packed.push_back(Packed{task, (to_lit << 3) | (kind << 1) | (seg ? 1u : 0u), lds_used * entry_bytes});
                 s = e;
             }
         };
         size_t first_lit = 0;
         while (first_lit < plan->streams.size() && !(plan->streams[first_lit].flags & 1)) first_lit++;
         pack_group(0, first_lit);
-        plan->n_direct_tasks = static_cast<uint32_t>(plan->tasks.size());
         pack_group(first_lit, plan->streams.size());
-        // inside each group: tasks with 8-byte tables first, compact ones last (the two are launched separately)
-        auto partition = [&](size_t t0, size_t t1) -> uint32_t {
-            std::vector<HufTask> a, b;
-            for (size_t t = t0; t < t1; t++) (task_compact[t] ? b : a).push_back(plan->tasks[t]);
-            std::copy(a.begin(), a.end(), plan->tasks.begin() + static_cast<std::ptrdiff_t>(t0));
-            std::copy(b.begin(), b.end(), plan->tasks.begin() + static_cast<std::ptrdiff_t>(t0 + a.size()));
-            return static_cast<uint32_t>(b.size());
-        };
-        plan->n_direct_compact = partition(0, plan->n_direct_tasks);
-        plan->n_lit_compact = partition(plan->n_direct_tasks, plan->tasks.size());
+        // launch classes: tasks of one key together, keys in ascending order (direct before literal buffer)
+        std::stable_sort(packed.begin(), packed.end(), [](const Packed &a, const Packed &b) { return a.key < b.key; });
+        for (const Packed &pk : packed) {
+            if (class_key.empty() || class_key.back() != pk.key) {
+                plan->classes.push_back(HufClass{static_cast<uint32_t>(plan->tasks.size()), 0, (pk.key >> 1) & 3u, pk.key >> 3, pk.key & 1u, 0});
+                class_key.push_back(pk.key);
+            }
+            HufClass &c = plan->classes.back();
+            c.n_tasks++;
+            c.lds_bytes = std::max(c.lds_bytes, pk.lds_bytes);
+            plan->tasks.push_back(pk.task);
+        }
     }
-    std::vector<uint8_t> task_compact;   // per task (in packing order): compact tables?
+    std::vector<uint32_t> class_key;
 };
 
 }  // namespace

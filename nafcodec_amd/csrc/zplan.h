@@ -22,12 +22,10 @@ struct ZPlan {
                                          // (k_seq_decode adds the match bytes on the device)
     // Huffman literals
     std::vector<HufStream> streams;
-    std::vector<HufTask> tasks;          // the first n_direct_tasks write the section output, the rest the literal buffer
-    uint32_t n_direct_tasks = 0;
-    // task order: [direct, 8-byte tables][direct, compact tables][literal buffer, 8-byte][literal buffer, compact]
-    uint32_t n_direct_compact = 0;       // of the n_direct_tasks, the last n_direct_compact use compact tables
-    uint32_t n_lit_compact = 0;          // of the remaining tasks, the last n_lit_compact use compact tables
+    std::vector<HufTask> tasks;          // grouped by launch class
+    std::vector<HufClass> classes;       // tasks that are launched together (table format x destination x segment-aware)
     std::vector<HufTblCopy> tbl_copies;
+    std::vector<uint8_t> dict_pool;      // kTblDict tasks: kHufDictSyms symbol values per task
     std::vector<uint16_t> huf_pool;      // decode tables, (len << 8 | symbol)
     // raw / RLE
     std::vector<CopyTask> copies;

@@ -74,6 +74,34 @@ def build_cases(scale=1):
     add("huge_nseq_no_names", nw.write_naf(huge, number_of_sequences=(1 << 64) - 1, ids=False, comments=False), _limit=6)
     add("title_bad_utf8", nw.write_naf(huge, title=b"caf\xe9 \xff"))              # from_utf8 fails: Nom(MapRes), parser.rs:133-137
 
+    # ---- Huffman table formats of k_huf_decode (plan.h: HufTblKind) x segment-aware variant -------------------------
+    # several trees with a small joint alphabet -> dictionary tables; rare IUPAC codes -> escape sub-tables; a few far
+    # matches -> blocks with a handful of sequences, whose literals go to their final positions segment by segment
+    def skewed(n, probs, extra="", pe=0.0):
+        t = rng.choice(list("ACGT"), n, p=probs)
+        if pe:
+            k = rng.random(n) < pe
+            t[k] = rng.choice(list(extra), int(k.sum()))
+        return "".join(t)
+    parts = []
+    for i in range(4 + 2 * scale):
+        p = np.array([0.1 + 0.1 * (i % 6), 0.4 - 0.05 * (i % 6), 0.3 - 0.03 * (i % 6), 0])
+        p[3] = 1 - p[:3].sum()
+        parts.append(skewed(262144 + i * 7, p, "NRY", 0.0015))
+    sk = "".join(parts)
+    sk = sk[:900000] + sk[1000:1500] + sk[900000:] + sk[5000:5300]
+    add("dna_skewed_blocks_dict_seg", nw.write_naf([{"id": "a", "sequence": sk}, {"id": "b", "sequence": sk[77:77 + 151]}], level=1))
+    # two dozen rare symbols with codes longer than the table index: an escape in almost every round of a lane (a round
+    # that resolves one must still produce no more than the row holds)
+    dense = "".join(skewed(262144 + i, np.array([0.4 - 0.1 * i, 0.2, 0.1 + 0.1 * i, 0.3]), "NRY", 0.012) for i in range(3))
+    add("dna_dense_escapes_dict", nw.write_naf([{"id": "e", "sequence": dense}], level=1))
+    # every IUPAC code in use: more than 64 byte values between the trees -> compact tables
+    add("dna_multi_tree_compact", nw.write_naf(make_records(rng, [700001 * scale], iupac=0.05), level=1))
+    # text with ~40 symbols, several blocks: dictionary tables without the ASCII expansion
+    qa = list("!\"#$%&'()*+,-./0123456789:;<=>?@ABCDEFGHIJ")
+    qtext = "".join(rng.choice(qa, 500000 * scale, p=np.r_[np.full(10, 0.002), np.full(32, (1 - 0.02) / 32)]))
+    add("text_multi_tree_dict", nw.write_naf([{"id": "q", "sequence": qtext}], sequence_type="text", level=1))
+
     # ---- mask ------------------------------------------------------------------------------
     recs = make_records(rng, [1550, 1800, 0, 700, 255, 510, 1000])
     total = sum(len(r["sequence"]) for r in recs)

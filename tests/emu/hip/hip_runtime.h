@@ -88,6 +88,12 @@ inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t shi
     return static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | lo) >> (shift & 31));
 }
 // v_perm_b32: byte select from {hi (bytes 4-7), lo (bytes 0-3)}
+// v_bfe_u32: `width` bits of v from bit `offset`
+inline uint32_t __builtin_amdgcn_ubfe(uint32_t v, uint32_t offset, uint32_t width) {
+    offset &= 31u;
+    width &= 31u;
+    return width ? (v >> offset) & ((1u << width) - 1u) : 0u;
+}
 inline uint32_t __builtin_amdgcn_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
     const uint64_t src = (static_cast<uint64_t>(hi) << 32) | lo;
     uint32_t r = 0;

@@ -14,8 +14,9 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if kern in r["Kernel_Name"]:
-            acc[r["Kernel_Name"].split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-res = {k: {c: {"avg": round(sum(v) / len(v)), "launches": len(v)} for c, v in sorted(cs.items())} for k, cs in acc.items()}
+            name = r["Kernel_Name"].replace("void nafgpu::(anonymous namespace)::", "").replace("nafgpu::(anonymous namespace)::", "")
+            acc[name.split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {k: {c: {"avg": round(sum(v) / len(v)), "max": round(max(v)), "launches": len(v)} for c, v in sorted(cs.items())} for k, cs in acc.items()}
 print(tag, json.dumps(res))
 json.dump(res, open("gpurun_out/pmc_%s.json" % tag, "w"), indent=1)
 PY

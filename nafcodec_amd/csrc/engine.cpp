@@ -172,9 +172,7 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
               d_meta_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(SeqMeta) + 16) &&
               d_rep_final_.alloc(n_seq_blocks_ * 12 + 16) && d_rep_init_.alloc(n_seq_blocks_ * 12 + 16) &&
               d_rep_scratch_.alloc((n_seq_blocks_ / 64 + 1) * 24 + 16) &&
-              d_lz_index_.alloc(n_seq_blocks_ && plan_.n_sequences < 0xFFFFFFFFull ? ((static_cast<size_t>(expect_size) >> 7) + 2) * 4 : 0) &&
-              d_blk_pending_.alloc(n_seq_blocks_ * 4 + 16) &&
-              d_roff_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(uint32_t) + 16) && d_counters_.alloc(64);
+              d_blk_pending_.alloc(n_seq_blocks_ * 4 + 16) && d_counters_.alloc(64);
     if (!ok) return Failure::make(NAFGPU_E_DEVICE, "out of device memory while preparing a section");
     // the host vectors were consumed by asynchronous copies: keep them until the stream drains
     if (!hip_ok(hipStreamSynchronize(stream))) return Failure::make(NAFGPU_E_DEVICE, "upload of task lists failed");
@@ -250,96 +248,51 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
         la.blocks = d_seq_blocks_.as<SeqBlock>();
         la.n_blocks = static_cast<uint32_t>(n_seq_blocks_);
         la.n_sequences = plan_.n_sequences;
-        la.mean_ml = plan_.n_sequences ? static_cast<uint32_t>((expect_ > plan_.known_out ? expect_ - plan_.known_out : 0) / plan_.n_sequences) : 0;   // known_out = everything but the match bytes
+        la.n_elems = expect_;
         la.seqs = d_seqs_.as<Seq>();
         la.lit = d_lit_.bytes();
         la.blk_base = d_blk_base_.as<uint64_t>();
         la.rep_final = d_rep_final_.as<uint32_t>();
         la.rep_init = d_rep_init_.as<uint32_t>();
         la.rep_scratch = d_rep_scratch_.as<uint32_t>();
-        // the pending lists are an accelerator: without memory for them every pass walks the blocks
-        const size_t list_bytes = static_cast<size_t>(plan_.n_sequences) * sizeof(uint64_t) + 16;
-        const bool lists = plan_.n_sequences < (1ull << 40) && n_seq_blocks_ < (1ull << 24) && d_lz_list_[0].alloc(list_bytes) &&
-                           d_lz_list_[1].alloc(list_bytes);
-        la.plist[0] = lists ? d_lz_list_[0].as<uint64_t>() : nullptr;
-        la.plist[1] = lists ? d_lz_list_[1].as<uint64_t>() : nullptr;
-        la.cidx = plan_.n_sequences < 0xFFFFFFFFull ? d_lz_index_.as<uint32_t>() : nullptr;
-        la.n_idx_chunks = (static_cast<uint64_t>(expect_) >> 7) + 2;
         la.meta = d_meta_.as<SeqMeta>();
         la.blk_pending = d_blk_pending_.as<uint32_t>();
         la.out = out_base;
         la.t_char = t_char_;
         la.status = status;
-        la.roff = d_roff_.as<uint32_t>();
         la.counters = d_counters_.as<unsigned long long>();
-        launch_lz_execute(stream, la, ascii);
-        // What the fixed number of passes could not resolve (dependency chains as long as the frame:
-        // quality strings, tandem repeats).  The host needs the count to size the scratch memory.
-        unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        uint32_t st_now = 1;
-        lz_residue_ = 0;
-        if (hip_ok(hipMemcpyAsync(cnt, la.counters, sizeof cnt, hipMemcpyDeviceToHost, stream)) &&
-            hip_ok(hipMemcpyAsync(&st_now, status, sizeof st_now, hipMemcpyDeviceToHost, stream)) &&
-            hip_ok(hipStreamSynchronize(stream)) && st_now == 0 && cnt[0] > 0) {   // a flagged section stays untouched
-            const uint64_t n_pending = cnt[0];
-            lz_residue_ = n_pending;
-            uint32_t *changed = reinterpret_cast<uint32_t *>(la.counters + 2);
-            bool done = false;
-            // the passes' last pending list is exactly what is left (counters[3] names it); without the lists: collect from the flags
-            const uint64_t *plist = nullptr;
-            if (la.plist[0] && la.plist[1] && cnt[3] < 2 && cnt[4 + cnt[3]] == n_pending) plist = la.plist[cnt[3]];
-            // A few pending LONG matches are a handful of chains of whole-block runs (a Length section of equal
-            // reads is one run per block, each waiting for the block before it): walking on pass by pass costs
-            // microseconds per link, pointer jumping would sweep their millions of elements a dozen times.
-            bool few = false;
-            // (long matches only: a chain of short ones is one link per pass -- thousands of launches -- while
-            //  pointer jumping sweeps its few elements in a dozen)
-            if (plist && n_pending <= lz_few_pending() && la.mean_ml >= 1024) {
-                uint32_t next_pass = lz_passes_done() + 1;
-                for (int batch = 0; batch < 256 && cnt[0] > 0 && cnt[0] <= lz_few_pending(); batch++) {
-                    const unsigned long long before = cnt[0];
-                    launch_lz_more_passes(stream, la, ascii, static_cast<uint32_t>(cnt[3]), next_pass, 64);
-                    next_pass += 64;
-                    if (!hip_ok(hipMemcpyAsync(cnt, la.counters, sizeof cnt, hipMemcpyDeviceToHost, stream)) ||
-                        !hip_ok(hipStreamSynchronize(stream)))
-                        break;
-                    if (cnt[0] == before) break;                   // no progress: leave it to the stage below
-                }
-                few = cnt[0] == 0;
-                lz_residue_ = n_pending;
-                plist = (cnt[3] < 2 && cnt[4 + cnt[3]] == cnt[0]) ? la.plist[cnt[3]] : nullptr;
-            }
-            const uint64_t n_left = cnt[0];
-            if (!few && n_left > 0 && (plist || d_pj_list_.alloc(n_left * sizeof(uint64_t))) &&
-                d_pj_dist_.alloc(static_cast<size_t>(expect_) * sizeof(uint32_t) + 16) && d_pj_stamp_.alloc(n_left + 16)) {
-                uint32_t *D = d_pj_dist_.as<uint32_t>();
-                uint8_t *stamp = d_pj_stamp_.bytes();
-                (void)hipMemsetAsync(D, 0, static_cast<size_t>(expect_) * sizeof(uint32_t), stream);
-                (void)hipMemsetAsync(stamp, 0, n_left, stream);
-                if (!plist) {
-                    launch_pj_collect(stream, la, d_pj_list_.as<uint64_t>());
-                    plist = d_pj_list_.as<uint64_t>();
-                }
-                launch_pj_step(stream, la, ascii, plist, n_left, D, 0, changed, stamp, 0);
-                for (int it = 0; it < 64 && !done; it++) {           // chain length halves per step
-                    (void)hipMemsetAsync(changed, 0, 2 * sizeof(uint32_t), stream);
-                    launch_pj_step(stream, la, ascii, plist, n_left, D, 1, changed, stamp, static_cast<uint32_t>(it) + 1);
-                    uint32_t ch[2] = {1, 0};                         // [0] a distance grew, [1] a distance could not grow (32-bit limit)
-                    if (!hip_ok(hipMemcpyAsync(ch, changed, sizeof ch, hipMemcpyDeviceToHost, stream)) ||
-                        !hip_ok(hipStreamSynchronize(stream)))
-                        break;
-                    // no change but an element still points at a pending one (a chain longer than 2^32 elements):
-                    // copying now would read bytes that are not final -- leave it to the frame-order fallback
-                    if (ch[0] == 0 && ch[1] != 0) break;
-                    done = ch[0] == 0;
-                }
-                if (done) launch_pj_step(stream, la, ascii, plist, n_left, D, 2, changed, stamp, 0);
-            }
-            if (!done && !few) {                                         // no scratch memory / no convergence: frame order
-                if (std::getenv("NAFGPU_DEBUG_PLAN")) std::fprintf(stderr, "[nafgpu] LZ residue of %llu matches finished in frame order\n", static_cast<unsigned long long>(n_left));
-                launch_lz_ordered(stream, la, ascii);
+        // Dense or sparse?  Where the matches are a good part of the output (level-3 DNA, quality strings) the frame is
+        // swept element by element (one word of scratch per output element, allocated on the first run and kept);
+        // a handful of matches in gigabytes of literals (real genomes at level 1) are visited one by one.
+        const uint64_t match_elems = expect_ > plan_.known_out ? expect_ - plan_.known_out : 0;   // known_out = everything but the match bytes
+        const char *force = std::getenv("NAFGPU_LZ_MODE");                                      // tests: "dense" / "sparse"
+        bool dense = plan_.n_sequences >= 4096 && match_elems * 2 >= expect_;                      // (level-3 DNA, a quarter of it matches at random
+                                                                                                   //  distances, is faster match by match: 38 against 46 ms)
+        if (force) dense = force[0] == 'd';
+        lz_dense_ = false;
+        if (dense && d_pj_dist_.alloc_items(expect_, sizeof(uint32_t), 64) && d_pj_tiles_.alloc_items(lz_pj_tiles(expect_), sizeof(uint32_t), 64)) {
+            la.pj_dist = d_pj_dist_.as<uint32_t>();
+            la.pj_tiles = d_pj_tiles_.as<uint32_t>();
+            lz_dense_ = true;
+        } else {
+            // the pending lists are an accelerator: without memory for them every pass walks the blocks
+            const bool lists = plan_.n_sequences < (1ull << 40) && n_seq_blocks_ < (1ull << 24) &&
+                               d_lz_list_[0].alloc_items(plan_.n_sequences, sizeof(uint64_t), 16) &&
+                               d_lz_list_[1].alloc_items(plan_.n_sequences, sizeof(uint64_t), 16);
+            la.plist[0] = lists ? d_lz_list_[0].as<uint64_t>() : nullptr;
+            la.plist[1] = lists ? d_lz_list_[1].as<uint64_t>() : nullptr;
+            la.roff = d_roff_.alloc_items(plan_.n_sequences, sizeof(uint32_t), 16) ? d_roff_.as<uint32_t>() : nullptr;
+            // the index of "first sequence at or after every 128th element" pays when sequences are everywhere; a few
+            // thousand sequences in gigabytes of output are found by binary search
+            const bool index = plan_.n_sequences < 0xFFFFFFFFull && plan_.n_sequences * 1024 >= expect_ &&
+                               d_lz_index_.alloc_items((expect_ >> 7) + 2, sizeof(uint32_t));
+            la.cidx = index ? d_lz_index_.as<uint32_t>() : nullptr;
+            la.n_idx_chunks = (static_cast<uint64_t>(expect_) >> 7) + 2;
+            if (!la.roff) {                                    // (cannot happen short of a device out of memory: flag the section)
+                (void)hipMemsetAsync(status, 0xFF, 4, stream);
             }
         }
+        if (la.pj_dist || la.roff) launch_lz_execute(stream, la, ascii);
         if (timer) timer->end(stream);
     }
 }
@@ -350,6 +303,12 @@ Failure SectionJob::check(hipStream_t stream) {
     if (!hip_ok(hipMemcpyAsync(st, d_status_.bytes(), sizeof st, hipMemcpyDeviceToHost, stream)) ||
         !hip_ok(hipStreamSynchronize(stream)))
         return Failure::make(NAFGPU_E_DEVICE, "device status read-back failed");
+    lz_residue_ = 0;
+    if (n_seq_blocks_) {                                       // statistics: matches the launched passes did not finish
+        unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hip_ok(hipMemcpyAsync(cnt, d_counters_.bytes(), sizeof cnt, hipMemcpyDeviceToHost, stream)) && hip_ok(hipStreamSynchronize(stream)))
+            lz_residue_ = lz_dense_ ? plan_.n_sequences : cnt[1];
+    }
     if (st[0] == kStInternal)
         return Failure::io(NAFGPU_IO_INVALID_DATA, std::string(status_text(st[0])) + " (detail " + std::to_string(st[1]) + ")");
     if (st[0] != 0) return Failure::io(NAFGPU_IO_INVALID_DATA, status_text(st[0]));

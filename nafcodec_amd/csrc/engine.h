@@ -127,7 +127,8 @@ private:
     DevBuf d_out_, d_lit_, d_seqs_, d_blk_size_, d_blk_base_, d_scan_tmp_, d_status_;
     DevBuf d_meta_, d_rep_final_, d_rep_init_, d_rep_scratch_, d_lz_index_, d_blk_pending_, d_roff_, d_counters_;
     DevBuf d_lz_list_[2];
-    DevBuf d_pj_list_, d_pj_dist_, d_pj_stamp_;   // pointer-jumping scratch, allocated only when the passes leave a residue
+    DevBuf d_pj_dist_, d_pj_tiles_;               // dense LZ sections: one word per output element + one per tile (allocated on first use, kept)
+    bool lz_dense_ = false;
     DevBuf d_streams_, d_tasks_, d_tbl_copies_, d_pool_, d_dicts_, d_copies_, d_seq_blocks_, d_cells_;
 };
 

@@ -75,45 +75,38 @@ void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *ta
                        const uint64_t *blk_base, uint8_t *out, uint8_t *lit, const SeqBlock *seq_blocks, const Seq *seqs,
                        const uint8_t *dicts, bool ascii, uint32_t t_char, uint32_t *status);
 
-// K4: LZ77 sequence execution: repeat-offset chain, parallel literal scatter, multi-pass match
-// resolution over all blocks, ordered fallback
+// K4: LZ77 sequence execution: repeat-offset chain, parallel literal scatter, then -- all enqueued at once, no host
+// round trip: every stage returns at once when the one before it left nothing --
+//   dense sections (pj_dist != null: matches are a good part of the output): every element learns the distance to the
+//     element it copies, then the frame is swept until every element is final (pointer jumping, k_pj_sweep);
+//   sparse sections: match passes over the list of what is still pending, one workgroup for the last few;
+//   a frame-order walk for whatever neither resolves (chains the distances cannot express / thousands of links deep).
 struct LzArgs {
     const SeqBlock *blocks;
     uint32_t n_blocks;
     uint64_t n_sequences;
-    uint32_t mean_ml;            // mean match length of the section (lanes per match in the pointer-jumping steps)
+    uint64_t n_elems;            // output elements of the section (bytes; packed bytes when the output is expanded to ASCII)
     const Seq *seqs;
     const uint8_t *lit;
     const uint64_t *blk_base;
     const uint32_t *rep_final;   // 3 per block, from k_seq_decode
     uint32_t *rep_init;          // 3 per block
     uint32_t *rep_scratch;       // 6 words per chunk of 64 blocks (k_rep_partial / k_rep_scan)
-    uint32_t *cidx;              // sequence index per 128 output elements (null: plain binary search)
+    uint32_t *cidx;              // sparse: sequence index per 128 output elements (null: plain binary search)
     uint64_t n_idx_chunks;       // entries of cidx
     SeqMeta *meta;               // per sequence: output position and length of its match, pass that completed it (0 = pending)
     uint32_t *blk_pending;       // per block: matches still pending
-    uint32_t *roff;              // per sequence: resolved offset of a match that is still pending
-    uint64_t *plist[2];          // two lists of pending matches (n_sequences entries each; null: block-wise passes only)
-    unsigned long long *counters;// [0] matches still pending after the passes, [1] pointer-jumping list length, [2] its flag, [4] [5] pending-list lengths
+    uint32_t *roff;              // sparse: per sequence, resolved offset of a match that is still pending
+    uint64_t *plist[2];          // sparse: two lists of pending matches (n_sequences entries each; null: block-wise passes only)
+    uint32_t *pj_dist;           // dense: D, one word per output element (n_elems, 16-byte aligned)
+    uint32_t *pj_tiles;          // dense: pending elements per tile of 2048 (lz_pj_tiles(n_elems) words)
+    unsigned long long *counters;// 8 words: [0] matches still pending (sparse), [1] matches left to the one-workgroup stage, [4..6] stage counters
     uint8_t *out;
     uint32_t t_char;
     uint32_t *status;
 };
-// rep chain + literal scatter + the fixed number of match passes (asynchronous)
+uint64_t lz_pj_tiles(uint64_t n_elems);
 void launch_lz_execute(hipStream_t stream, const LzArgs &args, bool ascii);
-// a short pending list (<= lz_few_pending() matches: a few long chains of long matches) is walked on, `n` more passes
-// at a time: cur = counters[3] (list that holds what is pending), first_pass = number of the next pass
-uint32_t lz_passes_done();
-uint32_t lz_few_pending();
-void launch_lz_more_passes(hipStream_t stream, const LzArgs &args, bool ascii, uint32_t cur, uint32_t first_pass, uint32_t n);
-// what the passes left pending (args.counters[0] != 0):
-//   pointer jumping: collect the pending list, then op 0 (init D), op 1 (jump, repeat while *changed), op 2 (copy)
-void launch_pj_collect(hipStream_t stream, const LzArgs &args, uint64_t *list);
-// stamp: one byte per list entry (zeroed before the first jump step); step = 1, 2, ... for the jump steps
-void launch_pj_step(hipStream_t stream, const LzArgs &args, bool ascii, const uint64_t *list, uint64_t n_list, uint32_t *D,
-                    int op, uint32_t *changed, uint8_t *stamp, uint32_t step);
-//   or, without scratch memory for D: one workgroup in frame order
-void launch_lz_ordered(hipStream_t stream, const LzArgs &args, bool ascii);
 
 // K5: 4-bit -> IUPAC ASCII; t_char = 'T' (DNA) or 'U' (RNA)
 void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed, uint8_t *ascii, uint64_t n_bases,

@@ -1364,8 +1364,8 @@ __device__ inline void unpack_dword(uint32_t w, uint32_t t0, uint32_t t1, uint32
 // match of `ml` packed bytes at distance `off` copies ml 16-bit elements at distance off, and
 // literals are expanded while they are scattered.  The ASCII buffer itself is the LZ window.
 constexpr uint32_t kLzShort = 48;        // runs up to this many elements are copied by their own thread
-constexpr uint32_t kLzFewPending = 65536;   // lists this short keep being walked pass by pass (launch_lz_more_passes), never pointer-jumped
-constexpr uint32_t kLzPasses = 64;       // at most; the first walks every block, the others the list of what is still pending
+constexpr uint32_t kLzPasses = 24;       // launched passes: the first walks every block, the others the list of what is still pending;
+                                         // what they leave goes to ONE workgroup (k_lz_finish_small), then to the frame-order walk
 
 __device__ inline uint32_t rep_resolve(uint32_t tok, const uint32_t *init, bool *bad) {
     if (!(tok & kRepToken)) return tok;
@@ -1570,6 +1570,31 @@ __global__ __launch_bounds__(256) void k_lz_literals(const SeqBlock *__restrict_
         for (uint32_t k = tid; k < sb.lit_size - lused; k += 256) put(out + oend + k, blit[lused + k]);
 }
 
+// One match copied by `nthr` threads (this one is number `me`): d[k] = d[k - off] for k < ml.  A match that does not
+// reach into itself (off >= ml) is a plain copy: 16-byte aligned stores from unaligned 16-byte loads between a scalar
+// head and tail; one that does is periodic with period off (a run, in quality strings and homopolymers).
+template <class Elem>
+__device__ inline void lz_copy_match(Elem *d, uint32_t ml, uint32_t off, uint32_t me, uint32_t nthr) {
+    const Elem *s = d - off;
+    constexpr uint32_t kPer = 16 / sizeof(Elem);
+    if (off >= ml && ml >= 4 * kPer) {
+        const uint32_t mis = static_cast<uint32_t>((16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15) / sizeof(Elem);
+        const uint32_t head = mis < ml ? mis : ml;
+        const uint32_t n_vec = (ml - head) / kPer, tail0 = head + n_vec * kPer;
+        for (uint32_t k = me; k < head; k += nthr) d[k] = s[k];
+        for (uint32_t k = tail0 + me; k < ml; k += nthr) d[k] = s[k];
+        for (uint32_t v = me; v < n_vec; v += nthr) {
+            uint4 w;
+            __builtin_memcpy(&w, s + head + v * kPer, 16);
+            *reinterpret_cast<uint4 *>(d + head + v * kPer) = w;
+        }
+    } else if (off >= ml) {
+        for (uint32_t k = me; k < ml; k += nthr) d[k] = s[k];
+    } else {
+        for (uint32_t k = me; k < ml; k += nthr) d[k] = s[k % off];
+    }
+}
+
 // cidx[c] = first sequence whose match starts at or after output element c << kLzIdxShift: where the
 // search for "who wrote this source range" starts (one load instead of a binary search over all
 // sequences per pending match and pass)
@@ -1691,13 +1716,7 @@ __global__ __launch_bounds__(256) void k_lz_match_pass(const SeqBlock *__restric
                 const Seq q = seqs[gi];
                 bool bad = false;
                 const uint32_t off = rep_resolve(q.off, init, &bad);
-                Elem *d = out + meta[gi].pos;
-                const Elem *s = d - off;
-                if (off >= q.ml) {
-                    for (uint32_t k = tid; k < q.ml; k += 256) d[k] = s[k];
-                } else {
-                    for (uint32_t k = tid; k < q.ml; k += 256) d[k] = s[k % off];   // overlapping: periodic
-                }
+                lz_copy_match<Elem>(out + meta[gi].pos, q.ml, off, tid, 256);
                 if (tid == 0) meta[gi].flag = pass;
             }
             __syncthreads();
@@ -1712,32 +1731,22 @@ __global__ __launch_bounds__(256) void k_lz_match_pass(const SeqBlock *__restric
     }
 }
 
-// Between two list passes: empty the list the next pass appends to, and stop the passes (counters[6])
-// once nothing is pending or a pass has resolved less than 3 % of what it was given.  A list pass
-// costs what is pending, so chains a few dozen links deep (quality strings) are cheaper to walk link
-// by link than to hand to the pointer-jumping stage, which is for chains as long as the frame.
-__global__ void k_lz_pass_ctl(unsigned long long *counters, uint32_t in, uint32_t out, uint32_t pass) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    if (counters[6]) return;                               // stopped earlier: counters[3] names the list that holds what is pending
-    const unsigned long long now = counters[4 + in];       // pending before the coming pass
-    const unsigned long long before = counters[7];         // pending before the previous pass
-    counters[3] = in;                                      // if the passes stop here, list `in` is the pending list
-    if (now > kLzFewPending && pass >= 3 && now * 200 > before * 199) counters[6] = 1;   // (a short list is cheap to walk: keep going)
-    if (now == 0) counters[6] = 1;
-    counters[7] = now;
-    if (!counters[6]) counters[4 + out] = 0;
-}
-
 // Passes after the first work from the list of matches that are still pending (entry = seq-block
 // index << 40 | sequence index) instead of re-reading every sequence of every unfinished block: a
-// pass costs what is left, not what there was.  Survivors go to the next pass's list.
+// pass costs what is left, not what there was.  Survivors go to the next pass's list.  No kernel
+// in between: pass k reads list k & 1 (its length in lcount[k % 3]), appends to the other list
+// (length lcount[(k + 1) % 3]) and clears lcount[(k + 2) % 3], which pass k + 1 appends to; a pass
+// whose input is empty returns at once, so the host enqueues a fixed number of them.
 template <bool ASCII>
-__global__ __launch_bounds__(256) void k_lz_match_list(const uint64_t *__restrict__ lin, const unsigned long long *__restrict__ nin,
-                                                       uint64_t *lout, unsigned long long *nout, const Seq *__restrict__ seqs,
+__global__ __launch_bounds__(256) void k_lz_match_list(const uint64_t *__restrict__ lin, uint64_t *lout, unsigned long long *lcount,
+                                                       const Seq *__restrict__ seqs,
                                                        SeqMeta *meta, const uint32_t *__restrict__ cidx,
                                                        uint32_t *blk_pending, const uint32_t *__restrict__ roff,
-                                                       unsigned long long *remaining, const unsigned long long *stop,
+                                                       unsigned long long *remaining,
                                                        uint8_t *out_bytes, uint32_t pass, const uint32_t *status) {
+    const unsigned long long *nin = lcount + pass % 3u;
+    unsigned long long *nout = lcount + (pass + 1u) % 3u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) lcount[(pass + 2u) % 3u] = 0;
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
     __shared__ uint32_t s_long[256];
@@ -1745,7 +1754,7 @@ __global__ __launch_bounds__(256) void k_lz_match_list(const uint64_t *__restric
     __shared__ uint32_t s_nlong, s_ndone, s_abort, s_npend;
     __shared__ unsigned long long s_pbase;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) s_abort = status[0] | static_cast<uint32_t>(stop[0]);
+    if (tid == 0) s_abort = status[0];
     __syncthreads();
     if (s_abort) return;
     const unsigned long long n = *nin;
@@ -1790,13 +1799,7 @@ __global__ __launch_bounds__(256) void k_lz_match_list(const uint64_t *__restric
             const uint64_t gi = e & ((1ull << 40) - 1ull);
             const Seq q = seqs[gi];
             const uint32_t off = roff[gi];
-            Elem *d = out + meta[gi].pos;
-            const Elem *sp = d - off;
-            if (off >= q.ml) {
-                for (uint32_t k = tid; k < q.ml; k += 256) d[k] = sp[k];
-            } else {
-                for (uint32_t k = tid; k < q.ml; k += 256) d[k] = sp[k % off];   // overlapping: periodic
-            }
+            lz_copy_match<Elem>(out + meta[gi].pos, q.ml, off, tid, 256);
             if (tid == 0) {
                 meta[gi].flag = pass;
                 atomicSub(&blk_pending[e >> 40], 1u);
@@ -1812,68 +1815,233 @@ __global__ __launch_bounds__(256) void k_lz_match_list(const uint64_t *__restric
     }
 }
 
-// ---- pointer jumping for what the passes leave behind --------------------------------------
-// Dense short-offset matches (quality strings, tandem repeats) form dependency chains as long as
-// the frame, which no fixed number of passes resolves.  For those, every element p of a pending
-// match gets D[p] = distance to an element it is a copy of (initially the match offset; 0 for every
-// final element).  One jump step replaces D[p] by D[p] + D[p - D[p]] -- the chain above p halves --
-// so after ~log2(chain length) steps every pending element points at a final one and is copied.
-__global__ __launch_bounds__(256) void k_pj_collect(const SeqMeta *__restrict__ meta, uint64_t n_sequences, uint64_t *list,
-                                                    unsigned long long *count) {
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-    for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n_sequences; g += stride)
-        if (meta[g].flag == 0) list[atomicAdd(count, 1ull)] = g;
-}
-
-enum PjOp { kPjInit = 0, kPjJump = 1, kPjCopy = 2 };
-
-template <bool ASCII, int OP, int GL>
-__global__ __launch_bounds__(256) void k_pj_step(const uint64_t *__restrict__ list, uint64_t n_list, const Seq *__restrict__ seqs,
-                                                 const SeqMeta *__restrict__ meta, const uint32_t *__restrict__ roff, uint32_t *D,
-                                                 uint8_t *out_bytes, uint32_t *changed, uint8_t *stamp, uint32_t step,
-                                                 uint32_t max_dist) {
+// ---- what the list passes leave behind, sparse sections: one workgroup walks on ---------------
+// A handful of pending matches (a real genome's few far repeats; the Length section of equal reads:
+// one whole-block run per block, each copying from the block before) needs no launch per pass: ONE
+// workgroup keeps passing over the list until it is empty, or until a pass resolves less than an
+// eighth of it -- chains that deep are left to the frame-order walk behind it (k_lz_matches_ordered,
+// which returns at once when nothing is pending).
+template <bool ASCII>
+__global__ __launch_bounds__(1024) void k_lz_finish_small(uint64_t *l0, uint64_t *l1, unsigned long long *lcount, uint32_t first_pass,
+                                                          const Seq *__restrict__ seqs, SeqMeta *meta, const uint32_t *__restrict__ cidx,
+                                                          uint32_t *blk_pending, const uint32_t *__restrict__ roff,
+                                                          unsigned long long *counters, uint8_t *out_bytes, const uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
+    __shared__ unsigned long long s_n, s_nout;
+    __shared__ uint64_t s_long[1024];
+    __shared__ uint32_t s_done, s_abort, s_nlong;
     const uint32_t tid = threadIdx.x;
-    bool any_change = false;
-    bool stuck = false;                  // an element still points at a pending one, but its distance would not fit 32 bits
-    bool unresolved = false;             // this lane saw an element whose source is still pending
-    auto element = [&](uint64_t p, uint32_t off) {
-        if (OP == kPjInit) {
-            D[p] = off;
-        } else if (OP == kPjJump) {
-            const uint32_t d = D[p];
-            const uint32_t da = D[p - d];
-            if (da != 0) unresolved = true;
-            if (da != 0 && static_cast<uint64_t>(d) + da <= max_dist) {
-                D[p] = d + da;
-                any_change = true;
-            } else if (da != 0) {
-                stuck = true;            // changed[1]: the host must not run the copy step (it falls back to frame order)
-            }
-        } else {
-            out[p] = out[p - D[p]];
-        }
-    };
-    // GL lanes per match (4, 8 or 16, by the section's mean match length): consecutive lanes on consecutive
-    // elements, 256 / GL matches per workgroup step; a long match is just more steps of its group
-    constexpr uint32_t kPer = 256 / GL;
-    const uint32_t grp = tid / GL, gl = tid % GL;
-    for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * kPer; base < n_list; base += static_cast<uint64_t>(gridDim.x) * kPer) {
-        if (base + grp >= n_list) continue;
-        // A match all of whose elements already point at final bytes never changes again: a jump step
-        // stamps the matches that still have an unresolved element, the next step skips the others
-        // (most chains are short; only the longest need all the steps).
-        if (OP == kPjJump && step > 1 && stamp[base + grp] != static_cast<uint8_t>(step - 1)) continue;
-        const uint64_t g = list[base + grp] & ((1ull << 40) - 1ull);   // a pending-list entry also carries its block index
-        const uint32_t ml = seqs[g].ml, off = roff[g];
-        const uint64_t mpos = meta[g].pos;
-        unresolved = false;
-        for (uint32_t k = gl; k < ml; k += GL) element(mpos + k, off);
-        if (OP == kPjJump && unresolved) stamp[base + grp] = static_cast<uint8_t>(step);   // same value from every lane that writes
+    if (tid == 0) {
+        s_abort = status[0];
+        s_n = lcount[first_pass % 3u];
+        counters[1] = s_n;                                 // statistics: matches the launched passes left over
     }
-    if (OP == kPjJump && any_change) changed[0] = 1;
-    if (OP == kPjJump && stuck) changed[1] = 1;
+    __syncthreads();
+    if (s_abort) return;
+    uint64_t *lin = (first_pass & 1u) ? l1 : l0, *lout = (first_pass & 1u) ? l0 : l1;
+    for (uint32_t pass = first_pass; s_n != 0; pass++) {
+        const unsigned long long n = s_n;
+        if (tid == 0) {
+            s_nout = 0;
+            s_done = 0;
+        }
+        __syncthreads();
+        for (unsigned long long base = 0; base < n; base += 1024) {
+            const unsigned long long i = base + tid;
+            if (tid == 0) s_nlong = 0;
+            __syncthreads();
+            if (i < n) {
+                const uint64_t ent = lin[i];
+                const uint64_t g = ent & ((1ull << 40) - 1ull);
+                const Seq q = seqs[g];
+                const uint32_t off = roff[g];
+                const uint64_t mpos = meta[g].pos;
+                const uint64_t src = mpos - off;
+                const uint64_t need_hi = src + q.ml < mpos ? src + q.ml : mpos;
+                if (lz_range_final(src, need_hi, meta, cidx, g, pass)) {
+                    if (q.ml <= kLzShort) {
+                        Elem *d = out + mpos;
+                        const Elem *sp = out + src;
+                        for (uint32_t k = 0; k < q.ml; k++) d[k] = sp[k];   // element-serial: overlap allowed
+                    } else {
+                        s_long[atomicAdd(&s_nlong, 1u)] = ent;   // long: the whole workgroup copies it below
+                    }
+                    meta[g].flag = pass;
+                    atomicSub(&blk_pending[ent >> 40], 1u);
+                    atomicAdd(&s_done, 1u);
+                } else {
+                    lout[atomicAdd(&s_nout, 1ull)] = ent;
+                }
+            }
+            __syncthreads();
+            const uint32_t nl = s_nlong;
+            for (uint32_t j = 0; j < nl; j++) {
+                const uint64_t g = s_long[j] & ((1ull << 40) - 1ull);
+                lz_copy_match<Elem>(out + meta[g].pos, seqs[g].ml, roff[g], tid, 1024);
+            }
+            __syncthreads();
+        }
+        __threadfence();                                   // this pass's bytes and stamps before the next pass reads them
+        __syncthreads();
+        const uint32_t done = s_done;
+        const unsigned long long left = s_nout;
+        __syncthreads();
+        if (tid == 0) {
+            atomicAdd(counters, ~static_cast<unsigned long long>(done) + 1ull);   // remaining -= done
+            s_n = done * 8ull >= n ? left : 0;             // slow progress: stop here, the frame-order walk finishes
+        }
+        uint64_t *t = lin;
+        lin = lout;
+        lout = t;
+        __syncthreads();
+    }
+}
+
+// ---- pointer jumping, dense sections -------------------------------------------------------
+// Where matches make up a good part of the output (level-3 DNA; quality strings, whose dense
+// short-offset matches chain through the whole frame) the matches are not visited one by one at
+// all.  Every output element p gets D[p] = distance to an element it is a copy of (k_pj_fill: the
+// match offset; 0 for literals, which are final), and the frame is SWEPT: an element whose source
+// is final takes its byte and becomes final; otherwise it points past its source,
+// D[p] += D[p - D[p]] -- the chain above it halves.  A sweep reads D sequentially, its gathers stay
+// inside the window, nothing but D and the output is touched (no per-match records), tiles without
+// pending elements cost one word, and after ~log2(longest chain) sweeps everything is final.  The
+// host enqueues a fixed number of sweeps; each returns at once when the one before left nothing.
+// "Final" must mean final BEFORE this launch (another workgroup may be writing the byte right now):
+// elements finalised by sweep s carry kPjFinal | s until a later sweep looks at them.
+constexpr uint32_t kPjTile = 2048;           // elements per tile (256 threads x 8)
+constexpr uint32_t kPjFinal = 0xFFFFFF00u;   // D >= kPjFinal: final, low byte = the sweep that made it so
+constexpr uint32_t kPjSweeps = 40;           // 2^40 > any chain; what is left after them goes to the frame-order walk
+
+template <bool ASCII>
+__global__ __launch_bounds__(256) void k_pj_fill(const SeqBlock *__restrict__ blocks, uint32_t n_blocks, const Seq *__restrict__ seqs,
+                                                 const uint32_t *__restrict__ rep_init, const uint64_t *__restrict__ blk_base,
+                                                 uint32_t *D, uint32_t *status) {
+    __shared__ uint64_t s_pos[256];
+    __shared__ uint32_t s_off[256];
+    __shared__ uint32_t s_pre[2][257];                     // element-count prefix sums (ping-pong for the scan)
+    __shared__ uint32_t s_abort;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_abort = status[0];
+    __syncthreads();
+    if (s_abort) return;
+    for (uint32_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const SeqBlock sb = blocks[b];
+        const uint64_t obase = blk_base[sb.blk], fstart = blk_base[sb.frame_first_blk];
+        const uint32_t init[3] = {rep_init[3 * b], rep_init[3 * b + 1], rep_init[3 * b + 2]};
+        for (uint32_t s0 = 0; s0 < sb.n_seq; s0 += 256) {
+            uint32_t ml = 0;
+            if (s0 + tid < sb.n_seq) {
+                const Seq q = seqs[sb.seq_first + s0 + tid];
+                bool bad = false;
+                const uint32_t off = rep_resolve(q.off, init, &bad);
+                const uint64_t mpos = obase + q.opos + q.ll;
+                if (bad || off > mpos - fstart || off >= kPjFinal) {   // reaches before the frame (corrupt) / beyond any legal window
+                    flag_error(status, kStBadOffset, sb.blk);
+                } else {
+                    ml = q.ml;
+                    s_pos[tid] = mpos;
+                    s_off[tid] = off;
+                }
+            }
+            __syncthreads();                               // previous round's readers are done (first round: nothing to wait for)
+            s_pre[0][tid + 1] = ml;
+            if (tid == 0) s_pre[0][0] = s_pre[1][0] = 0;
+            __syncthreads();
+            uint32_t cur = 0;
+            for (uint32_t d = 1; d < 256; d <<= 1) {       // inclusive scan of entries 1..256
+                const uint32_t v = s_pre[cur][tid + 1] + (tid >= d ? s_pre[cur][tid + 1 - d] : 0);
+                s_pre[cur ^ 1][tid + 1] = v;
+                cur ^= 1;
+                __syncthreads();
+            }
+            const uint32_t *pre = s_pre[cur];
+            const uint32_t total = pre[256];
+            for (uint32_t e = tid; e < total; e += 256) {  // consecutive threads on consecutive elements, whatever the match lengths
+                uint32_t lo = 0, hi = 256;                 // largest j with pre[j] <= e
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (pre[mid] <= e)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                D[s_pos[lo] + (e - pre[lo])] = s_off[lo];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <bool ASCII>
+__global__ __launch_bounds__(256) void k_pj_sweep(uint32_t *D, uint8_t *out_bytes, uint32_t *tile_pending, unsigned long long *pcount,
+                                                  uint64_t n_elems, uint32_t sweep, uint32_t max_dist, const uint32_t *status) {
+    using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
+    Elem *out = reinterpret_cast<Elem *>(out_bytes);
+    __shared__ uint32_t s_red[256];
+    __shared__ uint32_t s_skip;
+    const uint32_t tid = threadIdx.x;
+    // pcount[s % 3] = elements still pending after sweep s (pcount[0] != 0 before the first one)
+    const unsigned long long before = pcount[(sweep + 2u) % 3u];
+    if (blockIdx.x == 0 && tid == 0) {
+        pcount[(sweep + 1u) % 3u] = 0;
+        if (before == 0 || status[0] != 0) pcount[sweep % 3u] = 0;
+    }
+    if (before == 0 || status[0] != 0) return;
+    const uint32_t mark = kPjFinal | (sweep & 0xFFu);
+    const uint64_t n_tiles = (n_elems + kPjTile - 1) / kPjTile;
+    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        if (tid == 0) s_skip = sweep > 1 && tile_pending[t] == 0;
+        __syncthreads();
+        const bool skip = s_skip != 0;
+        __syncthreads();
+        if (skip) continue;
+        uint32_t remaining = 0;
+        const uint64_t p0 = t * kPjTile + tid * 4;
+#pragma unroll
+        for (uint32_t half = 0; half < 2; half++) {        // two runs of four consecutive elements per thread: 16-byte loads of D
+            const uint64_t p = p0 + half * (kPjTile / 2);
+            if (p >= n_elems) continue;
+            uint32_t v[4] = {0, 0, 0, 0};
+            const uint32_t n = n_elems - p < 4 ? static_cast<uint32_t>(n_elems - p) : 4u;
+            if (n == 4) {
+                const uint4 w = *reinterpret_cast<const uint4 *>(D + p);   // D is 16-byte aligned, p a multiple of 4
+                v[0] = w.x;
+                v[1] = w.y;
+                v[2] = w.z;
+                v[3] = w.w;
+            } else {
+                for (uint32_t k = 0; k < n; k++) v[k] = D[p + k];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                if (v[k] == 0 || v[k] >= kPjFinal) continue;         // literal / final already
+                const uint64_t q = p + k - v[k];
+                const uint32_t w = D[q];
+                if (w == 0 || (w >= kPjFinal && w != mark)) {        // the source was final before this sweep began
+                    out[p + k] = out[q];
+                    D[p + k] = mark;
+                } else if (w >= kPjFinal) {                          // became final during this sweep: its byte may not be visible yet
+                    remaining++;
+                } else {
+                    if (static_cast<uint64_t>(v[k]) + w < max_dist) D[p + k] = v[k] + w;   // (a distance that cannot grow waits for its source)
+                    remaining++;
+                }
+            }
+        }
+        s_red[tid] = remaining;
+        __syncthreads();
+        for (uint32_t d = 128; d > 0; d >>= 1) {
+            if (tid < d) s_red[tid] += s_red[tid + d];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            tile_pending[t] = s_red[0];
+            if (s_red[0]) atomicAdd(&pcount[sweep % 3u], static_cast<unsigned long long>(s_red[0]));
+        }
+        __syncthreads();
+    }
 }
 
 template <bool ASCII>
@@ -1881,14 +2049,14 @@ __global__ __launch_bounds__(256) void k_lz_matches_ordered(const SeqBlock *__re
                                                             const Seq *__restrict__ seqs, SeqMeta *meta,
                                                             const uint32_t *__restrict__ blk_pending,
                                                             const uint32_t *__restrict__ rep_init, const uint64_t *__restrict__ blk_base,
-                                                            uint8_t *out_bytes, uint32_t *status) {
+                                                            uint8_t *out_bytes, const unsigned long long *gate, uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
     __shared__ uint32_t s_abort, s_pending, s_n;
     __shared__ uint32_t s_idx[256], s_ml[256], s_off[256];
     __shared__ uint64_t s_mpos[256];
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) s_abort = status[0];
+    if (tid == 0) s_abort = status[0] != 0 || *gate == 0;  // gate: what the parallel stages left pending (0: nothing to do)
     __syncthreads();
     if (s_abort != 0) return;
     for (uint32_t b = 0; b < n_blocks; b++) {
@@ -1934,13 +2102,7 @@ __global__ __launch_bounds__(256) void k_lz_matches_ordered(const SeqBlock *__re
                 if (off == 0) {
                     flag_error(status, kStBadOffset, sb.blk);
                 } else {
-                    Elem *d = out + s_mpos[j];
-                    const Elem *s = d - off;
-                    if (off >= ml) {
-                        for (uint32_t k = tid; k < ml; k += 256) d[k] = s[k];
-                    } else {
-                        for (uint32_t k = tid; k < ml; k += 256) d[k] = s[k % off];
-                    }
+                    lz_copy_match<Elem>(out + s_mpos[j], ml, off, tid, 256);
                 }
                 __syncthreads();
             }
@@ -2287,6 +2449,14 @@ void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *ta
 #undef NAFGPU_LAUNCH_HUF
 }
 
+// largest distance a pointer-jumping element may hold (32-bit D, the top 256 values mark final elements);
+// NAFGPU_PJ_MAX_DIST lowers it so that a test can reach the "chain longer than D can express" fallback on a small input
+static uint32_t pj_max_dist() {
+    const char *e = std::getenv("NAFGPU_PJ_MAX_DIST");     // read per call: a test switches it inside one process
+    const uint32_t v = e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : kPjFinal;
+    return v < kPjFinal ? v : kPjFinal;
+}
+
 template <bool ASCII>
 static void lz_execute(hipStream_t stream, const LzArgs &a) {
     const uint32_t n_chunks = (a.n_blocks + kRepChunk - 1) / kRepChunk;
@@ -2298,127 +2468,69 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
                        chunk_init, a.rep_init, a.status);
     hipLaunchKernelGGL(k_lz_literals<ASCII>, dim3(a.n_blocks), dim3(256), 0, stream, a.blocks, a.seqs, a.lit, a.blk_base,
                        a.meta, a.blk_pending, a.out, a.t_char, a.status);
+    const uint32_t grid = a.n_blocks < 256u * 8u ? a.n_blocks : 256u * 8u;
+    if (a.pj_dist) {
+        // ---- dense: every element learns its source distance, then the frame is swept (see k_pj_sweep)
+        const uint32_t max_dist = pj_max_dist();
+        (void)hipMemsetAsync(a.pj_dist, 0, static_cast<size_t>(a.n_elems) * sizeof(uint32_t), stream);
+        hipLaunchKernelGGL(k_pj_fill<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.rep_init, a.blk_base,
+                           a.pj_dist, a.status);
+        uint64_t tiles = (a.n_elems + kPjTile - 1) / kPjTile;
+        if (tiles > 256u * 16u) tiles = 256u * 16u;
+        unsigned long long *pcount = a.counters + 4;       // [4..6]: pending elements, rotating (k_pj_sweep)
+        for (uint32_t sweep = 1; sweep <= kPjSweeps; sweep++)
+            hipLaunchKernelGGL(k_pj_sweep<ASCII>, dim3(static_cast<uint32_t>(tiles)), dim3(256), 0, stream, a.pj_dist, a.out,
+                               a.pj_tiles, pcount, a.n_elems, sweep, max_dist, a.status);
+        // anything still pending (a distance that would not fit 32 bits): frame order
+        hipLaunchKernelGGL(k_lz_matches_ordered<ASCII>, dim3(1), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.meta,
+                           a.blk_pending, a.rep_init, a.blk_base, a.out, pcount + kPjSweeps % 3u, a.status);
+        return;
+    }
+    // ---- sparse: matches one by one; pass 1 walks the blocks, the later ones the list of what is still pending
     if (a.cidx) {
         uint64_t ib = (a.n_idx_chunks + 255) / 256;
         if (ib > 256u * 16u) ib = 256u * 16u;
         hipLaunchKernelGGL(k_lz_index, dim3(static_cast<uint32_t>(ib)), dim3(256), 0, stream, a.meta, a.n_sequences, a.n_idx_chunks,
                            a.cidx, a.status);
     }
-    const uint32_t grid = a.n_blocks < 256u * 8u ? a.n_blocks : 256u * 8u;
     if (!a.plist[0] || !a.plist[1]) {                      // no memory for the pending lists: every pass walks the blocks
         for (uint32_t pass = 1; pass <= kLzPasses; pass++)
             hipLaunchKernelGGL(k_lz_match_pass<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.meta,
                                a.cidx, a.blk_pending, a.roff, a.counters, a.rep_init, a.blk_base, a.out, pass, nullptr,
                                nullptr, a.status);
-        return;
+    } else {
+        unsigned long long *lcount = a.counters + 4;       // [4..6]: lengths of the pending lists, rotating (k_lz_match_list)
+        hipLaunchKernelGGL(k_lz_match_pass<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.meta, a.cidx,
+                           a.blk_pending, a.roff, a.counters, a.rep_init, a.blk_base, a.out, 1u, a.plist[0], lcount + 2u, a.status);
+        uint64_t lgrid = (a.n_sequences + 255) / 256;
+        if (lgrid > 256u * 8u) lgrid = 256u * 8u;
+        for (uint32_t pass = 2; pass <= kLzPasses; pass++)   // pass k reads list k & 1 (its length in lcount[k % 3]): pass 1 wrote list 0 / lcount[2]
+            hipLaunchKernelGGL(k_lz_match_list<ASCII>, dim3(static_cast<uint32_t>(lgrid)), dim3(256), 0, stream, a.plist[pass & 1u],
+                               a.plist[(pass & 1u) ^ 1u], lcount, a.seqs, a.meta, a.cidx, a.blk_pending, a.roff, a.counters, a.out,
+                               pass, a.status);
+        hipLaunchKernelGGL(k_lz_finish_small<ASCII>, dim3(1), dim3(1024), 0, stream, a.plist[0], a.plist[1], lcount, kLzPasses + 1u,
+                           a.seqs, a.meta, a.cidx, a.blk_pending, a.roff, a.counters, a.out, a.status);
     }
-    unsigned long long *cnt = a.counters + 4;              // lengths of the two pending lists
-    hipLaunchKernelGGL(k_lz_match_pass<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.meta, a.cidx,
-                       a.blk_pending, a.roff, a.counters, a.rep_init, a.blk_base, a.out, 1u, a.plist[0], cnt + 0, a.status);
-    uint64_t lgrid = (a.n_sequences + 255) / 256;
-    if (lgrid > 256u * 8u) lgrid = 256u * 8u;
-    for (uint32_t pass = 2; pass <= kLzPasses; pass++) {
-        const uint32_t in = pass & 1u, ol = in ^ 1u;       // pass 2 reads list 0 and writes list 1, pass 3 the other way round
-        hipLaunchKernelGGL(k_lz_pass_ctl, dim3(1), dim3(1), 0, stream, a.counters, in, ol, pass);
-        hipLaunchKernelGGL(k_lz_match_list<ASCII>, dim3(static_cast<uint32_t>(lgrid)), dim3(256), 0, stream, a.plist[in], cnt + in,
-                           a.plist[ol], cnt + ol, a.seqs, a.meta, a.cidx,
-                           a.blk_pending, a.roff, a.counters, a.counters + 6, a.out, pass, a.status);
-    }
-    // ran to the end: the last pass's output list is the pending list (counters[3]); harmless when stopped earlier
-    hipLaunchKernelGGL(k_lz_pass_ctl, dim3(1), dim3(1), 0, stream, a.counters, (kLzPasses & 1u) ^ 1u, kLzPasses & 1u, kLzPasses + 1);
+    // deep chains of a sparse section: frame order (returns at once when nothing is pending)
+    hipLaunchKernelGGL(k_lz_matches_ordered<ASCII>, dim3(1), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.meta,
+                       a.blk_pending, a.rep_init, a.blk_base, a.out, a.counters, a.status);
 }
 
-template <bool ASCII>
-static void lz_more_passes(hipStream_t stream, const LzArgs &a, uint32_t cur, uint32_t first_pass, uint32_t n) {
-    unsigned long long *cnt = a.counters + 4;
-    uint64_t lgrid = (static_cast<uint64_t>(kLzFewPending) + 255) / 256;
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t in = (cur + i) & 1u, ol = in ^ 1u;
-        hipLaunchKernelGGL(k_lz_pass_ctl, dim3(1), dim3(1), 0, stream, a.counters, in, ol, first_pass + i);
-        hipLaunchKernelGGL(k_lz_match_list<ASCII>, dim3(static_cast<uint32_t>(lgrid)), dim3(256), 0, stream, a.plist[in], cnt + in,
-                           a.plist[ol], cnt + ol, a.seqs, a.meta, a.cidx, a.blk_pending, a.roff, a.counters, a.counters + 6, a.out,
-                           first_pass + i, a.status);
-    }
-    hipLaunchKernelGGL(k_lz_pass_ctl, dim3(1), dim3(1), 0, stream, a.counters, (cur + n) & 1u, ((cur + n) & 1u) ^ 1u, first_pass + n);
-}
-
-uint32_t lz_passes_done() { return kLzPasses; }
-// largest distance a pointer-jumping element may hold (32-bit D); NAFGPU_PJ_MAX_DIST lowers it so that a test can
-// reach the "chain longer than D can express" fallback on a small input
-static uint32_t pj_max_dist() {
-    const char *e = std::getenv("NAFGPU_PJ_MAX_DIST");     // read per call: a test switches it inside one process
-    return e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : 0xFFFFFFFFu;
-}
-uint32_t lz_few_pending() {                               // NAFGPU_LZ_FEW_PENDING=0 sends every residue to pointer jumping (tests)
-    const char *e = std::getenv("NAFGPU_LZ_FEW_PENDING");  // read per call: a test switches it inside one process
-    return e ? static_cast<uint32_t>(std::atoi(e)) : kLzFewPending;
-}
-
-void launch_lz_more_passes(hipStream_t stream, const LzArgs &a, bool ascii, uint32_t cur, uint32_t first_pass, uint32_t n) {
-    if (ascii)
-        lz_more_passes<true>(stream, a, cur, first_pass, n);
-    else
-        lz_more_passes<false>(stream, a, cur, first_pass, n);
-}
+uint64_t lz_pj_tiles(uint64_t n_elems) { return (n_elems + kPjTile - 1) / kPjTile; }
 
 void launch_lz_execute(hipStream_t stream, const LzArgs &a, bool ascii) {
     if (!a.n_blocks) return;
-    // remaining matches, pointer-jumping list length, [2] its `changed` flag, [4] [5] lengths of the two pending lists
-    static const unsigned long long zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    (void)hipMemcpyAsync(a.counters, zeros, sizeof zeros, hipMemcpyHostToDevice, stream);
-    (void)hipMemcpyAsync(a.counters, &a.n_sequences, sizeof(unsigned long long), hipMemcpyHostToDevice, stream);
+    // [0] matches still pending (sparse), [1] matches the launched passes left to the one-workgroup stage,
+    // [4..6] rotating counters of the stage in use (k_lz_match_list / k_pj_sweep)
+    static thread_local unsigned long long staged[8];      // (the copy is asynchronous: the source must outlive this call)
+    for (int i = 0; i < 8; i++) staged[i] = 0;
+    staged[0] = a.n_sequences;
+    if (a.pj_dist) staged[4] = 1;                          // "pending before the first sweep": anything but 0
+    (void)hipMemcpyAsync(a.counters, staged, sizeof staged, hipMemcpyHostToDevice, stream);
     if (ascii)
         lz_execute<true>(stream, a);
     else
         lz_execute<false>(stream, a);
-}
-
-void launch_lz_ordered(hipStream_t stream, const LzArgs &a, bool ascii) {
-    if (ascii)
-        hipLaunchKernelGGL(k_lz_matches_ordered<true>, dim3(1), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.meta,
-                           a.blk_pending, a.rep_init, a.blk_base, a.out, a.status);
-    else
-        hipLaunchKernelGGL(k_lz_matches_ordered<false>, dim3(1), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.meta,
-                           a.blk_pending, a.rep_init, a.blk_base, a.out, a.status);
-}
-
-void launch_pj_collect(hipStream_t stream, const LzArgs &a, uint64_t *list) {
-    hipLaunchKernelGGL(k_pj_collect, dim3(256 * 8), dim3(256), 0, stream, a.meta, a.n_sequences, list, a.counters + 1);
-}
-
-template <bool ASCII, int GL>
-static void pj_step_gl(hipStream_t stream, const LzArgs &a, const uint64_t *list, uint64_t n_list, uint32_t *D, int op,
-                       uint32_t *changed, uint8_t *stamp, uint32_t step) {
-    uint64_t blocks = (n_list * GL + 255) / 256;
-    if (blocks > 256u * 16u) blocks = 256u * 16u;
-    const dim3 grid(static_cast<uint32_t>(blocks));
-    const uint32_t max_dist = pj_max_dist();
-    if (op == kPjInit)
-        hipLaunchKernelGGL((k_pj_step<ASCII, kPjInit, GL>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed, stamp, step, max_dist);
-    else if (op == kPjJump)
-        hipLaunchKernelGGL((k_pj_step<ASCII, kPjJump, GL>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed, stamp, step, max_dist);
-    else
-        hipLaunchKernelGGL((k_pj_step<ASCII, kPjCopy, GL>), grid, dim3(256), 0, stream, list, n_list, a.seqs, a.meta, a.roff, D, a.out, changed, stamp, step, max_dist);
-}
-
-template <bool ASCII>
-static void pj_step(hipStream_t stream, const LzArgs &a, const uint64_t *list, uint64_t n_list, uint32_t *D, int op,
-                    uint32_t *changed, uint8_t *stamp, uint32_t step) {
-    if (a.mean_ml <= 5)
-        pj_step_gl<ASCII, 4>(stream, a, list, n_list, D, op, changed, stamp, step);
-    else if (a.mean_ml <= 12)
-        pj_step_gl<ASCII, 8>(stream, a, list, n_list, D, op, changed, stamp, step);
-    else
-        pj_step_gl<ASCII, 16>(stream, a, list, n_list, D, op, changed, stamp, step);
-}
-
-void launch_pj_step(hipStream_t stream, const LzArgs &a, bool ascii, const uint64_t *list, uint64_t n_list, uint32_t *D, int op,
-                    uint32_t *changed, uint8_t *stamp, uint32_t step) {
-    if (!n_list) return;
-    if (ascii)
-        pj_step<true>(stream, a, list, n_list, D, op, changed, stamp, step);
-    else
-        pj_step<false>(stream, a, list, n_list, D, op, changed, stamp, step);
 }
 
 void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed, uint8_t *ascii, uint64_t n_bases,

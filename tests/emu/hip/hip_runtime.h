@@ -46,6 +46,7 @@ inline void __syncthreads() { hipemu::sync_threads(); }
 int __syncthreads_or(int pred);
 // wave-level primitives: the harness runs one-wave workgroups as a block of fibers
 inline void __builtin_amdgcn_fence(int, const char *) {}
+inline void __threadfence() {}
 inline void __builtin_amdgcn_wave_barrier() { hipemu::sync_threads(); }
 inline int __any(int pred) { return __syncthreads_or(pred); }
 unsigned long long __ballot(int pred);

@@ -53,27 +53,31 @@ def test_fixtures_match_oracle(emu, name):
     assert cases.run_product(blob, {}, emu) == cases.run_oracle(blob, {})
 
 
-def test_pointer_jumping_stage_is_exercised(emu, all_cases, monkeypatch):
-    """Dense chains leave a residue after the passes.  A short residue is walked on pass by pass
-    (default), a long one is pointer-jumped; NAFGPU_LZ_FEW_PENDING=0 sends these small cases down the
-    pointer-jumping path too.  Both must agree with the oracle."""
+def test_lz_stages_dense_and_sparse(emu, all_cases, monkeypatch):
+    """Both ways of finishing LZ matches on the same inputs (NAFGPU_LZ_MODE forces one): the element sweeps of
+    dense sections (pointer jumping), and the list passes + one-workgroup stage + frame-order walk of sparse
+    ones.  Dense chains must leave the launched passes a residue (else this stopped covering the stages behind them)."""
     import io
     from nafcodec_amd.decoder import Decoder
-    for few in ("65536", "0"):
-        monkeypatch.setenv("NAFGPU_LZ_FEW_PENDING", few)
+    from oracle import oracle
+    for mode in ("dense", "sparse"):
+        monkeypatch.setenv("NAFGPU_LZ_MODE", mode)
         for name, blob, opts in all_cases:
-            if name in ("text_dense_chains", "dna_dense_chains"):
-                res = Decoder(io.BytesIO(blob), _lib=emu).decode_all_device()
-                assert res.lz_residue_matches > 0, name
-                assert cases.run_product(blob, opts, emu) == cases.run_oracle(blob, opts), (name, few)
+            if name in ("text_dense_chains", "dna_dense_chains", "dna_homopolymer", "dna_l3", "text_quality", "dna_repeats_l1"):
+                if "dense_chains" in name:
+                    res = Decoder(io.BytesIO(blob), _lib=emu).decode_all_device()
+                    assert res.lz_residue_matches > 0, (name, mode)
+                assert cases.run_product(blob, opts, emu) == cases.run_oracle(blob, opts), (name, mode)
+        for name, payload, data in cases.zstd_payload_cases(scale=1):
+            assert emu.zstd_decompress(payload, len(data)) == data, (name, mode)
 
 
 def test_pointer_jumping_distance_limit_falls_back_to_frame_order(emu, all_cases, monkeypatch):
     """D holds 32-bit distances: a chain longer than that cannot be jumped to its end.  With the limit lowered
-    to a few elements (NAFGPU_PJ_MAX_DIST) the jump steps stall with elements still pointing at pending bytes;
-    the copy step must then NOT run -- the section is finished in frame order -- and the bytes stay exact."""
-    monkeypatch.setenv("NAFGPU_LZ_FEW_PENDING", "0")
-    for limit in ("3", "64"):
+    to a few elements (NAFGPU_PJ_MAX_DIST) distances stop growing while elements still point at pending ones;
+    what the sweeps then leave is finished in frame order -- and the bytes stay exact."""
+    monkeypatch.setenv("NAFGPU_LZ_MODE", "dense")
+    for limit in ("8", "64"):
         monkeypatch.setenv("NAFGPU_PJ_MAX_DIST", limit)
         for name, blob, opts in all_cases:
             if name in ("text_dense_chains", "dna_dense_chains", "dna_homopolymer"):

@@ -196,20 +196,26 @@ def test_shared_cases_match_oracle(lib):
     assert not bad
 
 
-def test_pointer_jumping_stage_is_exercised(lib, monkeypatch):
-    """Dense short-offset chains must leave a residue after the fixed match passes (else this test
-    stopped covering the stages behind them) and still decode bit-exactly -- through the pass-by-pass
-    continuation a short residue takes by default, and (NAFGPU_LZ_FEW_PENDING=0) through pointer jumping."""
+def test_lz_stages_dense_and_sparse(lib, monkeypatch):
+    """Both ways of finishing LZ matches on the same inputs (NAFGPU_LZ_MODE forces one), at 4x the CPU-harness
+    sizes: element sweeps (pointer jumping) and list passes + one-workgroup stage + frame-order walk."""
     import cases
     import nafcodec_amd
-    todo = [c for c in cases.build_cases(scale=4) if c[0] in ("text_dense_chains", "dna_dense_chains")]
-    for few in ("65536", "0"):
-        monkeypatch.setenv("NAFGPU_LZ_FEW_PENDING", few)
+    todo = [c for c in cases.build_cases(scale=4) if c[0] in ("text_dense_chains", "dna_dense_chains", "dna_homopolymer", "dna_l3",
+                                                              "dna_l3_big", "text_quality", "dna_repeats_l1", "fastq_flush_per_record")]
+    for mode in ("dense", "sparse"):
+        monkeypatch.setenv("NAFGPU_LZ_MODE", mode)
         for name, blob, opts in todo:
-            dec = nafcodec_amd.Decoder(io.BytesIO(blob))
-            res = dec.decode_all_device()
-            assert res.lz_residue_matches > 0, name
-            assert cases.run_product(blob, opts) == cases.run_oracle(blob, opts), (name, few)
+            if "dense_chains" in name:
+                res = nafcodec_amd.Decoder(io.BytesIO(blob)).decode_all_device()
+                assert res.lz_residue_matches > 0, (name, mode)
+            assert cases.run_product(blob, opts) == cases.run_oracle(blob, opts), (name, mode)
+        for name, payload, data in cases.zstd_payload_cases(scale=2):
+            assert lib.zstd_decompress(payload, len(data)) == data, (name, mode)
+    monkeypatch.setenv("NAFGPU_LZ_MODE", "dense")
+    monkeypatch.setenv("NAFGPU_PJ_MAX_DIST", "16")          # distances cannot grow: the frame-order walk finishes
+    for name, blob, opts in todo[:3]:
+        assert cases.run_product(blob, opts) == cases.run_oracle(blob, opts), (name, "limit")
 
 
 def test_corrupted_archives_terminate_and_never_disagree_silently(lib):

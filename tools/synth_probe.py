@@ -9,10 +9,16 @@ n, ip = int(float(sys.argv[1])), int(sys.argv[2])
 mask = len(sys.argv) > 3 and sys.argv[3] == "1"
 base = _ffi.default()
 arc = base.synth(n, seed=0x4E4146, with_mask=mask, iupac_permille=ip)
-blob = ctypes.string_at(arc.bytes, arc.n)
+# (the archive goes through a file in /dev/shm and nafgpu_open_path: ctypes cannot hand a 10 GB buffer to a file-like)
+path_arc = "/dev/shm/nafgpu_probe_%d.naf" % os.getpid()
+with open(path_arc, "wb") as f:
+    view = (ctypes.c_char * arc.n).from_address(arc.bytes)
+    f.write(view)
+import atexit
+atexit.register(lambda: os.path.exists(path_arc) and os.unlink(path_arc))
 for path in [None] + [x for x in os.environ.get("NAFGPU_PROBE_LIBS", "").split(",") if x]:
     L = base if path is None else _ffi.Library(os.path.join(R, path))
-    dec = nafcodec_amd.Decoder(io.BytesIO(blob), _lib=L)
+    dec = nafcodec_amd.Decoder(path_arc, _lib=L)
     best = None
     for _ in range(4):
         res = dec.decode_all_device()

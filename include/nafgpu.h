@@ -82,7 +82,10 @@ typedef struct {
     int32_t device;              /* HIP device ordinal; -1 = current device */
     int32_t shard_rank;          /* multi-GPU: this process decodes shard `shard_rank` of `shard_count` */
     int32_t shard_count;         /* contiguous zstd-block ranges of the sequence section; 1 = everything */
-    int32_t reserved2;
+    int32_t tile_mib;            /* decode the sequence / quality sections in tiles of about this many MiB of output, so that
+                                    neither the compressed bytes nor the scratch memory -- nor, for nafgpu_next, the output --
+                                    are resident whole (the reference streams any size through 4 KiB buffers, mod.rs:223);
+                                    0 = only when the archive would not fit in the device's free memory */
 } nafgpu_opts;
 
 /* DecoderBuilder::new() (mod.rs:67-76) */
@@ -234,7 +237,11 @@ typedef struct {
     uint64_t seed;
     uint8_t with_mask;           /* add a Mask section (runs stay inside records) */
     uint8_t iupac_permille;      /* 0..255: per-mille of non-ACGT codes (N, R, Y, ...) */
-    uint8_t reserved[6];
+    uint8_t part_count;          /* > 1: write only part `part_rank` of the archive (several processes write one archive
+                                    together, each its share of the sequence section's zstd blocks: nafgpu_synth_archive.bytes
+                                    then holds that share alone, and nafgpu_synth_head writes what goes in front) */
+    uint8_t part_rank;
+    uint8_t reserved[4];
     uint32_t threads;            /* 0 = hardware concurrency */
     uint32_t reserved2;
 } nafgpu_synth_spec;
@@ -248,6 +255,10 @@ typedef struct {
 } nafgpu_synth_archive;
 
 int nafgpu_synth_write(const nafgpu_synth_spec *spec, nafgpu_synth_archive *out);
+/* What precedes the parts of an archive written in parts: container header, Length (and Mask) sections, the
+ * sequence section's two sizes and its frame header.  seq_part_bytes = sum of the parts' sizes.  out->bytes / n:
+ * that head; the archive is head followed by part 0, part 1, ...; seq_hash is 0 (the parts' values add up). */
+int nafgpu_synth_head(const nafgpu_synth_spec *spec, uint64_t seq_part_bytes, nafgpu_synth_archive *out);
 void nafgpu_synth_free(nafgpu_synth_archive *a);
 
 /* order-sensitive 64-bit checksum used for full-size parity checks: sum over the 8-byte words w_j of

@@ -26,7 +26,7 @@ class Opts(Structure):
     _fields_ = [("id", c_uint8), ("comment", c_uint8), ("sequence", c_uint8), ("quality", c_uint8),
                 ("mask", c_uint8), ("spec_mask", c_uint8), ("reserved", c_uint8 * 2),
                 ("buffer_size", c_uint64), ("device", c_int32), ("shard_rank", c_int32),
-                ("shard_count", c_int32), ("reserved2", c_int32)]
+                ("shard_count", c_int32), ("tile_mib", c_int32)]
 
 
 class Header(Structure):
@@ -67,7 +67,7 @@ class TextResult(Structure):
 
 class SynthSpec(Structure):
     _fields_ = [("n_bases", c_uint64), ("seed", c_uint64), ("with_mask", c_uint8), ("iupac_permille", c_uint8),
-                ("reserved", c_uint8 * 6), ("threads", c_uint32), ("reserved2", c_uint32)]
+                ("part_count", c_uint8), ("part_rank", c_uint8), ("reserved", c_uint8 * 4), ("threads", c_uint32), ("reserved2", c_uint32)]
 
 
 class SynthArchive(Structure):
@@ -85,7 +85,7 @@ EXPORTS = [
     "nafgpu_decode_all_device", "nafgpu_zstd_decompress", "nafgpu_synth_write", "nafgpu_synth_free",
     "nafgpu_hash64_host", "nafgpu_hash64_device", "nafgpu_abi_version", "nafgpu_device_info",
     "nafgpu_upload", "nafgpu_device_synchronize", "nafgpu_hash64_device_at",
-    "nafgpu_format_device", "nafgpu_copy_to_host",
+    "nafgpu_format_device", "nafgpu_copy_to_host", "nafgpu_synth_head",
 ]
 
 
@@ -119,6 +119,7 @@ class Library:
         L.nafgpu_zstd_decompress.argtypes = [c_char_p, c_size_t, c_void_p, c_size_t, POINTER(c_size_t), c_int,
                                              POINTER(Error)]
         L.nafgpu_synth_write.argtypes = [POINTER(SynthSpec), POINTER(SynthArchive)]
+        L.nafgpu_synth_head.argtypes = [POINTER(SynthSpec), c_uint64, POINTER(SynthArchive)]
         L.nafgpu_synth_free.argtypes = [POINTER(SynthArchive)]
         L.nafgpu_synth_free.restype = None
         L.nafgpu_hash64_host.argtypes = [c_char_p, c_uint64]
@@ -139,13 +140,23 @@ class Library:
             raise NafError.from_c(err)
         return buf.raw[:produced.value]
 
-    def synth(self, n_bases, seed=0x4E4146, with_mask=False, iupac_permille=0, threads=0):
+    def synth(self, n_bases, seed=0x4E4146, with_mask=False, iupac_permille=0, threads=0, part_rank=0, part_count=1):
+        """nafgpu_synth_write: the whole archive, or (part_count > 1) this process's share of its sequence blocks."""
         spec = SynthSpec(n_bases=n_bases, seed=seed, with_mask=int(with_mask), iupac_permille=iupac_permille,
-                         threads=threads)
+                         threads=threads, part_rank=part_rank, part_count=part_count)
         arc = SynthArchive()
         rc = self.c.nafgpu_synth_write(byref(spec), byref(arc))
         if rc != OK:
             raise RuntimeError("nafgpu_synth_write failed: %d" % rc)
+        return arc
+
+    def synth_head(self, n_bases, seq_part_bytes, seed=0x4E4146, with_mask=False, iupac_permille=0):
+        """nafgpu_synth_head: what goes in front of the parts of an archive written in parts."""
+        spec = SynthSpec(n_bases=n_bases, seed=seed, with_mask=int(with_mask), iupac_permille=iupac_permille)
+        arc = SynthArchive()
+        rc = self.c.nafgpu_synth_head(byref(spec), seq_part_bytes, byref(arc))
+        if rc != OK:
+            raise RuntimeError("nafgpu_synth_head failed: %d" % rc)
         return arc
 
     def device_info(self, device=0):

@@ -29,14 +29,17 @@ namespace {
 
 // Pinned read-back window over one decoded section in HBM (sequence / quality): records are
 // consumed front to back, so one sliding window replaces the reference's per-record Strings.
+// The section may be resident whole, or a tile at a time (SectionJob::tiled_output): the window then
+// asks for the next tile whenever it runs off the end of the one in HBM -- positions only move forward.
 class HostWindow {
 public:
     ~HostWindow() {
         if (buf_) (void)hipHostFree(buf_);
     }
-    void bind(ArchiveJob *job, const uint8_t *d_base, uint64_t total, uint64_t window) {
+    void bind(ArchiveJob *job, int section, uint64_t mult, uint64_t total, uint64_t window) {
         job_ = job;
-        d_base_ = d_base;
+        section_ = section;
+        mult_ = mult;
         total_ = total;
         window_ = window;
         lo_ = hi_ = 0;
@@ -45,30 +48,61 @@ public:
     const uint8_t *get(uint64_t start, uint64_t len, Failure *f) {
         if (len == 0) return reinterpret_cast<const uint8_t *>("");
         if (start >= lo_ && start + len <= hi_) return buf_ + (start - lo_);
-        uint64_t want = std::max(len, std::min(window_, total_ - start));
+        const uint64_t want = std::max(len, std::min(window_, total_ - start));
+        const uint64_t keep = (start >= lo_ && start < hi_) ? hi_ - start : 0;   // already on the host (a record straddling the old window)
         if (want > cap_) {
-            if (buf_) (void)hipHostFree(buf_);
-            buf_ = nullptr;
             void *p = nullptr;
             if (hipHostMalloc(&p, want) != hipSuccess) {
                 *f = Failure::make(NAFGPU_E_DEVICE, "cannot allocate the pinned read-back window");
-                cap_ = 0;
                 return nullptr;
             }
+            if (keep) std::memcpy(p, buf_ + (start - lo_), keep);
+            if (buf_) (void)hipHostFree(buf_);
             buf_ = static_cast<uint8_t *>(p);
             cap_ = want;
+        } else if (keep) {
+            std::memmove(buf_, buf_ + (start - lo_), keep);
         }
-        *f = job_->copy_to_host(buf_, d_base_ + start, want);
-        if (!f->ok()) return nullptr;
+        const SectionJob &sj = job_->job(section_);
+        uint64_t pos = start + keep;                       // next byte to fetch
+        const uint64_t end = start + want;
+        while (pos < end) {
+            uint64_t held0 = 0, held1 = total_;            // bytes of the section in HBM right now
+            const uint8_t *d_held = sj.out();
+            if (sj.tiled_output()) {
+                held0 = sj.tile_pos0() * mult_;
+                held1 = (sj.tile_pos0() + sj.tile_len()) * mult_;
+                d_held = sj.tile_data();
+                if (pos >= held1) {                        // off the end of the tile: the next one takes its place
+                    if (sj.tiles_done() >= sj.n_tiles()) break;
+                    *f = job_->advance_tile(section_);
+                    if (!f->ok()) return nullptr;
+                    continue;
+                }
+                if (pos < held0) {
+                    *f = Failure::make(NAFGPU_E_INVALID_ARG, "internal: the read-back window moved backwards over a tile");
+                    return nullptr;
+                }
+            }
+            const uint64_t n = std::min(end, held1) - pos;
+            if (n == 0) break;
+            *f = job_->copy_to_host(buf_ + (pos - start), d_held + (pos - held0), n);
+            if (!f->ok()) return nullptr;
+            pos += n;
+        }
         lo_ = start;
-        hi_ = start + want;
+        hi_ = pos;
+        if (start + len > hi_) {
+            *f = Failure::io(NAFGPU_IO_UNEXPECTED_EOF, "section ends before the record does");
+            return nullptr;
+        }
         return buf_;
     }
 
 private:
     ArchiveJob *job_ = nullptr;
-    const uint8_t *d_base_ = nullptr;
-    uint64_t total_ = 0, window_ = 0, lo_ = 0, hi_ = 0, cap_ = 0;
+    int section_ = 0;
+    uint64_t mult_ = 1, total_ = 0, window_ = 0, lo_ = 0, hi_ = 0, cap_ = 0;
     uint8_t *buf_ = nullptr;
 };
 
@@ -89,6 +123,8 @@ struct nafgpu_decoder {
     }
     ArchiveJob job;
     bool device_ready = false, decoded = false;
+    uint64_t tile_blocks = 0;            // > 0: the sequence / quality sections are decoded in tiles of this many zstd blocks
+    bool tiled_output = false;           // ... and their output is held a tile at a time (record iterator)
     Failure fatal;                       // device failure: every later call reports it
     Failure last;
     // iterator state (mod.rs:285-296)
@@ -104,12 +140,33 @@ struct nafgpu_decoder {
 
 namespace {
 
-Failure ensure_uploaded(nafgpu_decoder *d);
+Failure ensure_uploaded(nafgpu_decoder *d, bool for_iterator);
 
-Failure ensure_decoded(nafgpu_decoder *d) {
+// Decoded output of this many bytes per tile (0: no tiling): nafgpu_opts.tile_mib, NAFGPU_TILE_MIB, or -- when the
+// selected sections would not fit beside each other in the device's free memory -- a sixteenth of that memory.
+uint64_t tile_blocks_for(const nafgpu_decoder *d) {
+    uint64_t tile_bytes = static_cast<uint64_t>(d->opts.tile_mib > 0 ? d->opts.tile_mib : 0) << 20;
+    if (const char *e = std::getenv("NAFGPU_TILE_KIB")) tile_bytes = std::strtoull(e, nullptr, 10) << 10;   // tests: tiles far below a MiB
+    if (!tile_bytes) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+        uint64_t need = 0;
+        for (int s = 0; s < kNumSections; s++)
+            if (d->use[s]) {
+                const uint64_t out = s == kSequence && d->header.sequence_type <= 1 ? d->sec[s].original_size : d->sec[s].original_size;
+                need += d->sec[s].compressed_size + out + out / 8;      // compressed + decoded + scratch
+            }
+        if (need < static_cast<uint64_t>(free_b) / 10 * 8) return 0;
+        tile_bytes = std::max<uint64_t>(static_cast<uint64_t>(free_b) / 16, uint64_t(64) << 20);
+    }
+    const uint64_t per_block = kBlockMax * (d->header.sequence_type <= 1 ? 2 : 1);
+    return std::max<uint64_t>(1, tile_bytes / per_block);
+}
+
+Failure ensure_decoded(nafgpu_decoder *d, bool for_iterator) {
     if (!d->fatal.ok()) return d->fatal;
     if (d->decoded) return Failure();
-    Failure f = ensure_uploaded(d);
+    Failure f = ensure_uploaded(d, for_iterator);
     if (!f.ok()) return f;
     f = d->job.decode();
     if (!f.ok()) return d->fatal = f;
@@ -127,8 +184,8 @@ Failure ensure_decoded(nafgpu_decoder *d) {
         if (!f.ok()) return d->fatal = f;
     }
     const uint64_t window = std::max<uint64_t>(d->opts.buffer_size, uint64_t(64) << 20);
-    d->seq_win.bind(&d->job, d->job.d_sequence(), d->job.n_sequence_bytes(), window);
-    d->qual_win.bind(&d->job, d->job.d_section(kQuality), d->job.section_size(kQuality), window);
+    d->seq_win.bind(&d->job, kSequence, d->header.sequence_type <= 1 ? 2 : 1, d->job.n_sequence_bytes(), window);
+    d->qual_win.bind(&d->job, kQuality, 1, d->job.section_size(kQuality), window);
     // MaskReader yields units until their sum reaches the nucleotide count (reader.rs:200-202);
     // a record ending beyond what the units cover raises "failed to get mask unit" (mod.rs:430-435)
     const uint64_t total = d->sec[kSequence].present ? d->sec[kSequence].original_size : 0;
@@ -137,8 +194,10 @@ Failure ensure_decoded(nafgpu_decoder *d) {
     return Failure();
 }
 
-Failure ensure_uploaded(nafgpu_decoder *d) {
+Failure ensure_uploaded(nafgpu_decoder *d, bool for_iterator) {
     if (!d->fatal.ok()) return d->fatal;
+    const uint64_t tile_blocks = d->device_ready ? d->tile_blocks : 0;
+    if (d->device_ready && tile_blocks && d->tiled_output != for_iterator) d->device_ready = false;   // the other way of holding the output: prepare again
     if (!d->device_ready) {
         Failure f = d->job.init(d->opts.device);
         if (!f.ok()) return d->fatal = f;
@@ -149,6 +208,10 @@ Failure ensure_uploaded(nafgpu_decoder *d) {
         ao.spec_mask = d->opts.spec_mask != 0;
         ao.shard_count = d->opts.shard_count > 1 ? static_cast<uint32_t>(d->opts.shard_count) : 1u;
         ao.shard_rank = d->opts.shard_rank > 0 ? static_cast<uint32_t>(d->opts.shard_rank) : 0u;
+        d->tile_blocks = tile_blocks_for(d);
+        d->tiled_output = d->tile_blocks != 0 && for_iterator;
+        ao.tile_blocks = d->tile_blocks;
+        ao.tiled_output = d->tiled_output;
         f = d->job.upload(d->bytes, d->n_bytes, d->header, d->sec, ao);
         if (!f.ok()) return d->fatal = f;
         d->device_ready = true;
@@ -428,7 +491,7 @@ int nafgpu_next(nafgpu_decoder *d, nafgpu_record *rec) {
     if (d->n >= d->header.number_of_sequences) return NAFGPU_END;          // mod.rs:447-449
     if (d->opts.shard_count > 1)
         return fail(d, Failure::make(NAFGPU_E_INVALID_ARG, "record iteration needs the whole archive (shard_count == 1)"));
-    Failure f = ensure_decoded(d);
+    Failure f = ensure_decoded(d, true);
     if (!f.ok()) return fail(d, f);
     std::memset(rec, 0, sizeof *rec);
     // state consumed before an error is not rolled back, as in the reference (mod.rs:391)
@@ -489,7 +552,7 @@ int nafgpu_next(nafgpu_decoder *d, nafgpu_record *rec) {
 int nafgpu_decode_all_device(nafgpu_decoder *d, nafgpu_device_result *out) {
     if (!d || !out) return NAFGPU_E_INVALID_ARG;
     d->decoded = false;                                                    // every call re-runs the kernels
-    Failure f = ensure_decoded(d);
+    Failure f = ensure_decoded(d, false);
     if (!f.ok()) return fail(d, f);
     for (int s = 0; s < kNumSections; s++)
         if (d->use[s] && !d->job.section_failure(s).ok()) return fail(d, d->job.section_failure(s));
@@ -523,7 +586,10 @@ int nafgpu_decode_all_device(nafgpu_decoder *d, nafgpu_device_result *out) {
     out->n_comments_bytes = j.section_size(kComments);
     out->packed_bytes = j.packed_bytes();
     out->compressed_bytes = j.compressed_bytes();
-    out->seq_compressed_bytes = d->use[kSequence] ? d->sec[kSequence].compressed_size : 0;
+    // compressed bytes of the sequence section this process reads: its block range's when the section is sharded
+    out->seq_compressed_bytes = !d->use[kSequence] ? 0
+                                : (j.job(kSequence).ready() && j.job(kSequence).n_tiles() == 1 ? j.job(kSequence).source_bytes()
+                                                                                              : d->sec[kSequence].compressed_size);
     out->n_zstd_blocks = j.job(kSequence).n_blocks();
     out->n_huf_streams = j.job(kSequence).n_streams();
     const StageTimes &t = j.times();
@@ -547,7 +613,8 @@ int nafgpu_decode_all_device(nafgpu_decoder *d, nafgpu_device_result *out) {
 int nafgpu_format_device(nafgpu_decoder *d, nafgpu_text_result *out) {
     if (!d || !out) return NAFGPU_E_INVALID_ARG;
     std::memset(out, 0, sizeof *out);
-    Failure f = ensure_decoded(d);
+    if (d->decoded && d->tiled_output) d->decoded = false;                 // text needs the whole output in HBM
+    Failure f = ensure_decoded(d, false);
     if (!f.ok()) return fail(d, f);
     for (int s = 0; s < kNumSections; s++)
         if (d->use[s] && !d->job.section_failure(s).ok()) return fail(d, d->job.section_failure(s));
@@ -570,7 +637,7 @@ int nafgpu_copy_to_host(nafgpu_decoder *d, const void *d_ptr, uint64_t n, void *
 
 int nafgpu_upload(nafgpu_decoder *d) {
     if (!d) return NAFGPU_E_INVALID_ARG;
-    Failure f = ensure_uploaded(d);
+    Failure f = ensure_uploaded(d, false);
     return f.ok() ? NAFGPU_OK : fail(d, f);
 }
 
@@ -609,7 +676,6 @@ int nafgpu_zstd_decompress(const uint8_t *src, size_t n, uint8_t *dst, size_t ca
         return f.status;
     }
     {
-        DevBuf d_src;
         SectionJob job;
         // the decoded size is not part of a NAF-less call: take it from a host-side walk when the
         // frame is literal-only, else trust `cap` as the exact size
@@ -622,13 +688,8 @@ int nafgpu_zstd_decompress(const uint8_t *src, size_t n, uint8_t *dst, size_t ca
             const uint64_t expect = probe.seq_blocks.empty() ? probe.known_out : cap;
             if (expect > cap) {
                 f = Failure::io(NAFGPU_IO_INVALID_DATA, "zstd: destination buffer too small");
-            } else if (!d_src.alloc(kSrcFrontPad + n + kSrcBackPad)) {
-                f = Failure::make(NAFGPU_E_DEVICE, "out of device memory");
             } else {
-                (void)hipMemsetAsync(d_src.bytes(), 0, kSrcFrontPad, stream);
-                (void)hipMemsetAsync(d_src.bytes() + kSrcFrontPad + n, 0, kSrcBackPad, stream);
-                (void)hipMemcpyAsync(d_src.bytes() + kSrcFrontPad, src, n, hipMemcpyHostToDevice, stream);
-                f = job.prepare(src, n, expect, d_src.bytes() + kSrcFrontPad, stream);
+                f = job.prepare(src, n, expect, stream, SectionOptions());
                 if (f.ok()) {
                     job.run(stream, nullptr);
                     f = job.check(stream);

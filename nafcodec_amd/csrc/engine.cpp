@@ -25,6 +25,7 @@ const char *status_text(uint32_t code) {
     case kStSizeMismatch: return "zstd: decoded size differs from the size recorded in the archive";
     case kStRunsOverflow: return "run table overflow";
     case kStInternal: return "internal error: a decode task exceeds its address window";
+    case kStChecksum: return "zstd: frame checksum mismatch";
     default: return "zstd: device decoder reported an error";
     }
 }
@@ -124,65 +125,234 @@ StageTimes StageTimer::collect() {
 }
 
 // ------------------------------------------------------------------ SectionJob
-Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expect_size, const uint8_t *d_payload,
-                            hipStream_t stream, uint32_t ascii_t_char, uint32_t shard_rank, uint32_t shard_count) {
+Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expect_size, hipStream_t stream,
+                            const SectionOptions &opt) {
     ready_ = false;
-    t_char_ = ascii_t_char;
+    opt_ = opt;
+    t_char_ = opt.t_char;
+    host_payload_ = host_payload;
+    master_ = ZPlan();
     plan_ = ZPlan();
+    tiles_.clear();
+    loaded_tile_ = 0xFFFFFFFFu;
+    tiles_done_ = 0;
     const double t0 = now_ms();
     bool truncated = false;
-    std::string err = build_zplan(host_payload, n, &plan_, &truncated, shard_rank, shard_count);
+    std::string err = walk_zstd(host_payload, n, &master_, &truncated);
     plan_ms_ = static_cast<float>(now_ms() - t0);
     if (!err.empty())
         return Failure::io(truncated ? NAFGPU_IO_UNEXPECTED_EOF : NAFGPU_IO_INVALID_DATA, "zstd: " + err);
     expect_ = expect_size;
-    d_src_ = d_payload;
+    master_blocks_ = master_.blk_size.size();
+    master_streams_ = master_.streams.size();
+    if ((master_.seq_blocks.empty() && master_.known_out != expect_size) ||
+        expect_size > static_cast<uint64_t>(master_.blk_size.size()) * kBlockMax)     // untrusted: no block decodes to more than 128 KiB
+        return Failure::io(NAFGPU_IO_INVALID_DATA, "zstd: decoded size differs from the size recorded in the archive");
+    // ---- this process's block range (a shard of a section without LZ sequences, else everything)
+    uint32_t b0 = 0, b1 = static_cast<uint32_t>(master_blocks_);
+    sharded_ = shard_range(master_, opt.shard_rank, opt.shard_count, &b0, &b1);
+    out0_ = 0;
+    out1_ = expect_size;
+    if (sharded_) {
+        for (uint32_t b = 0; b < b0; b++) out0_ += master_.blk_size[b];
+        out1_ = out0_;
+        for (uint32_t b = b0; b < b1; b++) out1_ += master_.blk_size[b];
+    }
+    // ---- tiles
+    const uint64_t tb = opt.tile_blocks ? opt.tile_blocks : (static_cast<uint64_t>(b1 - b0) ? b1 - b0 : 1);
+    for (uint64_t b = b0; b < b1 || tiles_.empty(); b += tb) {
+        tiles_.push_back(Tile{static_cast<uint32_t>(b), static_cast<uint32_t>(std::min<uint64_t>(b + tb, b1))});
+        if (b1 == b0) break;
+    }
+    has_lz_ = !master_.seq_blocks.empty();
+    sec_known_ = master_.known_out;
+    sec_seqs_ = master_.n_sequences;
+    const bool lz = has_lz_;
+    // the window of a tile that follows another: its matches may reach that far back
+    halo_cap_ = (lz && tiles_.size() > 1) ? std::min<uint64_t>(std::max<uint64_t>(master_.window_max, 1), expect_size) : 0;
+    if (halo_cap_ > 0xF0000000ull) return Failure::io(NAFGPU_IO_INVALID_DATA, "zstd: window too large to decode in tiles");
+    tile_cap_ = 0;
+    const uint64_t mult = t_char_ ? 2 : 1;
+    bool ok = d_status_.alloc(64) && d_counters_.alloc(128);
+    if (tiled_output()) {
+        uint64_t most = 0;
+        for (const Tile &t : tiles_) most = std::max<uint64_t>(most, t.b1 - t.b0);
+        tile_cap_ = most * kBlockMax;
+        ok = ok && d_out_.alloc_items(halo_cap_ + tile_cap_, mult, 64);
+    } else {
+        ok = ok && d_out_.alloc_items(out1_ - out0_, mult, 64);
+    }
+    if (!ok) return Failure::make(NAFGPU_E_DEVICE, "out of device memory while preparing a section");
+    tile_pos0_ = out0_;
+    tile_len_ = 0;
+    rep_carry_[0] = 1;
+    rep_carry_[1] = 4;
+    rep_carry_[2] = 8;
+    carry_frame_ = 0xFFFFFFFFu;
+    carry_same_frame_ = false;
+    ready_ = true;
+    if (tiles_.size() == 1) {
+        Failure f = load_tile(0, stream);
+        if (!f.ok()) {
+            ready_ = false;
+            return f;
+        }
+    }
+    return Failure();
+}
+
+// The launchable plan of tile t: selected from the walk, uploaded together with the compressed bytes it reads.
+Failure SectionJob::load_tile(uint32_t t, hipStream_t stream) {
+    if (t == loaded_tile_) return Failure();
+    const Tile tile = tiles_[t];
+    const bool lz = has_lz_;
+    // LZ window in front of the tile: min(window, decoded so far in this process's range)
+    halo_elems_ = (lz && t > 0) ? std::min<uint64_t>(halo_cap_, tile_pos0_ - out0_) : 0;
+    const double t0 = now_ms();
+    if (tiles_.size() == 1 && !sharded_) {
+        plan_ = std::move(master_);                        // the whole section: nothing to re-base, nothing selected again
+        master_ = ZPlan();
+        plan_.src_lo = 0;
+        plan_.src_hi = plan_.blk_off.empty() ? 0 : plan_.blk_off.back();
+        pack_tasks_public(&plan_);
+    } else {
+        select_zplan(master_, tile.b0, tile.b1, halo_elems_, &plan_);
+    }
+    plan_ms_ += static_cast<float>(now_ms() - t0);
     n_blocks_ = plan_.blk_size.size();
     n_streams_ = plan_.streams.size();
     n_tasks_ = plan_.tasks.size();
     n_copies_ = plan_.copies.size();
     n_seq_blocks_ = plan_.seq_blocks.size();
-    if ((plan_.seq_blocks.empty() && plan_.known_out != expect_size) ||
-        expect_size > static_cast<uint64_t>(plan_.blk_size.size()) * kBlockMax)     // untrusted: no block decodes to more than 128 KiB
-        return Failure::io(NAFGPU_IO_INVALID_DATA, "zstd: decoded size differs from the size recorded in the archive");
-    out0_ = plan_.sharded ? plan_.shard_out0 : 0;
-    out1_ = plan_.sharded ? plan_.shard_out1 : expect_size;
     classes_ = plan_.classes;                              // launch classes of the Huffman tasks (plan.h: HufClass)
+    // frames with a Content_Checksum: the pieces of them this tile holds (a frame begun in front of a shard's range
+    // cannot be verified by this process)
+    xxh_segs_.clear();
+    if (t == 0) xxh_live_ = false;
+    if (plan_.has_checksum) {
+        const std::vector<ZPlan::Frame> &frames = plan_.frames;
+        bool live = false;
+        for (const ZPlan::Frame &f : frames) {
+            if (f.end_blk <= tile.b0) continue;
+            if (f.first_blk >= tile.b1) break;
+            const bool begins = f.first_blk >= tile.b0, ends = f.end_blk <= tile.b1;
+            if (!f.has_checksum || (!begins && !xxh_live_)) continue;
+            xxh_segs_.push_back(XxhSeg{std::max(f.first_blk, tile.b0) - tile.b0 + plan_.halo, std::min(f.end_blk, tile.b1) - tile.b0 + plan_.halo,
+                                       f.checksum, (begins ? 1u : 0u) | (ends ? 2u : 0u)});
+            live = !ends;
+        }
+        xxh_live_ = live;
+    }
     if (std::getenv("NAFGPU_DEBUG_PLAN")) {
-        std::fprintf(stderr, "[nafgpu] section plan: %zu blocks, %zu streams, %zu seq blocks, %llu sequences, literal buffer %llu B; task classes:",
-                     n_blocks_, n_streams_, n_seq_blocks_, static_cast<unsigned long long>(plan_.n_sequences),
-                     static_cast<unsigned long long>(plan_.lit_bytes));
+        std::fprintf(stderr, "[nafgpu] section plan: tile %u of %zu, %zu blocks, %zu streams, %zu seq blocks, %llu sequences, literal buffer %llu B, source %llu B; task classes:",
+                     t, tiles_.size(), n_blocks_, n_streams_, n_seq_blocks_, static_cast<unsigned long long>(plan_.n_sequences),
+                     static_cast<unsigned long long>(plan_.lit_bytes), static_cast<unsigned long long>(plan_.src_hi - plan_.src_lo));
         for (const HufClass &c : classes_)
             std::fprintf(stderr, " {%u tasks, tbl %u, %s%s, lds %u B}", c.n_tasks, c.tbl, c.to_lit ? "lit" : "out", c.seg ? "+seg" : "", c.lds_bytes);
         std::fprintf(stderr, "\n");
     }
-    bool ok = d_out_.alloc(static_cast<size_t>(out_bytes()) + 64) && d_status_.alloc(64) &&
-              d_blk_size_.upload(plan_.blk_size.data(), n_blocks_ * sizeof(uint32_t), stream) &&
-              d_blk_base_.alloc((n_blocks_ + 1) * sizeof(uint64_t)) && d_scan_tmp_.alloc(scan_tmp_bytes(n_blocks_)) &&
-              d_streams_.upload(plan_.streams.data(), n_streams_ * sizeof(HufStream), stream) &&
-              d_tasks_.upload(plan_.tasks.data(), n_tasks_ * sizeof(HufTask), stream) &&
-              d_tbl_copies_.upload(plan_.tbl_copies.data(), plan_.tbl_copies.size() * sizeof(HufTblCopy), stream) &&
-              d_pool_.upload(plan_.huf_pool.data(), plan_.huf_pool.size() * sizeof(uint16_t), stream) &&
-              d_dicts_.upload(plan_.dict_pool.data(), plan_.dict_pool.size(), stream) &&
-              d_copies_.upload(plan_.copies.data(), n_copies_ * sizeof(CopyTask), stream) &&
-              d_seq_blocks_.upload(plan_.seq_blocks.data(), n_seq_blocks_ * sizeof(SeqBlock), stream) &&
-              d_cells_.upload(plan_.fse_pool.data(), plan_.fse_pool.size() * sizeof(SeqCell), stream) &&
-              d_lit_.alloc(static_cast<size_t>(plan_.lit_bytes) + 64) &&
-              d_seqs_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(Seq) + 16) &&
-              d_meta_.alloc(static_cast<size_t>(plan_.n_sequences) * sizeof(SeqMeta) + 16) &&
-              d_rep_final_.alloc(n_seq_blocks_ * 12 + 16) && d_rep_init_.alloc(n_seq_blocks_ * 12 + 16) &&
-              d_rep_scratch_.alloc((n_seq_blocks_ / 64 + 1) * 24 + 16) &&
-              d_blk_pending_.alloc(n_seq_blocks_ * 4 + 16) && d_counters_.alloc(64);
+    // ---- the compressed bytes the tile's tasks read, with the padding k_huf_decode's whole-line loads may touch
+    const uint64_t src_n = plan_.src_hi - plan_.src_lo;
+    src_resident_ = src_n;
+    bool ok = d_src_buf_.alloc(kSrcFrontPad + static_cast<size_t>(src_n) + kSrcBackPad);
+    if (ok) {
+        (void)hipMemsetAsync(d_src_buf_.bytes(), 0, kSrcFrontPad, stream);
+        (void)hipMemsetAsync(d_src_buf_.bytes() + kSrcFrontPad + src_n, 0, kSrcBackPad, stream);
+        if (src_n) ok = hip_ok(hipMemcpyAsync(d_src_buf_.bytes() + kSrcFrontPad, host_payload_ + plan_.src_lo, src_n, hipMemcpyHostToDevice, stream));
+        d_src_ = d_src_buf_.bytes() + kSrcFrontPad - plan_.src_lo;     // kernels address the payload by its offsets
+    }
+    ok = ok && d_blk_size_.upload(plan_.blk_size.data(), n_blocks_ * sizeof(uint32_t), stream) &&
+         d_blk_base_.alloc((n_blocks_ + 1) * sizeof(uint64_t)) && d_scan_tmp_.alloc(scan_tmp_bytes(n_blocks_)) &&
+         d_streams_.upload(plan_.streams.data(), n_streams_ * sizeof(HufStream), stream) &&
+         d_tasks_.upload(plan_.tasks.data(), n_tasks_ * sizeof(HufTask), stream) &&
+         d_tbl_copies_.upload(plan_.tbl_copies.data(), plan_.tbl_copies.size() * sizeof(HufTblCopy), stream) &&
+         d_pool_.upload(plan_.huf_pool.data(), plan_.huf_pool.size() * sizeof(uint16_t), stream) &&
+         d_dicts_.upload(plan_.dict_pool.data(), plan_.dict_pool.size(), stream) &&
+         d_copies_.upload(plan_.copies.data(), n_copies_ * sizeof(CopyTask), stream) &&
+         d_seq_blocks_.upload(plan_.seq_blocks.data(), n_seq_blocks_ * sizeof(SeqBlock), stream) &&
+         d_cells_.upload(plan_.fse_pool.data(), plan_.fse_pool.size() * sizeof(SeqCell), stream) &&
+         d_lit_.alloc(static_cast<size_t>(plan_.lit_bytes) + 64) &&
+         d_seqs_.alloc_items(plan_.n_sequences, sizeof(Seq), 16) &&
+         d_meta_.alloc_items(plan_.n_sequences, sizeof(SeqMeta), 16) &&
+         d_rep_final_.alloc(n_seq_blocks_ * 12 + 16) && d_rep_init_.alloc(n_seq_blocks_ * 12 + 16) &&
+         d_rep_scratch_.alloc((n_seq_blocks_ / 64 + 1) * 24 + 16) &&
+         d_blk_pending_.alloc(n_seq_blocks_ * 4 + 16) &&
+         d_xxh_segs_.upload(xxh_segs_.data(), xxh_segs_.size() * sizeof(XxhSeg), stream) &&
+         (xxh_segs_.empty() || d_xxh_carry_.alloc(2 * sizeof(XxhCarry)));
     if (!ok) return Failure::make(NAFGPU_E_DEVICE, "out of device memory while preparing a section");
     // the host vectors were consumed by asynchronous copies: keep them until the stream drains
     if (!hip_ok(hipStreamSynchronize(stream))) return Failure::make(NAFGPU_E_DEVICE, "upload of task lists failed");
     // only the counts are needed from here on
     std::vector<HufStream>().swap(plan_.streams);
+    std::vector<HufTableRef>().swap(plan_.stream_ref);
     std::vector<uint16_t>().swap(plan_.huf_pool);
     std::vector<SeqCell>().swap(plan_.fse_pool);
     std::vector<CopyTask>().swap(plan_.copies);
-    ready_ = true;
+    std::vector<uint64_t>().swap(plan_.blk_off);
+    carry_same_frame_ = n_seq_blocks_ > 0 && carry_frame_ != 0xFFFFFFFFu && plan_.first_seq_frame == carry_frame_;
+    loaded_tile_ = t;
     return Failure();
+}
+
+// Tiles are decoded in order: tile t needs the position, the repeat offsets and -- when the output is held one
+// tile at a time -- the last window bytes the tiles before it left.
+Failure SectionJob::decode_tile(uint32_t t, hipStream_t stream, StageTimer *timer, hipStream_t aux) {
+    if (!ready_) return Failure();
+    if (t >= tiles_.size() || t != tiles_done_) return Failure::make(NAFGPU_E_INVALID_ARG, "tiles are decoded in order");
+    const uint64_t mult = t_char_ ? 2 : 1;
+    if (t > 0) {
+        // ---- move on: the next tile starts where this one ended
+        const uint64_t done = tile_pos0_ + tile_len_ - out0_;              // decoded so far in this process's range
+        if (tiled_output() && halo_cap_) {                                 // keep the last window bytes in front of the tile area
+            const uint64_t keep = std::min<uint64_t>(halo_cap_, done);
+            uint8_t *base = d_out_.bytes();
+            uint8_t *src = base + (halo_cap_ + tile_len_ - keep) * mult, *dst = base + (halo_cap_ - keep) * mult;
+            if (tile_len_ >= keep) {
+                (void)hipMemcpyAsync(dst, src, keep * mult, hipMemcpyDeviceToDevice, stream);
+            } else if (tile_len_ > 0) {                                    // tiny tile: source and destination overlap
+                if (!d_halo_tmp_.alloc_items(keep, mult)) return Failure::make(NAFGPU_E_DEVICE, "out of device memory");
+                (void)hipMemcpyAsync(d_halo_tmp_.bytes(), src, keep * mult, hipMemcpyDeviceToDevice, stream);
+                (void)hipMemcpyAsync(dst, d_halo_tmp_.bytes(), keep * mult, hipMemcpyDeviceToDevice, stream);
+            }
+        }
+        tile_pos0_ += tile_len_;
+        tile_len_ = 0;
+    }
+    Failure f = load_tile(t, stream);
+    if (!f.ok()) return f;
+    if (tiled_output() && halo_elems_ + static_cast<uint64_t>(n_blocks_ - plan_.halo) * kBlockMax > halo_cap_ + tile_cap_)
+        return Failure::make(NAFGPU_E_DEVICE, "internal: tile larger than its buffer");
+    run(stream, timer, aux);
+    // what the tile decoded to, the repeat offsets it ends with, its status
+    uint64_t total = 0;
+    uint32_t rep[3] = {1, 4, 8};
+    if (!hip_ok(hipMemcpyAsync(&total, d_blk_base_.as<uint64_t>() + n_blocks_, sizeof total, hipMemcpyDeviceToHost, stream)) ||
+        !hip_ok(hipMemcpyAsync(rep, d_counters_.bytes() + 64, sizeof rep, hipMemcpyDeviceToHost, stream)))
+        return Failure::make(NAFGPU_E_DEVICE, "tile read-back failed");
+    f = check(stream);                                                     // synchronises
+    if (!f.ok()) return f;
+    tile_len_ = total - halo_elems_;
+    if (n_seq_blocks_) {
+        for (int k = 0; k < 3; k++) rep_carry_[k] = rep[k];
+        carry_frame_ = plan_.last_seq_frame;
+    }
+    tiles_done_ = t + 1;
+    if (tile_pos0_ + tile_len_ > out1_ || (tiles_done_ == tiles_.size() && tile_pos0_ + tile_len_ != out1_))
+        return Failure::io(NAFGPU_IO_INVALID_DATA, status_text(kStSizeMismatch));
+    return Failure();
+}
+
+// Device address of the loaded selection's local position 0 (its pseudo block when it has one): kernels
+// address the output as base + blk_base[block] + offset inside the block.
+uint8_t *SectionJob::tile_out_base() const {
+    const uint64_t mult = t_char_ ? 2 : 1;
+    if (tiled_output()) return d_out_.bytes() + (halo_cap_ - halo_elems_) * mult;
+    return d_out_.bytes() + (tile_pos0_ - halo_elems_ - out0_) * mult;
+}
+
+const uint8_t *SectionJob::tile_data() const {
+    const uint64_t mult = t_char_ ? 2 : 1;
+    return tile_out_base() + halo_elems_ * mult;
 }
 
 SectionJob::~SectionJob() {
@@ -203,11 +373,15 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
         if (timer) timer->end(stream);
     }
     if (timer) timer->begin(stream, StageTimer::kOther);
+    // total of the selection's block sizes: known for the whole section and for ranges without LZ sequences; a tile
+    // of a section with sequences is added up by the host (decode_tile)
+    const uint64_t expect_sel = tiles_.size() == 1 && !sharded_ ? expect_
+                                : (!has_lz_ ? halo_elems_ + plan_.known_out : ~0ull);
     launch_scan_blocks(stream, d_blk_size_.as<uint32_t>(), n_blocks_, d_blk_base_.as<uint64_t>(), d_scan_tmp_.bytes(),
-                       expect_, status);
+                       expect_sel, status);
     const bool ascii = t_char_ != 0;
-    // kernels address the section output as out + position; a shard holds positions [out0_, out1_)
-    uint8_t *const out_base = d_out_.bytes() - out0_ * (ascii ? 2 : 1);
+    // kernels address the output as base + position inside the loaded selection
+    uint8_t *const out_base = tile_out_base();
     launch_copy_fill(stream, d_src_, d_copies_.as<CopyTask>(), static_cast<uint32_t>(n_copies_),
                      d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(), ascii, t_char_, status);
     if (timer) timer->end(stream);
@@ -248,13 +422,18 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
         la.blocks = d_seq_blocks_.as<SeqBlock>();
         la.n_blocks = static_cast<uint32_t>(n_seq_blocks_);
         la.n_sequences = plan_.n_sequences;
-        la.n_elems = expect_;
+        la.n_elems = tiles_.size() == 1 ? expect_ : halo_elems_ + static_cast<uint64_t>(n_blocks_ - plan_.halo) * kBlockMax;   // (tile: an upper bound)
         la.seqs = d_seqs_.as<Seq>();
         la.lit = d_lit_.bytes();
         la.blk_base = d_blk_base_.as<uint64_t>();
         la.rep_final = d_rep_final_.as<uint32_t>();
         la.rep_init = d_rep_init_.as<uint32_t>();
         la.rep_scratch = d_rep_scratch_.as<uint32_t>();
+        // repeat offsets in front of the first block: the frame's initial ones, or what the tile before left behind
+        const bool continues = plan_.first_frame_continues && loaded_tile_ > 0 && carry_same_frame_;
+        la.rep_continues = plan_.first_frame_continues ? 1u : 0u;
+        for (int k = 0; k < 3; k++) la.rep_carry[k] = continues ? rep_carry_[k] : (k == 0 ? 1u : (k == 1 ? 4u : 8u));
+        la.rep_out = reinterpret_cast<uint32_t *>(d_counters_.bytes() + 64);
         la.meta = d_meta_.as<SeqMeta>();
         la.blk_pending = d_blk_pending_.as<uint32_t>();
         la.out = out_base;
@@ -264,13 +443,14 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
         // Dense or sparse?  Where the matches are a good part of the output (level-3 DNA, quality strings) the frame is
         // swept element by element (one word of scratch per output element, allocated on the first run and kept);
         // a handful of matches in gigabytes of literals (real genomes at level 1) are visited one by one.
-        const uint64_t match_elems = expect_ > plan_.known_out ? expect_ - plan_.known_out : 0;   // known_out = everything but the match bytes
+        const uint64_t sec_known = sec_known_, sec_seqs = sec_seqs_;                            // (the whole section's figures: every tile decides alike)
+        const uint64_t match_elems = expect_ > sec_known ? expect_ - sec_known : 0;             // known_out = everything but the match bytes
         const char *force = std::getenv("NAFGPU_LZ_MODE");                                      // tests: "dense" / "sparse"
-        bool dense = plan_.n_sequences >= 4096 && match_elems * 2 >= expect_;                      // (level-3 DNA, a quarter of it matches at random
+        bool dense = sec_seqs >= 4096 && match_elems * 2 >= expect_;                      // (level-3 DNA, a quarter of it matches at random
                                                                                                    //  distances, is faster match by match: 38 against 46 ms)
         if (force) dense = force[0] == 'd';
         lz_dense_ = false;
-        if (dense && d_pj_dist_.alloc_items(expect_, sizeof(uint32_t), 64) && d_pj_tiles_.alloc_items(lz_pj_tiles(expect_), sizeof(uint32_t), 64)) {
+        if (dense && d_pj_dist_.alloc_items(la.n_elems, sizeof(uint32_t), 64) && d_pj_tiles_.alloc_items(lz_pj_tiles(la.n_elems), sizeof(uint32_t), 64)) {
             la.pj_dist = d_pj_dist_.as<uint32_t>();
             la.pj_tiles = d_pj_tiles_.as<uint32_t>();
             lz_dense_ = true;
@@ -284,15 +464,23 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
             la.roff = d_roff_.alloc_items(plan_.n_sequences, sizeof(uint32_t), 16) ? d_roff_.as<uint32_t>() : nullptr;
             // the index of "first sequence at or after every 128th element" pays when sequences are everywhere; a few
             // thousand sequences in gigabytes of output are found by binary search
-            const bool index = plan_.n_sequences < 0xFFFFFFFFull && plan_.n_sequences * 1024 >= expect_ &&
-                               d_lz_index_.alloc_items((expect_ >> 7) + 2, sizeof(uint32_t));
+            const bool index = plan_.n_sequences < 0xFFFFFFFFull && plan_.n_sequences * 1024 >= la.n_elems &&
+                               d_lz_index_.alloc_items((la.n_elems >> 7) + 2, sizeof(uint32_t));
             la.cidx = index ? d_lz_index_.as<uint32_t>() : nullptr;
-            la.n_idx_chunks = (static_cast<uint64_t>(expect_) >> 7) + 2;
+            la.n_idx_chunks = (la.n_elems >> 7) + 2;
             if (!la.roff) {                                    // (cannot happen short of a device out of memory: flag the section)
                 (void)hipMemsetAsync(status, 0xFF, 4, stream);
             }
         }
         if (la.pj_dist || la.roff) launch_lz_execute(stream, la, ascii);
+        if (timer) timer->end(stream);
+    }
+    if (!xxh_segs_.empty()) {                                  // Content_Checksum of the frames that carry one
+        if (timer) timer->begin(stream, StageTimer::kOther);
+        XxhCarry *carry = d_xxh_carry_.as<XxhCarry>();
+        const uint32_t t = loaded_tile_ & 1u;
+        launch_xxh64_frames(stream, d_xxh_segs_.as<XxhSeg>(), static_cast<uint32_t>(xxh_segs_.size()), d_blk_base_.as<uint64_t>(),
+                            out_base, ascii, t_char_, carry + t, carry + (t ^ 1u), status);
         if (timer) timer->end(stream);
     }
 }
@@ -349,16 +537,10 @@ Failure ArchiveJob::upload(const uint8_t *bytes, size_t n, const nafgpu_header &
     h_ = h;
     opt_ = opt;
     is_nuc_ = h.sequence_type <= 1;
-    // ---- archive bytes -> HBM, once
+    // ---- per section: host walk, then the compressed bytes of this process's block range (and only those: the
+    // container header, sections that are switched off and the other ranks' shards never cross the bus) and the
+    // task lists go to HBM
     const double t0 = now_ms();
-    if (!d_archive_.alloc(kSrcFrontPad + n + kSrcBackPad)) return Failure::make(NAFGPU_E_DEVICE, "out of device memory");
-    (void)hipMemsetAsync(d_archive_.bytes(), 0, kSrcFrontPad, stream_);
-    (void)hipMemsetAsync(d_archive_.bytes() + kSrcFrontPad + n, 0, kSrcBackPad, stream_);
-    if (n && !hip_ok(hipMemcpyAsync(d_archive_.bytes() + kSrcFrontPad, bytes, n, hipMemcpyHostToDevice, stream_)))
-        return Failure::make(NAFGPU_E_DEVICE, "archive upload failed");
-    if (!hip_ok(hipStreamSynchronize(stream_))) return Failure::make(NAFGPU_E_DEVICE, "archive upload failed");
-    h2d_ms_ = static_cast<float>(now_ms() - t0);
-    // ---- per-section host plan + task upload
     plan_ms_ = 0;
     compressed_ = 0;
     for (int s = 0; s < kNumSections; s++) {
@@ -370,15 +552,22 @@ Failure ArchiveJob::upload(const uint8_t *bytes, size_t n, const nafgpu_header &
         }
         uint64_t expect = sec[s].original_size;
         if (s == kSequence && is_nuc_) expect = (expect + 1) / 2;     // nucleotides -> packed bytes
-        const uint32_t t_char = (s == kSequence && is_nuc_) ? (h.sequence_type == 1 ? 'U' : 'T') : 0;
-        const bool shard_this = s == kSequence && opt.shard_count > 1;
-        fail_[s] = job_[s].prepare(bytes + sec[s].offset, static_cast<size_t>(sec[s].compressed_size), expect,
-                                   d_archive_.bytes() + kSrcFrontPad + sec[s].offset, stream_, t_char,
-                                   shard_this ? opt.shard_rank : 0, shard_this ? opt.shard_count : 1);
+        SectionOptions so;
+        so.t_char = (s == kSequence && is_nuc_) ? (h.sequence_type == 1 ? 'U' : 'T') : 0;
+        if (s == kSequence && opt.shard_count > 1) {
+            so.shard_rank = opt.shard_rank;
+            so.shard_count = opt.shard_count;
+        }
+        if (s == kSequence || s == kQuality) {                        // the two sections that can be large
+            so.tile_blocks = opt.tile_blocks;
+            so.tiled_output = opt.tiled_output;
+        }
+        fail_[s] = job_[s].prepare(bytes + sec[s].offset, static_cast<size_t>(sec[s].compressed_size), expect, stream_, so);
         plan_ms_ += job_[s].host_plan_ms();
         if (fail_[s].status == NAFGPU_E_DEVICE) return fail_[s];
-        if (fail_[s].ok()) compressed_ += sec[s].compressed_size;
+        if (fail_[s].ok()) compressed_ += job_[s].n_tiles() == 1 ? job_[s].source_bytes() : sec[s].compressed_size;
     }
+    h2d_ms_ = std::max(0.0f, static_cast<float>(now_ms() - t0) - plan_ms_);
     // ---- derived tables
     bool ok = d_totals_.alloc(8 * sizeof(ScanTotals)) && d_status_.alloc(64) && d_hash_.alloc(16);
     // The iterator never hands out more strings than records, and a section holds no more NULs than bytes:
@@ -435,7 +624,25 @@ Failure ArchiveJob::decode() {
         scans(aux_stream_);
         (void)hipEventRecord(ev_join_, aux_stream_);
     }
-    for (int s = kMask + 1; s < kNumSections; s++) job_[s].run(stream_, &timer_, aux_stream_);
+    // The sequence and quality sections: one resident tile each (kernels only), or tile after tile -- all of them
+    // now when the whole output is resident, the first one when the output is held a tile at a time (the
+    // iterator asks for the next ones, advance_tile).
+    for (int s = kMask + 1; s < kNumSections; s++) {
+        if (!job_[s].ready()) continue;
+        if (job_[s].n_tiles() == 1) {
+            job_[s].run(stream_, &timer_, aux_stream_);
+            continue;
+        }
+        const uint32_t upto = job_[s].tiled_output() ? 1u : job_[s].n_tiles();
+        for (uint32_t t = 0; t < upto; t++) {
+            Failure f = job_[s].decode_tile(t, stream_, &timer_, aux_stream_);
+            if (f.status == NAFGPU_E_DEVICE) return f;
+            if (!f.ok()) {
+                fail_[s] = f;
+                break;
+            }
+        }
+    }
     timer_.begin(stream_, StageTimer::kOther);
     if (scans_forked)
         (void)hipStreamWaitEvent(stream_, ev_join_, 0);
@@ -443,14 +650,8 @@ Failure ArchiveJob::decode() {
         scans(stream_);
     // (nucleotide sequence sections come out of their SectionJob already expanded to ASCII:
     //  SequenceReader::read_nucleotide, reader.rs:121-172, is fused into the zstd kernels)
-    if (want_mask) {                                               // mod.rs:386-388, 402-441
-        const uint64_t mult = is_nuc_ ? 2 : 1;
-        const uint64_t lo = job_[kSequence].shard_out0() * mult, hi = job_[kSequence].shard_out1() * mult;   // bases held here
-        uint8_t *seq = job_[kSequence].out_mut() - lo;         // addressed by global base index
-        const uint64_t n_all = is_nuc_ ? mask_total_bases_ : std::min<uint64_t>(mask_total_bases_, job_[kSequence].total_size());
-        launch_mask_apply(stream_, seq, n_all, lo, hi, d_mask_ends_.as<uint64_t>(), &totals[1], d_rec_ends_.as<uint64_t>(),
-                          &totals[0], mask_cap_, opt_.spec_mask ? 1 : 0, status);
-    }
+    want_mask_ = want_mask;
+    if (want_mask) apply_mask_to_held();                           // mod.rs:386-388, 402-441
     timer_.end(stream_);
     // ids / comments: CStringReader (reader.rs:22-30) as a scan; UTF-8 validity of every text section
     // (into_string().expect at mod.rs:362,368; from_utf8 at reader.rs:108-109) as one flag word
@@ -466,8 +667,11 @@ Failure ArchiveJob::decode() {
                         d_scan_tmp_.bytes(), &totals[3], status);
         launch_utf8_check(stream_, job_[kComments].out(), job_[kComments].size(), utf8, kComments);
     }
-    if (job_[kSequence].ready() && !is_nuc_) launch_utf8_check(stream_, job_[kSequence].out(), job_[kSequence].size(), utf8, kSequence);
-    if (job_[kQuality].ready()) launch_utf8_check(stream_, job_[kQuality].out(), job_[kQuality].size(), utf8, kQuality);
+    // (sections whose output is held a tile at a time are validated record by record by the iterator instead)
+    if (job_[kSequence].ready() && !is_nuc_ && !job_[kSequence].tiled_output())
+        launch_utf8_check(stream_, job_[kSequence].out(), job_[kSequence].size(), utf8, kSequence);
+    if (job_[kQuality].ready() && !job_[kQuality].tiled_output())
+        launch_utf8_check(stream_, job_[kQuality].out(), job_[kQuality].size(), utf8, kQuality);
     timer_.end(stream_);
     timer_.mark_total_end(stream_);
     ScanTotals host_totals[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
@@ -482,10 +686,48 @@ Failure ArchiveJob::decode() {
     com_totals_ = host_totals[3];
     times_ = timer_.collect();
     for (int s = 0; s < kNumSections; s++) {
-        if (!job_[s].ready()) continue;
+        if (!job_[s].ready() || job_[s].n_tiles() > 1) continue;   // (tiles were checked one by one)
         Failure f = job_[s].check(stream_);
         if (f.status == NAFGPU_E_DEVICE) return f;
         if (!f.ok()) fail_[s] = f;
+    }
+    return Failure();
+}
+
+// Lower-cases the masked runs inside the part of the sequence that is in HBM right now: this process's whole
+// range, or the tile just decoded.
+void ArchiveJob::apply_mask_to_held() {
+    const SectionJob &j = job_[kSequence];
+    const uint64_t mult = is_nuc_ ? 2 : 1;
+    uint64_t lo, hi;
+    uint8_t *seq;
+    if (j.tiled_output()) {
+        lo = j.tile_pos0() * mult;
+        hi = (j.tile_pos0() + j.tile_len()) * mult;
+        seq = const_cast<uint8_t *>(j.tile_data()) - lo;           // addressed by global base index
+    } else {
+        lo = j.shard_out0() * mult;
+        hi = j.shard_out1() * mult;
+        seq = j.out_mut() - lo;
+    }
+    const uint64_t n_all = is_nuc_ ? mask_total_bases_ : std::min<uint64_t>(mask_total_bases_, j.total_size());
+    launch_mask_apply(stream_, seq, n_all, lo, hi, d_mask_ends_.as<uint64_t>(), &d_totals_.as<ScanTotals>()[1], d_rec_ends_.as<uint64_t>(),
+                      &d_totals_.as<ScanTotals>()[0], mask_cap_, opt_.spec_mask ? 1 : 0, d_status_.as<uint32_t>());
+}
+
+// The iterator has consumed the tile section s holds: decode the next one into its place.
+Failure ArchiveJob::advance_tile(int s) {
+    (void)hipSetDevice(device_);
+    SectionJob &j = job_[s];
+    if (!j.ready() || !j.tiled_output() || j.tiles_done() >= j.n_tiles()) return Failure::make(NAFGPU_E_INVALID_ARG, "no tile left");
+    Failure f = j.decode_tile(j.tiles_done(), stream_, nullptr, aux_stream_);
+    if (!f.ok()) {
+        if (f.status != NAFGPU_E_DEVICE) fail_[s] = f;
+        return f;
+    }
+    if (s == kSequence && want_mask_) {
+        apply_mask_to_held();
+        if (!hip_ok(hipStreamSynchronize(stream_))) return Failure::make(NAFGPU_E_DEVICE, "mask application failed");
     }
     return Failure();
 }
@@ -499,6 +741,8 @@ Failure ArchiveJob::format_text(bool with_ids, bool with_comments, bool with_qua
     if (!job_[kSequence].ready() || !job_[kLengths].ready())
         return Failure::make(NAFGPU_E_INVALID_ARG, "text output needs the Sequence and Length sections");
     if (job_[kSequence].sharded()) return Failure::make(NAFGPU_E_INVALID_ARG, "text output is not available on a shard");
+    if (job_[kSequence].tiled_output() || job_[kQuality].tiled_output())
+        return Failure::make(NAFGPU_E_INVALID_ARG, "text output needs the whole sequence in HBM (tiled output is for the record iterator)");
     n_rec = std::min<uint64_t>(n_rec, rec_totals_.count);
     if (n_rec == 0) return Failure();
     FmtText t{};

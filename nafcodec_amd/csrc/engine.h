@@ -75,58 +75,95 @@ private:
     bool open_ = false;
 };
 
-// One Zstandard-compressed NAF section resident on the device.
+// How one section is cut up: which block range this process decodes (multi-GPU shards) and in how many
+// pieces (tiles), so that neither the compressed bytes nor the scratch memory -- nor, on the iterator
+// path, the output -- have to be resident whole.
+struct SectionOptions {
+    uint32_t t_char = 0;             // != 0: nucleotide sequence section -- every byte bound for the section output is expanded to its
+                                     // two IUPAC characters on the way ('T' / 'U' for code 1); the packed form never exists in HBM
+    uint32_t shard_rank = 0, shard_count = 1;   // decode only this rank's contiguous block range (sections without LZ sequences)
+    uint64_t tile_blocks = 0;        // > 0: decode in tiles of at most this many zstd blocks
+    bool tiled_output = false;       // the output buffer holds ONE tile (and the LZ window in front of it) at a time
+};
+
+// One Zstandard-compressed NAF section on the device.
 class SectionJob {
 public:
     SectionJob() = default;
     SectionJob(const SectionJob &) = delete;
     SectionJob &operator=(const SectionJob &) = delete;
     ~SectionJob();
-    // Walks the payload on the host (zplan), allocates HBM, uploads the task lists.
-    // d_payload points at the same bytes in device memory (>= 256 B readable in front, 64 behind).
-    // ascii_t_char != 0: nucleotide sequence section -- every byte bound for the section output is
-    // expanded to its two IUPAC characters on the way ('T' / 'U' for code 1); out() then holds
-    // 2 * size() ASCII bytes and the packed form never exists in HBM.
-    // shard_count > 1: decode only this rank's contiguous block range (see build_zplan); out() then
-    // holds decoded bytes [shard_out0(), shard_out1()) of the section.
-    Failure prepare(const uint8_t *host_payload, size_t n, uint64_t expect_size, const uint8_t *d_payload,
-                    hipStream_t stream, uint32_t ascii_t_char = 0, uint32_t shard_rank = 0, uint32_t shard_count = 1);
-    // Enqueues the decode kernels.  Results: out() holds size() bytes once the stream is done.
+    // Walks the payload on the host (zplan), chooses the block range and the tiles, allocates the output.
+    // One tile (the usual case): its compressed bytes and task lists are uploaded here and stay resident --
+    // run() then only enqueues kernels.  Several tiles: each is uploaded when it is decoded (decode_tile).
+    Failure prepare(const uint8_t *host_payload, size_t n, uint64_t expect_size, hipStream_t stream, const SectionOptions &opt);
+    // Enqueues the decode kernels of the resident tile.  Results: out() holds size() bytes once the stream is done.
     // aux: a second stream (or null) on which the literal-buffer Huffman tasks run beside the direct ones
     void run(hipStream_t stream, StageTimer *timer, hipStream_t aux = nullptr);
     // After synchronisation: device status -> Failure
     Failure check(hipStream_t stream);
+    // Tiles: uploads tile t (they are decoded in order), decodes it, synchronises, keeps what the next one needs
+    // (repeat offsets, position, the LZ window).  Tile t's output then is tile_data() .. + tile_len() elements.
+    uint32_t n_tiles() const { return static_cast<uint32_t>(tiles_.size()); }
+    Failure decode_tile(uint32_t t, hipStream_t stream, StageTimer *timer, hipStream_t aux = nullptr);
+    uint32_t tiles_done() const { return tiles_done_; }
+    uint64_t tile_pos0() const { return tile_pos0_; }             // decoded-byte position (in the section) of the loaded tile's first byte
+    uint64_t tile_len() const { return tile_len_; }               // decoded bytes of the loaded tile (known once it is decoded)
+    const uint8_t *tile_data() const;                             // device address of the loaded tile's first output byte
 
     const uint8_t *out() const { return d_out_.bytes(); }
     uint8_t *out_mut() const { return d_out_.bytes(); }
-    uint64_t size() const { return out1_ - out0_; }                 // decoded zstd bytes held (the whole section unless sharded)
+    uint64_t size() const { return out1_ - out0_; }                 // decoded zstd bytes of this process's range (the whole section unless sharded)
     uint64_t total_size() const { return expect_; }                 // decoded zstd bytes of the whole section
     uint64_t shard_out0() const { return out0_; }
     uint64_t shard_out1() const { return out1_; }
-    bool sharded() const { return plan_.sharded; }
-    uint64_t out_bytes() const { return size() * (t_char_ ? 2 : 1); }   // bytes behind out()
+    bool sharded() const { return sharded_; }
+    bool tiled_output() const { return opt_.tiled_output && tiles_.size() > 1; }
+    uint64_t out_bytes() const { return size() * (t_char_ ? 2 : 1); }   // bytes behind out() in whole-output mode
     bool ascii() const { return t_char_ != 0; }
     bool ready() const { return ready_; }
     const ZPlan &plan() const { return plan_; }
-    uint64_t n_blocks() const { return n_blocks_; }
-    uint64_t n_streams() const { return n_streams_; }
+    uint64_t n_blocks() const { return master_blocks_; }
+    uint64_t n_streams() const { return master_streams_; }
     float host_plan_ms() const { return plan_ms_; }
     uint64_t lz_residue() const { return lz_residue_; }
+    uint64_t source_bytes() const { return src_resident_; }       // compressed bytes uploaded for the resident tile
 
 private:
-    ZPlan plan_;
+    struct Tile {
+        uint32_t b0, b1;
+    };
+    Failure load_tile(uint32_t t, hipStream_t stream);
+    uint8_t *tile_out_base() const;                               // address of the loaded selection's local position 0
+    ZPlan master_, plan_;                                         // the walk; the loaded tile's launchable plan
+    std::vector<Tile> tiles_;
+    SectionOptions opt_;
+    const uint8_t *host_payload_ = nullptr;
+    uint32_t loaded_tile_ = 0xFFFFFFFFu, tiles_done_ = 0;
+    uint64_t tile_pos0_ = 0, tile_len_ = 0, halo_elems_ = 0, halo_cap_ = 0, tile_cap_ = 0;
+    uint32_t rep_carry_[3] = {1, 4, 8};
+    uint32_t carry_frame_ = 0xFFFFFFFFu;                          // master frame (its first block) of the last block with sequences decoded so far
+    bool carry_same_frame_ = false;                               // ... and the loaded tile's first block with sequences belongs to it
+    bool has_lz_ = false;                                         // the section has blocks with LZ sequences
+    uint64_t sec_known_ = 0, sec_seqs_ = 0;                       // the whole section: decoded bytes that are not match bytes; sequences
     uint64_t lz_residue_ = 0;
     uint64_t out0_ = 0, out1_ = 0;
     uint64_t expect_ = 0, n_blocks_ = 0, n_streams_ = 0, n_tasks_ = 0, n_copies_ = 0, n_seq_blocks_ = 0;
+    uint64_t master_blocks_ = 0, master_streams_ = 0, src_resident_ = 0;
     std::vector<HufClass> classes_;
     uint32_t t_char_ = 0;
+    bool sharded_ = false;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;   // K1 on two streams (created on first use, destroyed with the job)
-    const uint8_t *d_src_ = nullptr;
+    const uint8_t *d_src_ = nullptr;                     // device address of payload offset 0 (only [src_lo, src_hi) of the tile is behind it)
     float plan_ms_ = 0;
     bool ready_ = false;
-    DevBuf d_out_, d_lit_, d_seqs_, d_blk_size_, d_blk_base_, d_scan_tmp_, d_status_;
+    DevBuf d_src_buf_, d_out_, d_lit_, d_seqs_, d_blk_size_, d_blk_base_, d_scan_tmp_, d_status_;
     DevBuf d_meta_, d_rep_final_, d_rep_init_, d_rep_scratch_, d_lz_index_, d_blk_pending_, d_roff_, d_counters_;
     DevBuf d_lz_list_[2];
+    DevBuf d_halo_tmp_;
+    std::vector<XxhSeg> xxh_segs_;                // frame checksums: the (pieces of) checksummed frames in the loaded tile
+    bool xxh_live_ = false;                       // ... and whether the frame the next tile continues was begun in this process's range
+    DevBuf d_xxh_segs_, d_xxh_carry_;
     DevBuf d_pj_dist_, d_pj_tiles_;               // dense LZ sections: one word per output element + one per tile (allocated on first use, kept)
     bool lz_dense_ = false;
     DevBuf d_streams_, d_tasks_, d_tbl_copies_, d_pool_, d_dicts_, d_copies_, d_seq_blocks_, d_cells_;
@@ -136,6 +173,8 @@ struct ArchiveOptions {
     bool want[kNumSections] = {true, true, true, true, true, true};
     bool spec_mask = false;
     uint32_t shard_rank = 0, shard_count = 1;   // block-range sharding of the sequence section
+    uint64_t tile_blocks = 0;                   // > 0: sequence / quality sections are decoded in tiles of at most this many zstd blocks
+    bool tiled_output = false;                  // ... whose output is held one tile at a time (iterator path; not for decode_all_device)
 };
 
 // A whole archive on one GPU: sections -> record table -> ASCII bases.
@@ -148,6 +187,9 @@ public:
                    const ArchiveOptions &opt);
     // (re)runs every kernel; synchronises; fills times
     Failure decode();
+    // output held a tile at a time (iterator path): decodes the next tile of section s into the tile buffer
+    Failure advance_tile(int s);
+    SectionJob &job_mut(int s) { return job_[s]; }
 
     // device results (valid after decode())
     const uint8_t *d_sequence() const;       // ASCII (nucleotides) or text
@@ -191,7 +233,8 @@ private:
     nafgpu_header h_{};
     ArchiveOptions opt_;
     bool is_nuc_ = false;
-    DevBuf d_archive_;
+    void apply_mask_to_held();
+    bool want_mask_ = false;
     SectionJob job_[kNumSections];
     Failure fail_[kNumSections];
     DevBuf d_rec_ends_, d_mask_ends_, d_scan_tmp_, d_totals_, d_status_, d_hash_;

@@ -91,6 +91,9 @@ struct LzArgs {
     const uint64_t *blk_base;
     const uint32_t *rep_final;   // 3 per block, from k_seq_decode
     uint32_t *rep_init;          // 3 per block
+    uint32_t rep_carry[3];       // repeat offsets in front of the first block ({1, 4, 8} unless a tile in front left others)
+    uint32_t rep_continues;      // 1: the first block continues a frame begun in front of this tile (no reset to {1, 4, 8})
+    uint32_t *rep_out;           // 3 words: the repeat offsets behind the last block
     uint32_t *rep_scratch;       // 6 words per chunk of 64 blocks (k_rep_partial / k_rep_scan)
     uint32_t *cidx;              // sparse: sequence index per 128 output elements (null: plain binary search)
     uint64_t n_idx_chunks;       // entries of cidx
@@ -118,6 +121,12 @@ void launch_mask_apply(hipStream_t stream, uint8_t *ascii, uint64_t n_bases, uin
                        const uint64_t *mask_ends, const ScanTotals *mask_totals, const uint64_t *rec_ends,
                        const ScanTotals *rec_totals,
                        uint64_t max_runs, int spec_mask, uint32_t *status);
+
+// Content_Checksum of the frames (pieces of frames) in `segs`: XXH64 over the decoded bytes at out + blk_base[..]
+// (ascii: the section output holds two characters per decoded byte, packed again on the fly); a mismatch flags
+// kStChecksum.  carry_in / carry_out: running state of a frame that spans tiles.
+void launch_xxh64_frames(hipStream_t stream, const XxhSeg *segs, uint32_t n_segs, const uint64_t *blk_base, const uint8_t *out,
+                         bool ascii, uint32_t t_char, const XxhCarry *carry_in, XxhCarry *carry_out, uint32_t *status);
 
 // order-sensitive checksum of a device buffer (see hash64.h); *result must be zeroed first.
 // first_chunk: index of the buffer's first 4 KiB chunk in the whole object (shards add up)

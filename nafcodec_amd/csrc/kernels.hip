@@ -1087,7 +1087,7 @@ __global__ void k_scan_finish_blocks(uint64_t *blk_base, uint64_t n, const ScanT
                                      uint32_t *status) {
     if (status[0] != 0) return;
     blk_base[n] = totals->sum;
-    if (totals->sum != expect) flag_error(status, kStSizeMismatch, 0xFFFFFFFFu);
+    if (expect != ~0ull && totals->sum != expect) flag_error(status, kStSizeMismatch, 0xFFFFFFFFu);   // (~0: a tile of a section with sequences -- the host adds the tiles up)
 }
 
 // ======================================================================================
@@ -1402,14 +1402,17 @@ __device__ inline uint32_t rep_apply_entry(uint32_t tok, const uint32_t *f, bool
     return (fv & 0xFF000000u) | (d2 & 0xFFFFFFu);
 }
 
+// (continues: the first block goes on with a frame begun in front of this tile -- its repeat offsets are the
+//  ones carried over, not {1, 4, 8})
 __global__ __launch_bounds__(256) void k_rep_partial(const SeqBlock *__restrict__ blocks, uint32_t n_blocks,
-                                                     const uint32_t *__restrict__ rep_final, uint32_t *partial, uint32_t *status) {
+                                                     const uint32_t *__restrict__ rep_final, uint32_t *partial, uint32_t continues,
+                                                     uint32_t *status) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     const uint32_t b0 = t * kRepChunk;
     if (status[0] != 0 || b0 >= n_blocks) return;
     const uint32_t b1 = b0 + kRepChunk < n_blocks ? b0 + kRepChunk : n_blocks;
     uint32_t cur[3] = {kRepToken | (0u << 24), kRepToken | (1u << 24), kRepToken | (2u << 24)};   // identity
-    uint32_t frame = b0 ? blocks[b0 - 1].frame_first_blk : 0xFFFFFFFFu;
+    uint32_t frame = b0 ? blocks[b0 - 1].frame_first_blk : (continues ? blocks[0].frame_first_blk : 0xFFFFFFFFu);
     bool bad = false;
     for (uint32_t b = b0; b < b1; b++) {
         if (blocks[b].frame_first_blk != frame) {
@@ -1431,9 +1434,10 @@ __global__ __launch_bounds__(256) void k_rep_partial(const SeqBlock *__restrict_
     if (bad) flag_error(status, kStBadOffset, 0xFFFFFFFEu);
 }
 
-__global__ void k_rep_scan(uint32_t n_chunks, const uint32_t *__restrict__ partial, uint32_t *chunk_init, uint32_t *status) {
+__global__ void k_rep_scan(uint32_t n_chunks, const uint32_t *__restrict__ partial, uint32_t *chunk_init, uint32_t c0, uint32_t c1,
+                           uint32_t c2, uint32_t *status) {
     if (status[0] != 0 || blockIdx.x != 0 || threadIdx.x != 0) return;
-    uint32_t cur[3] = {1, 4, 8};
+    uint32_t cur[3] = {c0, c1, c2};                        // {1, 4, 8}, or what the tile in front left behind
     bool bad = false;
     for (uint32_t t = 0; t < n_chunks; t++) {
         chunk_init[3 * t + 0] = cur[0];
@@ -1451,13 +1455,13 @@ __global__ void k_rep_scan(uint32_t n_chunks, const uint32_t *__restrict__ parti
 
 __global__ __launch_bounds__(256) void k_rep_apply(const SeqBlock *__restrict__ blocks, uint32_t n_blocks,
                                                    const uint32_t *__restrict__ rep_final, const uint32_t *__restrict__ chunk_init,
-                                                   uint32_t *rep_init, uint32_t *status) {
+                                                   uint32_t *rep_init, uint32_t continues, uint32_t *rep_out, uint32_t *status) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     const uint32_t b0 = t * kRepChunk;
     if (status[0] != 0 || b0 >= n_blocks) return;
     const uint32_t b1 = b0 + kRepChunk < n_blocks ? b0 + kRepChunk : n_blocks;
     uint32_t cur[3] = {chunk_init[3 * t], chunk_init[3 * t + 1], chunk_init[3 * t + 2]};
-    uint32_t frame = b0 ? blocks[b0 - 1].frame_first_blk : 0xFFFFFFFFu;
+    uint32_t frame = b0 ? blocks[b0 - 1].frame_first_blk : (continues ? blocks[0].frame_first_blk : 0xFFFFFFFFu);
     bool bad = false;
     for (uint32_t b = b0; b < b1; b++) {
         if (blocks[b].frame_first_blk != frame) {        // repeat offsets restart with each frame
@@ -1475,6 +1479,11 @@ __global__ __launch_bounds__(256) void k_rep_apply(const SeqBlock *__restrict__ 
         cur[0] = n0;
         cur[1] = n1;
         cur[2] = n2;
+    }
+    if (b1 == n_blocks) {                                  // what the next tile starts from
+        rep_out[0] = cur[0];
+        rep_out[1] = cur[1];
+        rep_out[2] = cur[2];
     }
     if (bad) flag_error(status, kStBadOffset, 0xFFFFFFFEu);
 }
@@ -2290,6 +2299,155 @@ __global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_b
 }
 
 // ======================================================================================
+// frame checksums
+// ======================================================================================
+// Content_Checksum (RFC 8878 3.1.1): the low 32 bits of XXH64 (seed 0) of everything the frame decodes to, which
+// the reference's zstd decoder verifies as it reaches the end of the frame (mod.rs:221-222 builds that decoder;
+// a mismatch surfaces as Io(InvalidData)).  XXH64 is four serial multiply-rotate chains over the 32-byte stripes
+// of the frame: one workgroup per frame piece, all 64 lanes stage a chunk of 32 stripes (packing the characters
+// of a nucleotide section back into the bytes they came from) and pre-multiply it, lanes 0-3 run the chains.
+// About 0.5 GB/s per frame: archives written by `ennaf` or the reference's encoder carry no checksum, those that
+// do are verified in full, frames side by side.
+constexpr uint64_t kXxhP1 = 11400714785074694791ull, kXxhP2 = 14029467366897019727ull, kXxhP3 = 1609587929392839161ull,
+                   kXxhP4 = 9650029242287828579ull, kXxhP5 = 2870177450012600261ull;
+__device__ inline uint64_t rotl64(uint64_t x, uint32_t r) { return (x << r) | (x >> (64u - r)); }
+__device__ inline uint64_t xxh_round(uint64_t acc, uint64_t prod) { return rotl64(acc + prod, 31) * kXxhP1; }   // prod = input * P2
+
+__global__ __launch_bounds__(64) void k_xxh64_frames(const XxhSeg *__restrict__ segs, const uint64_t *__restrict__ blk_base,
+                                                      const uint8_t *__restrict__ out, uint32_t ascii, uint32_t t_char,
+                                                      const XxhCarry *__restrict__ carry_in, XxhCarry *__restrict__ carry_out,
+                                                      uint32_t *status) {
+    __shared__ uint64_t s_prod[2][128];
+    __shared__ XxhCarry s_c;
+    __shared__ uint8_t s_inv[256];               // character -> 4-bit code
+    const uint32_t lane = threadIdx.x;
+    const XxhSeg seg = segs[blockIdx.x];
+    uint64_t a = blk_base[seg.blk0];
+    const uint64_t b = blk_base[seg.blk1];
+    for (uint32_t k = lane; k < 256; k += 64) s_inv[k] = 0;
+    __syncthreads();
+    if (ascii && lane < 16) s_inv[nib_char(lane, t_char)] = static_cast<uint8_t>(lane);
+    if (lane == 0) {
+        if (seg.flags & 1u) {
+            s_c.v[0] = kXxhP1 + kXxhP2;
+            s_c.v[1] = kXxhP2;
+            s_c.v[2] = 0;
+            s_c.v[3] = 0ull - kXxhP1;
+            s_c.total = 0;
+            s_c.n_mem = 0;
+        } else {
+            s_c = *carry_in;
+        }
+    }
+    __syncthreads();
+    auto byte_at = [&](uint64_t pos) -> uint8_t {   // decoded byte `pos` of the loaded selection
+        if (!ascii) return out[pos];
+        return static_cast<uint8_t>(s_inv[out[2 * pos]] | (s_inv[out[2 * pos + 1]] << 4));
+    };
+    uint64_t acc = s_c.v[lane & 3u];
+    const uint64_t n_new = b - a;
+    uint32_t n_mem = s_c.n_mem;
+    if (n_mem) {                                 // finish the stripe the tile before left open
+        const uint32_t take = static_cast<uint32_t>(n_new < 32u - n_mem ? n_new : 32u - n_mem);
+        if (lane < take) s_c.mem[n_mem + lane] = byte_at(a + lane);
+        __syncthreads();
+        a += take;
+        n_mem += take;
+        if (n_mem == 32) {
+            if (lane < 4) {
+                uint64_t w;
+                __builtin_memcpy(&w, s_c.mem + 8 * lane, 8);
+                acc = xxh_round(acc, w * kXxhP2);
+            }
+            n_mem = 0;
+        }
+        __syncthreads();
+    }
+    const uint64_t n_stripes = (b - a) / 32, n_chunks = (n_stripes + 31) / 32;
+    auto load_words = [&](uint64_t chunk, uint64_t *w) {     // this lane's 16 bytes of the chunk
+        const uint64_t off = chunk * 1024 + lane * 16;
+        w[0] = w[1] = 0;
+        if (off >= n_stripes * 32) return;
+        if (!ascii) {
+            __builtin_memcpy(w, out + a + off, 16);
+        } else {
+            uint32_t cw[8];
+            __builtin_memcpy(cw, out + 2 * (a + off), 32);
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint32_t two = cw[k >> 1] >> (16 * (k & 1));
+                const uint64_t byte = s_inv[two & 0xFFu] | (static_cast<uint32_t>(s_inv[(two >> 8) & 0xFFu]) << 4);
+                w[k >> 3] |= byte << (8 * (k & 7));
+            }
+        }
+    };
+    uint64_t w[2];
+    if (n_chunks) load_words(0, w);
+    for (uint64_t chunk = 0; chunk < n_chunks; chunk++) {
+        uint64_t *buf = s_prod[chunk & 1];
+        buf[2 * lane] = w[0] * kXxhP2;
+        buf[2 * lane + 1] = w[1] * kXxhP2;
+        __syncthreads();
+        if (chunk + 1 < n_chunks) load_words(chunk + 1, w);  // in flight while the chains run
+        const uint64_t left = n_stripes - chunk * 32;
+        if (lane < 4) {
+            if (left >= 32) {
+#pragma unroll 8
+                for (uint32_t s = 0; s < 32; s++) acc = xxh_round(acc, buf[4 * s + lane]);
+            } else {
+                for (uint32_t s = 0; s < left; s++) acc = xxh_round(acc, buf[4 * s + lane]);
+            }
+        }
+    }
+    a += n_stripes * 32;
+    const uint32_t tail = static_cast<uint32_t>(b - a);      // < 32 (and 0 when the lead-in took everything)
+    __syncthreads();
+    if (lane < tail) s_c.mem[n_mem + lane] = byte_at(a + lane);
+    if (lane < 4) s_c.v[lane] = acc;
+    __syncthreads();
+    if (lane != 0) return;
+    n_mem += tail;
+    s_c.n_mem = n_mem;
+    s_c.total += n_new;
+    if (!(seg.flags & 2u)) {
+        *carry_out = s_c;
+        return;
+    }
+    uint64_t h;
+    if (s_c.total >= 32) {
+        h = rotl64(s_c.v[0], 1) + rotl64(s_c.v[1], 7) + rotl64(s_c.v[2], 12) + rotl64(s_c.v[3], 18);
+        for (uint32_t k = 0; k < 4; k++) h = (h ^ xxh_round(0, s_c.v[k] * kXxhP2)) * kXxhP1 + kXxhP4;
+    } else {
+        h = kXxhP5;
+    }
+    h += s_c.total;
+    uint32_t i = 0;
+    for (; i + 8 <= n_mem; i += 8) {
+        uint64_t x;
+        __builtin_memcpy(&x, s_c.mem + i, 8);
+        h ^= xxh_round(0, x * kXxhP2);
+        h = rotl64(h, 27) * kXxhP1 + kXxhP4;
+    }
+    if (i + 4 <= n_mem) {
+        uint32_t x;
+        __builtin_memcpy(&x, s_c.mem + i, 4);
+        h ^= static_cast<uint64_t>(x) * kXxhP1;
+        h = rotl64(h, 23) * kXxhP2 + kXxhP3;
+        i += 4;
+    }
+    for (; i < n_mem; i++) {
+        h ^= static_cast<uint64_t>(s_c.mem[i]) * kXxhP5;
+        h = rotl64(h, 11) * kXxhP1;
+    }
+    h ^= h >> 33;
+    h *= kXxhP2;
+    h ^= h >> 29;
+    h *= kXxhP3;
+    h ^= h >> 32;
+    if (static_cast<uint32_t>(h) != seg.expected) flag_error(status, kStChecksum, seg.blk0);
+}
+
+// ======================================================================================
 // checksum (hash64.h)
 // ======================================================================================
 __global__ __launch_bounds__(256) void k_hash64(const uint8_t *__restrict__ p, uint64_t n, uint64_t first_chunk,
@@ -2462,10 +2620,11 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
     const uint32_t n_chunks = (a.n_blocks + kRepChunk - 1) / kRepChunk;
     uint32_t *partial = a.rep_scratch, *chunk_init = a.rep_scratch + 3 * static_cast<size_t>(n_chunks);
     hipLaunchKernelGGL(k_rep_partial, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, a.blocks, a.n_blocks, a.rep_final, partial,
-                       a.status);
-    hipLaunchKernelGGL(k_rep_scan, dim3(1), dim3(1), 0, stream, n_chunks, partial, chunk_init, a.status);
+                       a.rep_continues, a.status);
+    hipLaunchKernelGGL(k_rep_scan, dim3(1), dim3(1), 0, stream, n_chunks, partial, chunk_init, a.rep_carry[0], a.rep_carry[1],
+                       a.rep_carry[2], a.status);
     hipLaunchKernelGGL(k_rep_apply, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, a.blocks, a.n_blocks, a.rep_final,
-                       chunk_init, a.rep_init, a.status);
+                       chunk_init, a.rep_init, a.rep_continues, a.rep_out, a.status);
     hipLaunchKernelGGL(k_lz_literals<ASCII>, dim3(a.n_blocks), dim3(256), 0, stream, a.blocks, a.seqs, a.lit, a.blk_base,
                        a.meta, a.blk_pending, a.out, a.t_char, a.status);
     const uint32_t grid = a.n_blocks < 256u * 8u ? a.n_blocks : 256u * 8u;
@@ -2558,6 +2717,13 @@ void launch_mask_apply(hipStream_t stream, uint8_t *ascii, uint64_t n_bases, uin
     }();
     hipLaunchKernelGGL(k_mask_apply, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, ascii, n_bases, lo_clamp,
                        hi_clamp, mask_ends, mask_totals, rec_ends, rec_totals, spec_mask | (dbg << 8), status);
+}
+
+void launch_xxh64_frames(hipStream_t stream, const XxhSeg *segs, uint32_t n_segs, const uint64_t *blk_base, const uint8_t *out,
+                         bool ascii, uint32_t t_char, const XxhCarry *carry_in, XxhCarry *carry_out, uint32_t *status) {
+    if (!n_segs) return;
+    hipLaunchKernelGGL(k_xxh64_frames, dim3(n_segs), dim3(64), 0, stream, segs, blk_base, out, ascii ? 1u : 0u, t_char, carry_in,
+                       carry_out, status);
 }
 
 void launch_hash64(hipStream_t stream, const uint8_t *p, uint64_t n, uint64_t first_chunk, unsigned long long *result) {

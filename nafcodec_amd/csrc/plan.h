@@ -134,6 +134,22 @@ enum : uint32_t {
     kStSizeMismatch = 5,   // decoded size != section original size / block too large
     kStRunsOverflow = 6,
     kStInternal = 7,       // a host-side guarantee did not hold (k_huf_decode: task spans > kHufTaskSpan)
+    kStChecksum = 8,       // a frame's Content_Checksum differs from XXH64 of what it decoded to
+};
+
+// Frame checksums (RFC 8878 3.1.1: low 32 bits of XXH64, seed 0, of the frame's decoded bytes).  One piece of a
+// frame per k_xxh64_frames workgroup: the blocks of the frame that the loaded selection holds.  A frame that
+// continues into the next tile leaves its running state (XxhCarry) behind.
+struct XxhSeg {
+    uint32_t blk0, blk1;   // blocks [blk0, blk1) of the loaded selection
+    uint32_t expected;     // the stored checksum
+    uint32_t flags;        // 1: the frame begins with blk0; 2: it ends with blk1 - 1
+};
+struct XxhCarry {
+    uint64_t v[4];
+    uint64_t total;        // bytes hashed so far
+    uint32_t n_mem, pad;
+    uint8_t mem[32];       // bytes of the stripe not yet complete
 };
 
 }  // namespace nafgpu

@@ -456,8 +456,11 @@ const char kLut[17] = "-TGKCYSBAWRDMHVN";
 
 }  // namespace
 
-extern "C" int nafgpu_synth_write(const nafgpu_synth_spec *spec, nafgpu_synth_archive *out) {
+// head_only: build what precedes the sequence blocks, given their total size (nafgpu_synth_head)
+static int synth_impl(const nafgpu_synth_spec *spec, nafgpu_synth_archive *out, bool head_only, uint64_t seq_part_bytes) {
     if (!spec || !out || spec->n_bases == 0) return NAFGPU_E_INVALID_ARG;
+    const uint32_t part_count = spec->part_count > 1 ? spec->part_count : 1, part_rank = spec->part_rank;
+    if (part_rank >= part_count) return NAFGPU_E_INVALID_ARG;
     std::memset(out, 0, sizeof *out);
     const uint64_t n_bases = spec->n_bases;
     const uint64_t n_packed = (n_bases + 1) / 2;
@@ -537,16 +540,19 @@ extern "C" int nafgpu_synth_write(const nafgpu_synth_spec *spec, nafgpu_synth_ar
     // ---- sequence section: blocks in parallel, chunks of kChunkBlocks
     const uint64_t n_blocks = (n_packed + kBlockMax - 1) / kBlockMax;
     const uint64_t n_chunks = (n_blocks + kChunkBlocks - 1) / kChunkBlocks;
+    // this process's share of the chunks (all of them unless the archive is written in parts)
+    const uint64_t chunk0 = head_only ? 0 : n_chunks * part_rank / part_count;
+    const uint64_t chunk1 = head_only ? 0 : n_chunks * (part_rank + 1) / part_count;
     std::vector<std::vector<uint8_t>> chunk_out(n_chunks);
     std::vector<uint64_t> chunk_hash(n_chunks, 0);
-    std::atomic<uint64_t> next_chunk{0};
+    std::atomic<uint64_t> next_chunk{chunk0};
     unsigned n_threads = spec->threads ? spec->threads : std::max(1u, std::thread::hardware_concurrency());
-    n_threads = static_cast<unsigned>(std::min<uint64_t>(n_threads, n_chunks));
+    n_threads = static_cast<unsigned>(std::max<uint64_t>(1, std::min<uint64_t>(n_threads, chunk1 - chunk0)));
     auto worker = [&]() {
         std::vector<uint8_t> packed(kBlockMax), ascii(2 * kBlockMax);
         for (;;) {
             const uint64_t c = next_chunk.fetch_add(1);
-            if (c >= n_chunks) break;
+            if (c >= chunk1) break;
             HufCode prev{};
             std::vector<uint8_t> &o = chunk_out[c];
             o.reserve(kChunkBlocks * (kBlockMax / 2 + 64));
@@ -587,6 +593,25 @@ extern "C" int nafgpu_synth_write(const nafgpu_synth_spec *spec, nafgpu_synth_ar
     }
     uint64_t seq_csize = 2;
     for (auto &c : chunk_out) seq_csize += c.size();
+    if (part_count > 1 && !head_only) {                  // a part: its blocks, nothing in front
+        uint64_t part_n = 0;
+        for (auto &c : chunk_out) part_n += c.size();
+        uint8_t *pb = static_cast<uint8_t *>(std::malloc(part_n ? part_n : 1));
+        if (!pb) return NAFGPU_E_DEVICE;
+        uint64_t at = 0;
+        for (auto &c : chunk_out) {
+            std::memcpy(pb + at, c.data(), c.size());
+            at += c.size();
+        }
+        out->bytes = pb;
+        out->n = part_n;
+        out->n_records = n_rec;
+        out->n_bases = n_bases;
+        for (uint64_t h : chunk_hash) out->seq_hash += h;
+        out->offsets_hash = nafgpu::hash64_host(reinterpret_cast<const uint8_t *>(rec_end.data()), n_rec * 8);
+        return NAFGPU_OK;
+    }
+    if (head_only) seq_csize = 2 + seq_part_bytes;
 
     // ---- assemble (encoder/mod.rs:334-384): header, then Length, [Mask], Sequence
     std::vector<uint8_t> head;
@@ -608,7 +633,7 @@ extern "C" int nafgpu_synth_write(const nafgpu_synth_spec *spec, nafgpu_synth_ar
     }
     put_varint(head, n_bases);                                               // nucleotides, not bytes (mod.rs:241)
     put_varint(head, seq_csize);
-    const uint64_t total = head.size() + seq_csize;
+    const uint64_t total = head.size() + (head_only ? 2 : seq_csize);
     uint8_t *buf = static_cast<uint8_t *>(std::malloc(total));
     if (!buf) return NAFGPU_E_DEVICE;
     std::memcpy(buf, head.data(), head.size());
@@ -627,6 +652,14 @@ extern "C" int nafgpu_synth_write(const nafgpu_synth_spec *spec, nafgpu_synth_ar
     for (uint64_t h : chunk_hash) out->seq_hash += h;
     out->offsets_hash = nafgpu::hash64_host(reinterpret_cast<const uint8_t *>(rec_end.data()), n_rec * 8);
     return NAFGPU_OK;
+}
+
+extern "C" int nafgpu_synth_write(const nafgpu_synth_spec *spec, nafgpu_synth_archive *out) {
+    return synth_impl(spec, out, false, 0);
+}
+
+extern "C" int nafgpu_synth_head(const nafgpu_synth_spec *spec, uint64_t seq_part_bytes, nafgpu_synth_archive *out) {
+    return synth_impl(spec, out, true, seq_part_bytes);
 }
 
 extern "C" void nafgpu_synth_free(nafgpu_synth_archive *a) {

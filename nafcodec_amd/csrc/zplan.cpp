@@ -215,12 +215,7 @@ bool append_seq_table(ZPlan *plan, SeqKind kind, const FseStates &t, TableRef *r
 }
 
 // ---------------------------------------------------------------- Huffman (App. B "Huffman tree description")
-struct HufRef {
-    uint32_t pool_off = 0;
-    uint16_t n_syms = 0;       // symbols with a code
-    uint8_t max_bits = 0;
-    bool valid = false;
-};
+using HufRef = HufTableRef;
 
 // Parses the tree description at src, appends the 2^max_bits decode table to the pool.
 long read_huf_table(const uint8_t *src, size_t n, ZPlan *plan, HufRef *ref, Fail &f) {
@@ -342,7 +337,6 @@ struct Walker {
     size_t n;
     ZPlan *plan;
     Fail fail;
-    std::vector<HufRef> stream_tbl;      // table of each emitted stream, for task packing
     TableRef predefined[3];
 
     bool need(size_t at, size_t k, const char *what) {
@@ -527,7 +521,7 @@ struct Walker {
                 hs.max_bits = huf->max_bits;
                 hs.flags = lflag;
                 plan->streams.push_back(hs);
-                stream_tbl.push_back(*huf);
+                plan->stream_ref.push_back(*huf);
                 dst += counts[s];
             }
         }
@@ -610,6 +604,7 @@ struct Walker {
             const int type = (bh >> 1) & 3;
             const size_t bsize = bh >> 3;
             const uint32_t blk = static_cast<uint32_t>(plan->blk_size.size());
+            plan->blk_off.push_back(i - 3);
             if (type == 0) {                                   // Raw
                 if (!need(i, bsize, "a raw block")) return false;
                 if (bsize > kBlockMax) return bad("raw block larger than 128 KiB");
@@ -634,179 +629,185 @@ struct Walker {
             }
             if (last) break;
         }
-        if (checksum) {
+        ZPlan::Frame fr{frame_first_blk, static_cast<uint32_t>(plan->blk_size.size()), 0, checksum != 0};
+        if (checksum) {                                        // low 32 bits of XXH64 of the decoded frame, verified on the device
             if (!need(i, 4, "the frame checksum")) return false;
-            i += 4;                                            // xxh64 low word: not verified
+            fr.checksum = uint32_t(p[i]) | (uint32_t(p[i + 1]) << 8) | (uint32_t(p[i + 2]) << 16) | (uint32_t(p[i + 3]) << 24);
+            i += 4;
         }
+        plan->frames.push_back(fr);
         return true;
     }
 
-    // Greedy packing of streams into wave tasks: <= 64 lanes whose decode tables fit the LDS budget of
-    // their table format.  Streams that write the section output (directly, or segment by segment
-    // around the matches of a block with a few sequences) come first, those that feed the literal
-    // buffer of a block with many sequences second: the two groups never share a task (the first
-    // may expand 4-bit codes to ASCII on the fly, the second never does).  Tasks are then grouped
-    // into launch classes (table format x destination x segment-aware kernel).
-    void pack_tasks() {
-        {   // stable partition by destination
-            std::vector<HufStream> ordered;
-            std::vector<HufRef> ordered_tbl;
-            ordered.reserve(plan->streams.size());
-            ordered_tbl.reserve(plan->streams.size());
-            for (int pass = 0; pass < 2; pass++)
-                for (size_t s = 0; s < plan->streams.size(); s++)
-                    if ((plan->streams[s].flags & 1) == pass) {
-                        ordered.push_back(plan->streams[s]);
-                        ordered_tbl.push_back(stream_tbl[s]);
+};
+
+// Greedy packing of streams into wave tasks: <= 64 lanes whose decode tables fit the LDS budget of
+// their table format.  Streams that write the section output (directly, or segment by segment
+// around the matches of a block with a few sequences) come first, those that feed the literal
+// buffer of a block with many sequences second: the two groups never share a task (the first
+// may expand 4-bit codes to ASCII on the fly, the second never does).  Tasks are then grouped
+// into launch classes (table format x destination x segment-aware kernel).
+void pack_tasks(ZPlan *plan) {
+    std::vector<HufRef> &stream_tbl = plan->stream_ref;
+    std::vector<uint32_t> class_key;
+    {   // stable partition by destination
+        std::vector<HufStream> ordered;
+        std::vector<HufRef> ordered_tbl;
+        ordered.reserve(plan->streams.size());
+        ordered_tbl.reserve(plan->streams.size());
+        for (int pass = 0; pass < 2; pass++)
+            for (size_t s = 0; s < plan->streams.size(); s++)
+                if ((plan->streams[s].flags & 1) == pass) {
+                    ordered.push_back(plan->streams[s]);
+                    ordered_tbl.push_back(stream_tbl[s]);
+                }
+        plan->streams.swap(ordered);
+        stream_tbl.swap(ordered_tbl);
+    }
+    // Every table of a task is staged with the same index width W (8, 7 or 6 bits): 2^W
+    // two-symbol entries plus, for codes longer than W bits, one 2^(max_bits - W) entry
+    // sub-table per escaping W-bit prefix.  The widest W whose tables fit the budget wins,
+    // so archives where every block brings its own (possibly 11-bit) tree still fill 64 lanes.
+    auto staged_entries = [&](const HufRef &t, uint32_t W) -> uint32_t {
+        if (t.max_bits <= W) return 1u << W;
+        const uint16_t *x1 = plan->huf_pool.data() + t.pool_off;
+        uint32_t esc = 0;
+        for (uint32_t p = 0; p < (1u << W); p++)
+            if ((x1[p << (t.max_bits - W)] >> 8) > W) esc++;
+        return (1u << W) + (esc << (t.max_bits - W));
+    };
+    struct Packed {
+        HufTask task;
+        uint32_t key;        // to_lit << 3 | tbl << 1 | seg
+        uint32_t lds_bytes;
+    };
+    std::vector<Packed> packed;
+    auto pack_group = [&](size_t g0, size_t g1) {
+        size_t s = g0;
+        while (s < g1) {
+            size_t e = std::min(g1, s + kHufWave);
+            // k_huf_decode addresses a task's input and output with 32-bit offsets from the lowest
+            // address of the task: keep both spans within kHufTaskSpan (output of a block with
+            // sequences is not known here: bound it by the block maximum, x2 for the ASCII expansion)
+            for (size_t k = s + 1; k < e; k++) {
+                const HufStream &a = plan->streams[s], &b = plan->streams[k];
+                const uint64_t src_span = b.src_end - (a.src_end - a.src_len);
+                const uint64_t dst_span = (b.flags & 1) ? b.dst + b.n_syms - a.dst
+                                                        : (uint64_t(b.blk) - a.blk + 1) * kBlockMax * 2;
+                if (b.src_end < a.src_end || b.blk < a.blk || src_span > kHufTaskSpan || dst_span > kHufTaskSpan) {
+                    e = k;
+                    break;
+                }
+            }
+            uint32_t W = 8, kind = kTblBaked;
+            std::vector<HufRef> distinct;
+            uint8_t min_len[256];                      // shortest code of every symbol over the task's trees (0xFF: unused)
+            uint32_t n_union = 0;
+            for (;;) {
+                distinct.clear();
+                for (size_t k = s; k < e; k++) {
+                    bool seen = false;
+                    for (const HufRef &d : distinct) seen = seen || d.pool_off == stream_tbl[k].pool_off;
+                    if (!seen) distinct.push_back(stream_tbl[k]);
+                }
+                // the symbols the trees use between them: few enough for one shared dictionary?
+                bool small = distinct.size() > 1;
+                std::memset(min_len, 0xFF, sizeof min_len);
+                n_union = 0;
+                for (size_t d = 0; small && d < distinct.size(); d++) {
+                    if (distinct[d].n_syms > kHufDictSyms) {
+                        small = false;
+                        break;
                     }
-            plan->streams.swap(ordered);
-            stream_tbl.swap(ordered_tbl);
-        }
-        // Every table of a task is staged with the same index width W (8, 7 or 6 bits): 2^W
-        // two-symbol entries plus, for codes longer than W bits, one 2^(max_bits - W) entry
-        // sub-table per escaping W-bit prefix.  The widest W whose tables fit the budget wins,
-        // so archives where every block brings its own (possibly 11-bit) tree still fill 64 lanes.
-        auto staged_entries = [&](const HufRef &t, uint32_t W) -> uint32_t {
-            if (t.max_bits <= W) return 1u << W;
-            const uint16_t *x1 = plan->huf_pool.data() + t.pool_off;
-            uint32_t esc = 0;
-            for (uint32_t p = 0; p < (1u << W); p++)
-                if ((x1[p << (t.max_bits - W)] >> 8) > W) esc++;
-            return (1u << W) + (esc << (t.max_bits - W));
-        };
-        struct Packed {
-            HufTask task;
-            uint32_t key;        // to_lit << 3 | tbl << 1 | seg
-            uint32_t lds_bytes;
-        };
-        std::vector<Packed> packed;
-        auto pack_group = [&](size_t g0, size_t g1) {
-            size_t s = g0;
-            while (s < g1) {
-                size_t e = std::min(g1, s + kHufWave);
-                // k_huf_decode addresses a task's input and output with 32-bit offsets from the lowest
-                // address of the task: keep both spans within kHufTaskSpan (output of a block with
-                // sequences is not known here: bound it by the block maximum, x2 for the ASCII expansion)
-                for (size_t k = s + 1; k < e; k++) {
-                    const HufStream &a = plan->streams[s], &b = plan->streams[k];
-                    const uint64_t src_span = b.src_end - (a.src_end - a.src_len);
-                    const uint64_t dst_span = (b.flags & 1) ? b.dst + b.n_syms - a.dst
-                                                            : (uint64_t(b.blk) - a.blk + 1) * kBlockMax * 2;
-                    if (b.src_end < a.src_end || b.blk < a.blk || src_span > kHufTaskSpan || dst_span > kHufTaskSpan) {
-                        e = k;
+                    const uint16_t *x1 = plan->huf_pool.data() + distinct[d].pool_off;
+                    for (uint32_t i = 0; i < (1u << distinct[d].max_bits);) {
+                        const uint32_t sym = x1[i] & 0xFFu, len = x1[i] >> 8;
+                        if (min_len[sym] == 0xFF) n_union++;
+                        if (len < min_len[sym]) min_len[sym] = static_cast<uint8_t>(len);
+                        i += 1u << (distinct[d].max_bits - len);       // a code of `len` bits fills that many entries
+                    }
+                    small = n_union <= kHufDictSyms;
+                }
+                // several trees: 2-byte dictionary entries (small alphabets) or compact 4-byte entries, and a
+                // larger budget, so that the task keeps 64 lanes
+                kind = distinct.size() == 1 ? kTblBaked : (small ? kTblDict : kTblCompact);
+                const uint32_t budget = kind == kTblBaked ? kHufLdsEntries : (kind == kTblDict ? kHufLdsSlots2 : kHufLdsEntries4);
+                const uint32_t per_tree = kind == kTblDict ? kHufDictSlots : 0;
+                bool fits = false;
+                for (W = 8; W >= 6; W--) {
+                    uint32_t total = 0;
+                    for (const HufRef &d : distinct) total += per_tree + staged_entries(d, W);
+                    if (total <= budget) {
+                        fits = true;
                         break;
                     }
                 }
-                uint32_t W = 8, kind = kTblBaked;
-                std::vector<HufRef> distinct;
-                uint8_t min_len[256];                      // shortest code of every symbol over the task's trees (0xFF: unused)
-                uint32_t n_union = 0;
-                for (;;) {
-                    distinct.clear();
-                    for (size_t k = s; k < e; k++) {
-                        bool seen = false;
-                        for (const HufRef &d : distinct) seen = seen || d.pool_off == stream_tbl[k].pool_off;
-                        if (!seen) distinct.push_back(stream_tbl[k]);
-                    }
-                    // the symbols the trees use between them: few enough for one shared dictionary?
-                    bool small = distinct.size() > 1;
-                    std::memset(min_len, 0xFF, sizeof min_len);
-                    n_union = 0;
-                    for (size_t d = 0; small && d < distinct.size(); d++) {
-                        if (distinct[d].n_syms > kHufDictSyms) {
-                            small = false;
-                            break;
-                        }
-                        const uint16_t *x1 = plan->huf_pool.data() + distinct[d].pool_off;
-                        for (uint32_t i = 0; i < (1u << distinct[d].max_bits);) {
-                            const uint32_t sym = x1[i] & 0xFFu, len = x1[i] >> 8;
-                            if (min_len[sym] == 0xFF) n_union++;
-                            if (len < min_len[sym]) min_len[sym] = static_cast<uint8_t>(len);
-                            i += 1u << (distinct[d].max_bits - len);       // a code of `len` bits fills that many entries
-                        }
-                        small = n_union <= kHufDictSyms;
-                    }
-                    // several trees: 2-byte dictionary entries (small alphabets) or compact 4-byte entries, and a
-                    // larger budget, so that the task keeps 64 lanes
-                    kind = distinct.size() == 1 ? kTblBaked : (small ? kTblDict : kTblCompact);
-                    const uint32_t budget = kind == kTblBaked ? kHufLdsEntries : (kind == kTblDict ? kHufLdsSlots2 : kHufLdsEntries4);
-                    const uint32_t per_tree = kind == kTblDict ? kHufDictSlots : 0;
-                    bool fits = false;
-                    for (W = 8; W >= 6; W--) {
-                        uint32_t total = 0;
-                        for (const HufRef &d : distinct) total += per_tree + staged_entries(d, W);
-                        if (total <= budget) {
-                            fits = true;
-                            break;
-                        }
-                    }
-                    if (fits || e == s + 1) break;
-                    e = s + (e - s + 1) / 2;                 // too many distinct deep trees: take fewer streams
-                }
-                if (W < 6) W = 6;
-                const uint32_t per_tree = kind == kTblDict ? kHufDictSlots : 0;
-                HufTask task{static_cast<uint32_t>(s), static_cast<uint32_t>(e - s),
-                             static_cast<uint32_t>(plan->tbl_copies.size()), static_cast<uint32_t>(distinct.size()), 0, 0, {0, 0}};
-                if (kind == kTblDict) {                    // the task's dictionary: symbols by shortest code, then by value
-                    task.dict_off = static_cast<uint32_t>(plan->dict_pool.size());
-                    task.n_dict = n_union;
-                    std::vector<uint32_t> order;
-                    for (uint32_t sym = 0; sym < 256; sym++)
-                        if (min_len[sym] != 0xFF) order.push_back((static_cast<uint32_t>(min_len[sym]) << 8) | sym);
-                    std::sort(order.begin(), order.end());
-                    for (uint32_t k = 0; k < kHufDictSyms; k++)
-                        plan->dict_pool.push_back(k < order.size() ? static_cast<uint8_t>(order[k] & 0xFFu) : 0);
-                }
-                uint32_t lds_used = 0;
-                std::vector<uint32_t> lds_of(distinct.size());
-                for (size_t d = 0; d < distinct.size(); d++) {
-                    const uint32_t n = per_tree + staged_entries(distinct[d], W);
-                    lds_of[d] = lds_used;
-                    plan->tbl_copies.push_back(HufTblCopy{distinct[d].pool_off, lds_used, n, distinct[d].max_bits | (W << 8)});
-                    lds_used += n;
-                }
-                bool seg = false;
-                for (size_t k = s; k < e; k++) {
-                    size_t d = 0;
-                    while (distinct[d].pool_off != stream_tbl[k].pool_off) d++;
-                    HufStream &hs = plan->streams[k];
-                    hs.tbl_lds = static_cast<uint16_t>(lds_of[d]);
-                    hs.max_bits = static_cast<uint8_t>(W);
-                    const uint32_t esc_bits = stream_tbl[k].max_bits > W ? stream_tbl[k].max_bits - W : 0;
-                    hs.flags = static_cast<uint8_t>((hs.flags & 0x0F) | (esc_bits << 4));
-                    seg = seg || (hs.flags & 2);
-                }
-                const uint32_t to_lit = plan->streams[s].flags & 1u;
-                const uint32_t entry_bytes = kind == kTblBaked ? 8u : (kind == kTblDict ? 2u : 4u);
-                packed.push_back(Packed{task, (to_lit << 3) | (kind << 1) | (seg ? 1u : 0u), lds_used * entry_bytes});
-                s = e;
+                if (fits || e == s + 1) break;
+                e = s + (e - s + 1) / 2;                 // too many distinct deep trees: take fewer streams
             }
-        };
-        size_t first_lit = 0;
-        while (first_lit < plan->streams.size() && !(plan->streams[first_lit].flags & 1)) first_lit++;
-        pack_group(0, first_lit);
-        pack_group(first_lit, plan->streams.size());
-        // launch classes: tasks of one key together, keys in ascending order (direct before literal buffer)
-        std::stable_sort(packed.begin(), packed.end(), [](const Packed &a, const Packed &b) { return a.key < b.key; });
-        for (const Packed &pk : packed) {
-            if (class_key.empty() || class_key.back() != pk.key) {
-                plan->classes.push_back(HufClass{static_cast<uint32_t>(plan->tasks.size()), 0, (pk.key >> 1) & 3u, pk.key >> 3, pk.key & 1u, 0});
-                class_key.push_back(pk.key);
+            if (W < 6) W = 6;
+            const uint32_t per_tree = kind == kTblDict ? kHufDictSlots : 0;
+            HufTask task{static_cast<uint32_t>(s), static_cast<uint32_t>(e - s),
+                         static_cast<uint32_t>(plan->tbl_copies.size()), static_cast<uint32_t>(distinct.size()), 0, 0, {0, 0}};
+            if (kind == kTblDict) {                    // the task's dictionary: symbols by shortest code, then by value
+                task.dict_off = static_cast<uint32_t>(plan->dict_pool.size());
+                task.n_dict = n_union;
+                std::vector<uint32_t> order;
+                for (uint32_t sym = 0; sym < 256; sym++)
+                    if (min_len[sym] != 0xFF) order.push_back((static_cast<uint32_t>(min_len[sym]) << 8) | sym);
+                std::sort(order.begin(), order.end());
+                for (uint32_t k = 0; k < kHufDictSyms; k++)
+                    plan->dict_pool.push_back(k < order.size() ? static_cast<uint8_t>(order[k] & 0xFFu) : 0);
             }
-            HufClass &c = plan->classes.back();
-            c.n_tasks++;
-            c.lds_bytes = std::max(c.lds_bytes, pk.lds_bytes);
-            plan->tasks.push_back(pk.task);
+            uint32_t lds_used = 0;
+            std::vector<uint32_t> lds_of(distinct.size());
+            for (size_t d = 0; d < distinct.size(); d++) {
+                const uint32_t n = per_tree + staged_entries(distinct[d], W);
+                lds_of[d] = lds_used;
+                plan->tbl_copies.push_back(HufTblCopy{distinct[d].pool_off, lds_used, n, distinct[d].max_bits | (W << 8)});
+                lds_used += n;
+            }
+            bool seg = false;
+            for (size_t k = s; k < e; k++) {
+                size_t d = 0;
+                while (distinct[d].pool_off != stream_tbl[k].pool_off) d++;
+                HufStream &hs = plan->streams[k];
+                hs.tbl_lds = static_cast<uint16_t>(lds_of[d]);
+                hs.max_bits = static_cast<uint8_t>(W);
+                const uint32_t esc_bits = stream_tbl[k].max_bits > W ? stream_tbl[k].max_bits - W : 0;
+                hs.flags = static_cast<uint8_t>((hs.flags & 0x0F) | (esc_bits << 4));
+                seg = seg || (hs.flags & 2);
+            }
+            const uint32_t to_lit = plan->streams[s].flags & 1u;
+            const uint32_t entry_bytes = kind == kTblBaked ? 8u : (kind == kTblDict ? 2u : 4u);
+            packed.push_back(Packed{task, (to_lit << 3) | (kind << 1) | (seg ? 1u : 0u), lds_used * entry_bytes});
+            s = e;
         }
+    };
+    size_t first_lit = 0;
+    while (first_lit < plan->streams.size() && !(plan->streams[first_lit].flags & 1)) first_lit++;
+    pack_group(0, first_lit);
+    pack_group(first_lit, plan->streams.size());
+    // launch classes: tasks of one key together, keys in ascending order (direct before literal buffer)
+    std::stable_sort(packed.begin(), packed.end(), [](const Packed &a, const Packed &b) { return a.key < b.key; });
+    for (const Packed &pk : packed) {
+        if (class_key.empty() || class_key.back() != pk.key) {
+            plan->classes.push_back(HufClass{static_cast<uint32_t>(plan->tasks.size()), 0, (pk.key >> 1) & 3u, pk.key >> 3, pk.key & 1u, 0});
+            class_key.push_back(pk.key);
+        }
+        HufClass &c = plan->classes.back();
+        c.n_tasks++;
+        c.lds_bytes = std::max(c.lds_bytes, pk.lds_bytes);
+        plan->tasks.push_back(pk.task);
     }
-    std::vector<uint32_t> class_key;
-};
+}
 
 }  // namespace
 
-std::string build_zplan(const uint8_t *payload, size_t n, ZPlan *plan, bool *truncated, uint32_t shard_rank,
-                        uint32_t shard_count) {
-    Walker w{payload, n, plan, {}, {}, {}, {}};
+void pack_tasks_public(ZPlan *plan) { pack_tasks(plan); }
+
+std::string walk_zstd(const uint8_t *payload, size_t n, ZPlan *master, bool *truncated) {
+    Walker w{payload, n, master, {}, {}};
     *truncated = false;
     if (n == 0) {
         *truncated = true;
@@ -819,53 +820,184 @@ std::string build_zplan(const uint8_t *payload, size_t n, ZPlan *plan, bool *tru
             return w.fail.msg.empty() ? std::string("malformed zstd frame") : w.fail.msg;
         }
     }
-    if (shard_count > 1 && plan->seq_blocks.empty() && !plan->blk_size.empty()) {
-        // contiguous block ranges balanced by decoded bytes; block boundaries only
-        const uint64_t total = plan->known_out;
-        const uint64_t lo_target = total / shard_count * shard_rank + std::min<uint64_t>(shard_rank, total % shard_count);
-        const uint64_t hi_target = total / shard_count * (shard_rank + 1) + std::min<uint64_t>(shard_rank + 1, total % shard_count);
-        uint64_t pos = 0;
-        uint32_t b0 = 0, b1 = 0;
-        uint64_t o0 = 0, o1 = 0;
-        bool have0 = false;
-        const uint32_t nb = static_cast<uint32_t>(plan->blk_size.size());
-        for (uint32_t b = 0; b <= nb; b++) {                 // a block belongs to the shard its first byte falls in
-            if (!have0 && (pos >= lo_target || b == nb)) {
-                b0 = b;
-                o0 = pos;
-                have0 = true;
-            }
-            if (have0 && (pos >= hi_target || b == nb)) {
-                b1 = b;
-                o1 = pos;
-                break;
-            }
-            if (b < nb) pos += plan->blk_size[b];
-        }
-        if (shard_rank + 1 == shard_count) {
-            b1 = nb;
-            o1 = total;
-        }
-        plan->sharded = true;
-        plan->shard_blk0 = b0;
-        plan->shard_blk1 = b1;
-        plan->shard_out0 = o0;
-        plan->shard_out1 = o1;
-        std::vector<HufStream> ks;
-        std::vector<HufRef> kt;
-        for (size_t s = 0; s < plan->streams.size(); s++)
-            if (plan->streams[s].blk >= b0 && plan->streams[s].blk < b1) {
-                ks.push_back(plan->streams[s]);
-                kt.push_back(w.stream_tbl[s]);
-            }
-        plan->streams.swap(ks);
-        w.stream_tbl.swap(kt);
-        std::vector<CopyTask> kc;
-        for (const CopyTask &t : plan->copies)
-            if (t.blk >= b0 && t.blk < b1) kc.push_back(t);
-        plan->copies.swap(kc);
+    master->blk_off.push_back(i);
+    if (!master->seq_blocks.empty()) {
+        master->first_seq_frame = master->seq_blocks.front().frame_first_blk;
+        master->last_seq_frame = master->seq_blocks.back().frame_first_blk;
     }
-    w.pack_tasks();
+    master->sel_blk0 = 0;
+    master->sel_blk1 = static_cast<uint32_t>(master->blk_size.size());
+    master->src_lo = 0;
+    master->src_hi = n;
+    return std::string();
+}
+
+bool shard_range(const ZPlan &master, uint32_t shard_rank, uint32_t shard_count, uint32_t *b0_out, uint32_t *b1_out) {
+    if (shard_count <= 1 || !master.seq_blocks.empty() || master.blk_size.empty()) return false;
+    // contiguous block ranges balanced by decoded bytes; block boundaries only
+    const uint64_t total = master.known_out;
+    const uint64_t lo_target = total / shard_count * shard_rank + std::min<uint64_t>(shard_rank, total % shard_count);
+    const uint64_t hi_target = total / shard_count * (shard_rank + 1) + std::min<uint64_t>(shard_rank + 1, total % shard_count);
+    uint64_t pos = 0;
+    uint32_t b0 = 0, b1 = 0;
+    bool have0 = false;
+    const uint32_t nb = static_cast<uint32_t>(master.blk_size.size());
+    for (uint32_t b = 0; b <= nb; b++) {                 // a block belongs to the shard its first byte falls in
+        if (!have0 && (pos >= lo_target || b == nb)) {
+            b0 = b;
+            have0 = true;
+        }
+        if (have0 && (pos >= hi_target || b == nb)) {
+            b1 = b;
+            break;
+        }
+        if (b < nb) pos += master.blk_size[b];
+    }
+    if (shard_rank + 1 == shard_count) b1 = nb;
+    *b0_out = b0;
+    *b1_out = b1;
+    return true;
+}
+
+void select_zplan(const ZPlan &m, uint32_t b0, uint32_t b1, uint64_t halo_elems, ZPlan *out) {
+    ZPlan &p = *out;
+    p = ZPlan();
+    const uint32_t nb = static_cast<uint32_t>(m.blk_size.size());
+    if (b1 > nb) b1 = nb;
+    if (b0 > b1) b0 = b1;
+    const uint32_t halo = halo_elems ? 1u : 0u;
+    p.sel_blk0 = b0;
+    p.sel_blk1 = b1;
+    p.halo = halo;
+    p.src_lo = m.blk_off[b0];
+    p.src_hi = m.blk_off[b1];
+    p.n_frames = m.n_frames;
+    p.window_max = m.window_max;
+    p.has_checksum = m.has_checksum;
+    p.frames = m.frames;
+    if (halo) p.blk_size.push_back(static_cast<uint32_t>(halo_elems));      // (a window is far below 4 GiB)
+    p.blk_size.insert(p.blk_size.end(), m.blk_size.begin() + b0, m.blk_size.begin() + b1);
+    for (uint32_t b = b0; b < b1; b++) p.known_out += m.blk_size[b];
+    if (m.seq_blocks.empty()) {                                             // decoded-byte range of the selection
+        for (uint32_t b = 0; b < b0; b++) p.shard_out0 += m.blk_size[b];
+        p.shard_out1 = p.shard_out0 + p.known_out;
+    }
+    auto in_range = [&](uint32_t blk) { return blk >= b0 && blk < b1; };
+    auto reblk = [&](uint32_t blk) { return blk - b0 + halo; };
+    // tables: only what the selection uses, in first-use order
+    std::vector<std::pair<uint32_t, uint32_t>> huf_map, fse_map;            // (old offset, new offset), few entries per selection: linear search is fine for tiles,
+    auto map_get = [](std::vector<std::pair<uint32_t, uint32_t>> &mp, uint32_t old) -> int64_t {   // sorted insert + binary search for the big ones
+        auto it = std::lower_bound(mp.begin(), mp.end(), std::make_pair(old, 0u));
+        return (it != mp.end() && it->first == old) ? static_cast<int64_t>(it->second) : -1;
+    };
+    auto map_put = [](std::vector<std::pair<uint32_t, uint32_t>> &mp, uint32_t old, uint32_t neu) {
+        mp.insert(std::lower_bound(mp.begin(), mp.end(), std::make_pair(old, 0u)), std::make_pair(old, neu));
+    };
+    auto huf_remap = [&](HufTableRef r) -> HufTableRef {
+        int64_t k = map_get(huf_map, r.pool_off);
+        if (k < 0) {
+            k = static_cast<int64_t>(p.huf_pool.size());
+            p.huf_pool.insert(p.huf_pool.end(), m.huf_pool.begin() + r.pool_off, m.huf_pool.begin() + r.pool_off + (size_t(1) << r.max_bits));
+            map_put(huf_map, r.pool_off, static_cast<uint32_t>(k));
+            p.n_huf_tables++;
+        }
+        r.pool_off = static_cast<uint32_t>(k);
+        return r;
+    };
+    auto fse_remap = [&](uint32_t off, uint32_t al) -> uint32_t {
+        int64_t k = map_get(fse_map, off);
+        if (k < 0) {
+            k = static_cast<int64_t>(p.fse_pool.size());
+            p.fse_pool.insert(p.fse_pool.end(), m.fse_pool.begin() + off, m.fse_pool.begin() + off + (size_t(1) << al));
+            map_put(fse_map, off, static_cast<uint32_t>(k));
+        }
+        return static_cast<uint32_t>(k);
+    };
+    // blocks with sequences: new literal-buffer and sequence offsets
+    std::vector<std::pair<uint32_t, uint64_t>> lit_delta;                   // (master block, old literal offset - new one) of blocks that use the literal buffer
+    size_t sb0 = 0;
+    while (sb0 < m.seq_blocks.size() && m.seq_blocks[sb0].blk < b0) sb0++;
+    size_t sb1 = sb0;
+    while (sb1 < m.seq_blocks.size() && m.seq_blocks[sb1].blk < b1) sb1++;
+    for (size_t k = sb0; k < sb1; k++) {
+        SeqBlock sb = m.seq_blocks[k];
+        if (!sb.direct) {
+            lit_delta.push_back({sb.blk, sb.lit_off - p.lit_bytes});
+            sb.lit_off = p.lit_bytes;
+            p.lit_bytes += (static_cast<uint64_t>(sb.lit_size) + 15) & ~uint64_t(15);
+        }
+        if (k == sb0) {
+            p.first_frame_continues = sb.frame_first_blk < b0;
+            p.first_seq_frame = sb.frame_first_blk;
+        }
+        p.last_seq_frame = sb.frame_first_blk;
+        sb.frame_first_blk = sb.frame_first_blk < b0 ? 0u : reblk(sb.frame_first_blk);   // a frame begun in front starts at the pseudo block (or at block 0)
+        sb.blk = reblk(sb.blk);
+        sb.seq_first = p.n_sequences;
+        p.n_sequences += sb.n_seq;
+        sb.ll_tbl = fse_remap(sb.ll_tbl, sb.ll_al);
+        sb.of_tbl = fse_remap(sb.of_tbl, sb.of_al);
+        sb.ml_tbl = fse_remap(sb.ml_tbl, sb.ml_al);
+        p.seq_blocks.push_back(sb);
+    }
+    auto lit_rebase = [&](uint32_t blk, uint64_t old) -> uint64_t {
+        auto it = std::lower_bound(lit_delta.begin(), lit_delta.end(), std::make_pair(blk, uint64_t(0)));
+        return old - it->second;
+    };
+    // the master's seq block index of a stream tagged "segmented" -> the selection's
+    auto seg_rebase = [&](uint64_t dst) -> uint64_t {
+        const uint64_t idx1 = dst >> 32;
+        return idx1 ? ((idx1 - sb0) << 32) | (dst & 0xFFFFFFFFull) : dst;
+    };
+    {
+        size_t s0 = 0;                                                      // streams are in block order in the master
+        size_t lo = 0, hi = m.streams.size();
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            if (m.streams[mid].blk < b0)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        s0 = lo;
+        for (size_t k = s0; k < m.streams.size() && m.streams[k].blk < b1; k++) {
+            HufStream hs = m.streams[k];
+            if (hs.flags & 1)
+                hs.dst = lit_rebase(hs.blk, hs.dst);
+            else if (hs.flags & 2)
+                hs.dst = seg_rebase(hs.dst);
+            hs.blk = reblk(hs.blk);
+            p.streams.push_back(hs);
+            p.stream_ref.push_back(huf_remap(m.stream_ref[k]));
+        }
+    }
+    for (const CopyTask &t : m.copies) {
+        if (!in_range(t.blk)) continue;
+        CopyTask c = t;
+        if (c.flags & 1) c.dst = lit_rebase(c.blk, c.dst);
+        c.blk = reblk(c.blk);
+        p.copies.push_back(c);
+    }
+    pack_tasks(&p);
+}
+
+std::string build_zplan(const uint8_t *payload, size_t n, ZPlan *plan, bool *truncated, uint32_t shard_rank,
+                        uint32_t shard_count) {
+    ZPlan master;
+    std::string err = walk_zstd(payload, n, &master, truncated);
+    if (!err.empty()) {
+        *plan = ZPlan();
+        return err;
+    }
+    uint32_t b0 = 0, b1 = static_cast<uint32_t>(master.blk_size.size());
+    const bool sharded = shard_range(master, shard_rank, shard_count, &b0, &b1);
+    if (!sharded) {                                       // the whole section: no need to copy anything
+        *plan = std::move(master);
+        pack_tasks(plan);
+        return std::string();
+    }
+    select_zplan(master, b0, b1, 0, plan);
+    plan->sharded = true;
     return std::string();
 }
 

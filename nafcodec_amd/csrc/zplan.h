@@ -16,6 +16,13 @@
 
 namespace nafgpu {
 
+struct HufTableRef {                     // one Huffman tree in the table pool
+    uint32_t pool_off = 0;
+    uint16_t n_syms = 0;                 // symbols with a code
+    uint8_t max_bits = 0;
+    bool valid = false;
+};
+
 struct ZPlan {
     // per zstd block
     std::vector<uint32_t> blk_size;      // decoded size; blocks with sequences: literal bytes only
@@ -33,24 +40,47 @@ struct ZPlan {
     std::vector<SeqBlock> seq_blocks;
     std::vector<SeqCell> fse_pool;
     uint64_t n_sequences = 0;
-    uint64_t lit_bytes = 0;              // literal buffer size (blocks with sequences only)
+    uint64_t lit_bytes = 0;              // literal buffer size (blocks with many sequences only)
     uint64_t known_out = 0;              // sum of blk_size
     uint32_t n_frames = 0;
     uint32_t n_huf_tables = 0;
     uint64_t window_max = 0;
     bool has_checksum = false;
-    // multi-GPU sharding: this plan covers zstd blocks [shard_blk0, shard_blk1) only
-    bool sharded = false;
-    uint32_t shard_blk0 = 0, shard_blk1 = 0;
-    uint64_t shard_out0 = 0, shard_out1 = 0;   // decoded-byte range of those blocks
+    // ---- what the walk keeps besides (master plan only)
+    std::vector<HufTableRef> stream_ref; // tree of each stream (parallel to `streams` until the tasks are packed)
+    std::vector<uint64_t> blk_off;       // payload offset of every block header; one more entry: the end of the last block
+    struct Frame {                       // one Zstandard frame of the section
+        uint32_t first_blk, end_blk;     // its blocks
+        uint32_t checksum;               // low 32 bits of XXH64 of the decoded frame, when has_checksum
+        bool has_checksum;
+    };
+    std::vector<Frame> frames;
+    // ---- a selection (select_zplan): blocks [sel_blk0, sel_blk1) of the master, re-based to start at block `halo`
+    bool sharded = false;                // the selection is one of several shards (multi-GPU)
+    uint32_t sel_blk0 = 0, sel_blk1 = 0;
+    uint32_t halo = 0;                   // 1: block 0 is a pseudo block standing for the decoded bytes in front of the selection
+    uint64_t src_lo = 0, src_hi = 0;     // payload bytes the selection's tasks read
+    uint64_t shard_out0 = 0, shard_out1 = 0;   // decoded-byte range of the selection when no block has sequences (else unknown: 0)
+    bool first_frame_continues = false;  // the selection's first block with sequences continues a frame begun in front of it
+    uint32_t first_seq_frame = 0xFFFFFFFFu, last_seq_frame = 0xFFFFFFFFu;   // master frame (its first block) of the first / last block with sequences
 };
 
+// The walk: every block / literals / sequences header of the section's frame(s), tables built, nothing packed.
 // Returns "" on success, else a description of the first malformed field.
 // `truncated` is set when the payload ends early (maps to Io(UnexpectedEof)).
-// shard_count > 1 restricts the task lists to the shard_rank-th of shard_count contiguous block
-// ranges balanced by decoded bytes.  That is only possible when no block has LZ sequences (every
-// block is then independent once treeless chains are resolved, which the walk has done); otherwise
-// the plan stays complete and `sharded` stays false (every rank decodes the whole section).
+std::string walk_zstd(const uint8_t *payload, size_t n, ZPlan *master, bool *truncated);
+// The shard_rank-th of shard_count contiguous block ranges balanced by decoded bytes (block boundaries only).
+// Only for a master without LZ sequences (every block is then independent once treeless chains are resolved,
+// which the walk has done); returns false otherwise.
+bool shard_range(const ZPlan &master, uint32_t shard_rank, uint32_t shard_count, uint32_t *b0, uint32_t *b1);
+// The launchable plan of blocks [b0, b1): task lists re-based to the range (block indices, literal-buffer and
+// sequence offsets, table pools holding only what the range uses), tasks packed into launch classes.
+// halo_elems > 0: block 0 of the selection is a pseudo block of that size standing for the decoded bytes in
+// front of the range (the LZ window of a tile); frames begun in front of the range then start at it.
+void select_zplan(const ZPlan &master, uint32_t b0, uint32_t b1, uint64_t halo_elems, ZPlan *out);
+// packs the tasks of a plan that holds a whole walk (no selection needed)
+void pack_tasks_public(ZPlan *plan);
+// walk + (shard) + select: the whole section, or one shard of it, in one call
 std::string build_zplan(const uint8_t *payload, size_t n, ZPlan *plan, bool *truncated, uint32_t shard_rank = 0,
                         uint32_t shard_count = 1);
 

@@ -13,7 +13,7 @@ _SO = os.path.join(_HERE, "_build", "libnaforacle.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("zstd_oracle.c", "naf_oracle.c", "naf_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("zstd_oracle.c", "naf_oracle.c", "ref_shape.c", "naf_oracle.h", "Makefile")]
     stale = force or not os.path.exists(_SO) or any(
         os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if stale:
@@ -75,6 +75,10 @@ def lib():
         L.no_mask_units.restype = c_size_t
         L.no_mask_units.argtypes = [c_void_p, POINTER(c_uint64), POINTER(c_uint8), c_size_t]
         L.no_drain.argtypes = [c_void_p, c_int, POINTER(DrainResult)]
+        L.rs_available.restype = c_int
+        L.rs_drain.argtypes = [c_char_p, c_size_t, c_int, POINTER(DrainResult)]
+        L.rs_drain_parallel.restype = c_uint64
+        L.rs_drain_parallel.argtypes = [c_char_p, c_size_t, c_int]
         _lib = L
     return _lib
 
@@ -116,6 +120,26 @@ def parse_header(data: bytes):
     if rc != 0:
         raise OracleError(rc, code.value)
     return h, used.value
+
+
+def ref_shape_available():
+    """True when the reference-shaped pipeline (oracle/ref_shape.c) can run: it needs the system libzstd."""
+    return bool(lib().rs_available())
+
+
+def ref_shape_drain(data: bytes, want_hash=True):
+    """The reference pipeline in its own shape (streaming libzstd through 4 KiB buffers, per-nibble push, one heap
+    string per field and record; oracle/ref_shape.c) drained over a whole archive -> DrainResult."""
+    out = DrainResult()
+    rc = lib().rs_drain(data, len(data), int(want_hash), byref(out))
+    if rc != 0:
+        raise OracleError(rc)
+    return out
+
+
+def ref_shape_drain_parallel(data: bytes, threads: int) -> int:
+    """`threads` independent drains of the same archive at once (an upper bound for "all cores"); bases decoded in all."""
+    return int(lib().rs_drain_parallel(data, len(data), threads))
 
 
 class Record:

@@ -729,6 +729,58 @@ static int decode_block(frame_ctx *fc, const uint8_t *src, size_t n, uint8_t *ds
 }
 
 /*
+ * XXH64, seed 0 (the xxHash specification, as used by RFC 8878 3.1.1 for the
+ * Content_Checksum field).
+ */
+static uint64_t zo_rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static uint64_t zo_rd64(const uint8_t *p)
+{
+    uint64_t v = 0;
+    for (int k = 7; k >= 0; k--)
+        v = (v << 8) | p[k];
+    return v;
+}
+uint64_t zo_xxh64(const uint8_t *p, size_t n)
+{
+    const uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P3 = 1609587929392839161ULL,
+                   P4 = 9650029242287828579ULL, P5 = 2870177450012600261ULL;
+    const uint8_t *end = p + n;
+    uint64_t h;
+    if (n >= 32) {
+        uint64_t v[4] = {P1 + P2, P2, 0, 0 - P1};
+        for (; p + 32 <= end; p += 32)
+            for (int k = 0; k < 4; k++)
+                v[k] = zo_rotl64(v[k] + zo_rd64(p + 8 * k) * P2, 31) * P1;
+        h = zo_rotl64(v[0], 1) + zo_rotl64(v[1], 7) + zo_rotl64(v[2], 12) + zo_rotl64(v[3], 18);
+        for (int k = 0; k < 4; k++)
+            h = (h ^ (zo_rotl64(v[k] * P2, 31) * P1)) * P1 + P4;
+    } else {
+        h = P5;
+    }
+    h += (uint64_t)n;
+    for (; p + 8 <= end; p += 8) {
+        h ^= zo_rotl64(zo_rd64(p) * P2, 31) * P1;
+        h = zo_rotl64(h, 27) * P1 + P4;
+    }
+    if (p + 4 <= end) {
+        uint64_t x = (uint64_t)p[0] | ((uint64_t)p[1] << 8) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 24);
+        h ^= x * P1;
+        h = zo_rotl64(h, 23) * P2 + P3;
+        p += 4;
+    }
+    for (; p < end; p++) {
+        h ^= (uint64_t)*p * P5;
+        h = zo_rotl64(h, 11) * P1;
+    }
+    h ^= h >> 33;
+    h *= P2;
+    h ^= h >> 29;
+    h *= P3;
+    h ^= h >> 32;
+    return h;
+}
+
+/*
  * Decode ONE magicless frame starting at src.  *consumed and *dpos are updated.
  * (mod.rs:221-222: the reference feeds the section payload to a zstd stream
  * decoder configured with include_magicbytes(false).)
@@ -864,8 +916,14 @@ static int decode_frame(const uint8_t *src, size_t n, size_t *consumed, uint8_t 
     if (rc == 0 && checksum) {
         if (i + 4 > n)
             rc = -ZO_E_TRUNCATED;
-        else
-            i += 4; /* xxh64 low 32 bits: not verified by the oracle */
+        else {
+            /* Content_Checksum: low 32 bits of XXH64 of the decoded frame; libzstd (which the reference's zstd
+             * crate wraps) refuses a frame whose checksum differs */
+            uint32_t want = (uint32_t)src[i] | ((uint32_t)src[i + 1] << 8) | ((uint32_t)src[i + 2] << 16) | ((uint32_t)src[i + 3] << 24);
+            if ((uint32_t)zo_xxh64(dst + frame_start, *dpos - frame_start) != want)
+                rc = -ZO_E_CORRUPT;
+            i += 4;
+        }
     }
     if (rc == 0 && fcs_bytes && (uint64_t)(*dpos - frame_start) != fcs)
         rc = -ZO_E_CORRUPT;

@@ -66,6 +66,15 @@ def build_cases(scale=1):
     add("more_records_than_lengths", nw.write_naf(make_records(rng, [4, 5]), number_of_sequences=4))
     add("fewer_records_than_lengths", nw.write_naf(make_records(rng, [4, 5, 6]), number_of_sequences=2))
     add("checksum_frames", nw.write_naf(make_records(rng, [50000, 3]), level=3, zstd_kwargs={"checksum": True}))
+    # Content_Checksum over several blocks: nucleotides (verified on the characters the section was expanded to), text
+    # with matches; and one whose stored checksum is wrong although everything decodes (libzstd refuses the frame)
+    ck_dna = nw.write_naf(make_records(rng, [700000 * scale + 1, 777], iupac=0.01), level=1, zstd_kwargs={"checksum": True})
+    add("checksum_dna_blocks", ck_dna)
+    add("checksum_text_l3", nw.write_naf([{"id": "q", "sequence": "".join(rng.choice(list("GGGGGGGJJJJF#"), 300000 * scale + 13))}],
+                                         sequence_type="text", level=3, zstd_kwargs={"checksum": True}))
+    bad = bytearray(ck_dna)
+    bad[-2] ^= 0x04                                                        # (the sequence section is the last one: its checksum ends the file)
+    add("checksum_wrong", bytes(bad))
     # number_of_sequences is an untrusted varint: it must not size anything (ids/comment tables, scan scratch);
     # the iterator keeps yielding (empty) records until it is reached, so only the first few are compared
     huge = make_records(rng, [40, 50, 60])
@@ -302,6 +311,9 @@ def zstd_payload_cases(scale=1):
     for level, step in ((3, 97), (1, 211), (19, 151)):
         payload = b"".join(zstd_ref.compress_magicless(p, level, True, flush_every=step) for p in parts)
         out.append(("multi_frame_l%d_flush%d" % (level, step), payload, b"".join(parts)))
+    # ... and every frame with its Content_Checksum (one workgroup of k_xxh64_frames per frame)
+    payload = b"".join(zstd_ref.compress_magicless(p, 3, True, flush_every=97, checksum=(k != 1)) for k, p in enumerate(parts))
+    out.append(("multi_frame_checksums", payload, b"".join(parts)))
     # the Length section of equal-length reads: one whole-block run per block, each copying from the block
     # before it -- a chain of a few LONG matches, finished pass by pass (launch_lz_more_passes), not pointer-jumped
     words = (151).to_bytes(4, "little") * (400000 * scale)

@@ -158,6 +158,7 @@ hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t st);
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st);
 hipError_t hipMemset(void *d, int v, size_t n);
+hipError_t hipMemGetInfo(size_t *free_bytes, size_t *total_bytes);
 hipError_t hipStreamCreate(hipStream_t *s);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);

@@ -45,6 +45,12 @@ def test_zstd_multi_frame_many_blocks(emu):
     for name, payload, data in cases.zstd_payload_cases(scale=1):
         assert oracle.zstd_decode(payload, len(data)) == data, name
         assert emu.zstd_decompress(payload, len(data)) == data, name
+        if name == "multi_frame_checksums":                 # a wrong checksum in the last frame: refused by both
+            bad = payload[:-1] + bytes([payload[-1] ^ 0x80])
+            with pytest.raises(Exception, match="checksum"):
+                emu.zstd_decompress(bad, len(data))
+            with pytest.raises(Exception):
+                oracle.zstd_decode(bad, len(data))
 
 
 @pytest.mark.parametrize("name", ["LuxC", "masked", "phix", "CP040672", "NZ_AAEN01000029"])

@@ -104,6 +104,9 @@ def test_zstd_multi_frame_many_blocks(lib):
     for name, payload, data in cases.zstd_payload_cases(scale=2):
         assert oracle.zstd_decode(payload, len(data)) == data, name
         assert lib.zstd_decompress(payload, len(data)) == data, name
+        if name == "multi_frame_checksums":                 # a wrong Content_Checksum: Io(InvalidData), as libzstd refuses the frame
+            with pytest.raises(Exception, match="checksum"):
+                lib.zstd_decompress(payload[:-1] + bytes([payload[-1] ^ 0x80]), len(data))
 
 
 @pytest.mark.skipif(not zstd_ref.available(), reason="libzstd not loadable")

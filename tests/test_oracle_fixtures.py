@@ -270,3 +270,17 @@ def test_section_facts():  # Appendix C table: original -> compressed sizes, zst
     out, st = oracle.zstd_decode(golden_bytes("phix.naf")[off:off + comp], orig, stats=True)
     assert (orig, comp, st.sequences, st.lit_bytes) == (12436, 2605, 501, 2954)
     assert st.seq_mode_count[2] == st.seq_mode_count[6] == st.seq_mode_count[10] == 1  # all FSE-described
+
+
+@pytest.mark.parametrize("name", ["LuxC", "masked", "phix", "CP040672", "NZ_AAEN01000029"])
+def test_reference_shaped_pipeline_equals_the_checker(name):
+    """oracle/ref_shape.c (what bench.py's cpu_baseline leg times: streaming libzstd through 4 KiB buffers, per-nibble
+    push, one heap string per field and record) decodes every fixture to the same records as the checker."""
+    from oracle import oracle
+    if not oracle.ref_shape_available():
+        pytest.skip("libzstd.so.1 not loadable")
+    blob = golden_bytes(name + ".naf")
+    a, b = oracle.ref_shape_drain(blob), oracle.Decoder(blob).drain()
+    for field, _ in oracle.DrainResult._fields_:
+        assert getattr(a, field) == getattr(b, field), field
+    assert oracle.ref_shape_drain_parallel(blob, 3) == 3 * b.n_bases

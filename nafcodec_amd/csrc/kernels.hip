@@ -29,7 +29,8 @@ namespace {
 #define NAFGPU_ABLATE 0
 #endif
 constexpr uint32_t kAblate = NAFGPU_ABLATE;   // k_huf_decode: 1 no output stores, 2 no look-ups (rows fill instantly), 4 no input loads,
-                                              // 8 no table staging, 16 stores only to a small window, 32 no dictionary reads
+                                              // 8 no table staging, 16 stores only to a small window, 32 no dictionary reads,
+                                              // (fused mask) 64 no bit loads, 128 bits not applied in the flush, 256 bits not posted / rows not sorted
 
 __device__ inline void flag_error(uint32_t *status, uint32_t code, uint32_t detail) {
     if (kAblate) return;
@@ -158,14 +159,19 @@ struct HufLook {           // what one table look-up says about the next one or 
     uint32_t first;        // format-specific handle for "bits of the first symbol alone" (stream tail only)
 };
 
-template <bool ASCII, int TBL, bool SEG>
+// MASK: the soft mask is applied as the characters leave (flush): `mask_bits` holds one bit per output byte of the
+// section (k_mask_apply<true>), the owner of a row keeps the bits of its row's current unit in registers (loaded a round
+// ahead) and publishes them with the row.
+template <bool ASCII, int TBL, bool SEG, bool MASK>
 __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ src, const HufTask *__restrict__ tasks,
                                                    const HufTblCopy *__restrict__ copies,
                                                    const HufStream *__restrict__ streams,
                                                    const uint16_t *__restrict__ pool,
                                                    const uint64_t *__restrict__ blk_base, uint8_t *out, uint8_t *lit,
                                                    const SeqBlock *__restrict__ sblocks, const Seq *__restrict__ seqs,
-                                                   const uint8_t *__restrict__ dicts, uint32_t t_char, uint32_t *status) {
+                                                   const uint8_t *__restrict__ dicts, uint32_t t_char,
+                                                   const uint8_t *__restrict__ mask_bits, uint32_t *status) {
+    static_assert(!MASK || (ASCII && !SEG), "the fused mask is for nucleotide sections without LZ sequences");
     using G = HufGeom<TBL>;
     constexpr uint32_t kUnit = G::kUnit, kPitch = G::kPitch, kLanesPerRow = G::kLanesPerRow;
     constexpr uint32_t kRowsPerStore = G::kRowsPerStore, kStoreIters = G::kStoreIters, kUnitShift = G::kUnitShift;
@@ -174,9 +180,9 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[kRingWords * 64 * 4];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[64 * kPitch];
     __shared__ __attribute__((aligned(16))) uint32_t s_cunit[64];   // per round: descriptors of the ready rows, compacted (see publish)
-    __shared__ uint32_t s_h[64];       // first row coordinate that belongs to this stream (segment)
-    __shared__ uint32_t s_q[64];       // row coordinate of the next write
-    __shared__ uint32_t s_fl[64];      // row coordinate of the row's byte 0 (multiple of kUnit)
+    __shared__ uint32_t s_pv[64];      // incomplete units (publish): first valid byte of the row | bytes in the row << 8
+    constexpr uint32_t kMaskWords = G::kUnit / 32;         // mask bits of one unit
+    __shared__ __attribute__((aligned(16))) uint32_t s_mask[MASK ? 64 * kMaskWords : 4];
 
     // compact tables: characters of a packed byte, shared by all the trees of the task
     __shared__ uint16_t s_lut[(TBL == kTblCompact && ASCII) ? 256 : 2];
@@ -400,7 +406,6 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         my_low = (reinterpret_cast<uintptr_t>(src) + st.src_end - st.src_len - 384u) & ~static_cast<uint64_t>(127);
     }
     wave_sync();                                           // (dict staging scratch is dead)
-    s_h[lane] = h;
     {   // wave minima of my_dst / my_low through the (still unused) output rows
         uint64_t *scratch = reinterpret_cast<uint64_t *>(s_out);
         scratch[lane] = my_dst;
@@ -438,6 +443,34 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     const __amdgpu_buffer_rsrc_t rs_src =
         __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(static_cast<uintptr_t>(sbase)), 0, static_cast<int>(kBufRange), kBufWord3);
 
+    // ---- soft mask (MASK): bits of the unit this lane's row is filling
+    uint32_t mreg[kMaskWords] = {};
+    auto load_mask = [&](uint32_t ahead) {
+        if constexpr (MASK && !(kAblate & 64u)) {
+            const uint8_t *mp = mask_bits + ((dbase + dst_rel + rbase + ahead) >> 3);   // unit-aligned position: 16- (8-) byte aligned address
+            if constexpr (kMaskWords == 4) {
+                const uint4 m = *reinterpret_cast<const uint4 *>(mp);
+                mreg[0] = m.x;
+                mreg[1] = m.y;
+                mreg[2] = m.z;
+                mreg[3] = m.w;
+            } else {
+                const uint2 m = *reinterpret_cast<const uint2 *>(mp);
+                mreg[0] = m.x;
+                mreg[1] = m.y;
+            }
+        }
+    };
+    auto post_mask = [&]() {                               // the row's bits where the flush finds them
+        if constexpr (MASK && !(kAblate & 256u)) {
+            if constexpr (kMaskWords == 4)
+                *reinterpret_cast<uint4 *>(&s_mask[4 * lane]) = make_uint4(mreg[0], mreg[1], mreg[2], mreg[3]);
+            else
+                *reinterpret_cast<uint2 *>(&s_mask[2 * lane]) = make_uint2(mreg[0], mreg[1]);
+        }
+    };
+    if (MASK && have) load_mask(0);
+    post_mask();
     // ---- input.  The stream is consumed in 32-byte aligned PIECES, numbered backwards from the one
     // that holds its last byte (piece j = bytes [ptop - 32 j, ptop - 32 j + 32); ring word 8 j + i is the
     // dword at offset 28 - 4 i of piece j).  Pieces come out of a whole 128-byte LINE that the lane keeps
@@ -491,6 +524,7 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     // The first and last unit of a stream or segment (bytes of a neighbour / not produced yet) are
     // written byte-wise.
     const uint32_t oct = lane % kLanesPerRow, grp = lane / kLanesPerRow;
+    uint32_t n_cls0 = 0, n_cls01 = 0;                      // set by publish (MASK): ready rows the mask leaves alone; those plus the rows it covers whole
     uint32_t n_part = 0;                                   // set by publish: rows whose unit is incomplete (uniform)
     bool took_partial = false;                             // set by publish: this lane's row goes out as an incomplete unit
     auto publish = [&](bool lane_final) -> uint32_t {      // returns the number of ready rows
@@ -498,16 +532,34 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         const bool ready = have && (avail >= kUnit || (lane_final && avail > 0));
         const bool full = rbase >= h && avail >= kUnit;
         const unsigned long long m = __ballot(ready ? 1 : 0);
-        const uint32_t rank = static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+        uint32_t rank = static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+        if constexpr (MASK && !(kAblate & 256u)) {
+            // rows are listed by what the mask does to their unit -- nothing, all of it, part of it -- so that most
+            // store instructions of the flush meet one kind only: the bit-to-character expansion is then run for the
+            // few instructions that hold a unit with a run boundary inside, not for all of them
+            uint32_t any = mreg[0] | mreg[1], all = mreg[0] & mreg[1];
+            if constexpr (kMaskWords == 4) {
+                any |= mreg[2] | mreg[3];
+                all &= mreg[2] & mreg[3];
+            }
+            const uint32_t cls = any == 0 ? 0u : (all == ~0u ? 1u : 2u);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const unsigned long long m1 = __ballot(ready && cls == 1u ? 1 : 0), m2 = __ballot(ready && cls == 2u ? 1 : 0);
+            const unsigned long long m0 = m & ~m1 & ~m2;
+            n_cls0 = static_cast<uint32_t>(__popcll(m0));
+            n_cls01 = n_cls0 + static_cast<uint32_t>(__popcll(m1));
+            rank = cls == 0 ? static_cast<uint32_t>(__popcll(m0 & below))
+                            : (cls == 1 ? n_cls0 + static_cast<uint32_t>(__popcll(m1 & below)) : n_cls01 + static_cast<uint32_t>(__popcll(m2 & below)));
+        }
         if (ready)
             s_cunit[(rank % kRowsPerStore) * kStoreIters + (rank / kRowsPerStore)] =
                 (((dst_rel + rbase) >> kUnitShift) << 7) | (lane << 1) | (full ? 1u : 0u);
+        // (MASK) s_mask already holds the bits of every row's current unit (post_mask); a row that is about to give
+        // its unit away asks for the bits of the one behind it now, a whole round before they are wanted
+        if (MASK && ready && avail >= kUnit) load_mask(kUnit);
         took_partial = ready && avail < kUnit;
         n_part = static_cast<uint32_t>(__popcll(__ballot(ready && !full ? 1 : 0)));
-        if (n_part) {                                      // only the byte-wise path needs these
-            s_q[lane] = rbase + avail;
-            s_fl[lane] = rbase;
-        }
+        if (n_part) s_pv[lane] = (h > rbase ? h - rbase : 0u) | (avail << 8);   // only the byte-wise path needs these
         return static_cast<uint32_t>(__popcll(m));
     };
     auto flush = [&](uint32_t n_ready) {
@@ -532,23 +584,33 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
                 const uint32_t ck = s_cunit[grp * kStoreIters + k];
                 if (kRowsPerStore * k + grp >= n_ready || (ck & 1u)) continue;
                 const uint32_t row = (ck >> 1) & 63u, pos = (ck >> 7) << kUnitShift;
-                const uint32_t rfl = s_fl[row], rq = s_q[row], rh = s_h[row];
-                const uint32_t lo_x = rfl + 16 * oct, hi_x = lo_x + 16;
+                const uint32_t pv = s_pv[row], rh = pv & 0xFFu, rq = pv >> 8;      // (unit-relative: the row's byte 0 is 0)
+                const uint32_t lo_x = 16 * oct, hi_x = lo_x + 16;
                 const uint32_t v_lo = lo_x > rh ? lo_x : rh, v_hi = hi_x < rq ? hi_x : rq;
                 uint8_t *d = obase + pos + 16 * oct;
                 const uint8_t *rowp = s_out + row * kPitch + 16 * oct;
+                const uint32_t mb = MASK ? reinterpret_cast<const uint16_t *>(s_mask)[row * kLanesPerRow + oct] : 0u;
 #pragma clang loop vectorize(disable) unroll(disable)
-                for (uint32_t x = v_lo; x < v_hi; x++) d[x - lo_x] = rowp[x - lo_x];
+                for (uint32_t x = v_lo; x < v_hi; x++)
+                    d[x - lo_x] = static_cast<uint8_t>(rowp[x - lo_x] | (((mb >> (x - lo_x)) & 1u) << 5));
             }
         }
         uint2 w[kStoreIters][2];                           // all LDS reads first: the stores then go out back to back
+        uint32_t mbits[kStoreIters];
 #pragma unroll
         for (uint32_t k = 0; k < kStoreIters; k++) {
             if (kRowsPerStore * k >= n_ready) break;       // uniform
-            const uint8_t *rowp = s_out + ((c[k] >> 1) & 63u) * kPitch + 16 * oct;
+            const uint32_t row = (c[k] >> 1) & 63u;
+            const uint8_t *rowp = s_out + row * kPitch + 16 * oct;
             w[k][0] = *reinterpret_cast<const uint2 *>(rowp);
             w[k][1] = *reinterpret_cast<const uint2 *>(rowp + 8);
+            if constexpr (MASK && !(kAblate & 128u)) {
+                if (kRowsPerStore * (k + 1) > n_cls0)      // (uniform) some row of this instruction is masked
+                    mbits[k] = reinterpret_cast<const uint16_t *>(s_mask)[row * kLanesPerRow + oct];
+            }
         }
+        // four mask bits -> bit 5 of four characters
+        auto spread = [](uint32_t nib) -> uint32_t { return ((__umul24(nib, 0x00204081u) & 0x01010101u) << 5); };
 #pragma unroll
         for (uint32_t k = 0; k < kStoreIters; k++) {
             if (kRowsPerStore * k >= n_ready) break;       // uniform
@@ -560,6 +622,20 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
             v[1] = w[k][0].y;
             v[2] = w[k][1].x;
             v[3] = w[k][1].y;
+            if constexpr (MASK && !(kAblate & 128u)) {
+                if (kRowsPerStore * (k + 1) > n_cls01) {   // (uniform) a unit with a run boundary inside
+                    v[0] |= spread(mbits[k] & 15u);
+                    v[1] |= spread((mbits[k] >> 4) & 15u);
+                    v[2] |= spread((mbits[k] >> 8) & 15u);
+                    v[3] |= spread(mbits[k] >> 12);
+                } else if (kRowsPerStore * (k + 1) > n_cls0) {   // whole units only: all of the 16 characters or none
+                    const uint32_t mm = mbits[k] ? 0x20202020u : 0u;
+                    v[0] |= mm;
+                    v[1] |= mm;
+                    v[2] |= mm;
+                    v[3] |= mm;
+                }
+            }
             __builtin_amdgcn_raw_buffer_store_b128(v, rs_dst, voff, 0, 0);
         }
     };
@@ -765,13 +841,14 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
             rbase = 0;
             wa = orow + h;
             end_abs = h + seg_len * kOutB;
-            s_h[lane] = h;
         }
         if (TBL == kTblDict) decode_round_dict();
         else if (TBL == kTblCompact && task_esc) decode_round_compact(std::true_type{});
         else if (TBL == kTblCompact) decode_round_compact(std::false_type{});
         else if (task_esc) decode_round(std::true_type{});
         else decode_round(std::false_type{});
+        // (waits for the mask bits requested at the start of the round -- where the wait for the line below is anyway)
+        post_mask();
         // ---- land the next piece, if the ring has room for it.
         // d = words between the oldest ring slot and the cursor; staged past the cursor = 16 - d;
         // 8 words fit once d >= 8.  A round uses <= 6 words + 2 of look-ahead, and d >= 8 whenever
@@ -789,6 +866,7 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         flush(n_ready);
         wave_sync();
         const uint32_t avail = static_cast<uint32_t>(wa - orow);
+        post_mask();
         if (avail > kUnit) {
             for (uint32_t j = 0; j < 64; j += 8) *reinterpret_cast<uint2 *>(orow + j) = *reinterpret_cast<const uint2 *>(orow + kUnit + j);
             wa -= kUnit;
@@ -1020,24 +1098,35 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint8_t *in, uint64_t
     if (threadIdx.x == 0) tiles[blockIdx.x] = tot;
 }
 
-// single workgroup: exclusive scan of the tile aggregates in place; grand total -> totals
+// single workgroup: exclusive scan of the tile aggregates in place; grand total -> totals.  Every thread adds up a
+// contiguous share of the tiles, one workgroup scan joins the shares, every thread rewrites its share (one pass of
+// synchronisation whatever the number of tiles: 18 k tiles of a 37 MB Mask section took 0.43 ms tile row by tile row).
 __global__ __launch_bounds__(256) void k_scan_tiles(TileAgg *tiles, uint64_t n_tiles, ScanTotals *totals) {
     __shared__ uint64_t s_sum[kScanThreads];
     __shared__ uint32_t s_cnt[kScanThreads];
-    uint64_t run_sum = 0, run_cnt = 0;
-    for (uint64_t base = 0; base < n_tiles; base += kScanThreads) {
-        const uint64_t i = base + threadIdx.x;
-        TileAgg a{0, 0};
-        if (i < n_tiles) a = tiles[i];
-        uint64_t sum = a.sum;
-        uint32_t cnt = static_cast<uint32_t>(a.cnt);     // a tile holds at most kScanTile terminators
-        TileAgg tot;
-        block_scan_pair(sum, cnt, &tot, s_sum, s_cnt);
-        if (i < n_tiles) tiles[i] = TileAgg{run_sum + sum, run_cnt + cnt};
-        run_sum += tot.sum;
-        run_cnt += tot.cnt;
+    const uint64_t per = (n_tiles + kScanThreads - 1) / kScanThreads;
+    const uint64_t lo = threadIdx.x * per < n_tiles ? threadIdx.x * per : n_tiles;
+    const uint64_t hi = lo + per < n_tiles ? lo + per : n_tiles;
+    uint64_t sum = 0, cnt64 = 0;
+    for (uint64_t i = lo; i < hi; i++) {
+        const TileAgg a = tiles[i];
+        sum += a.sum;
+        cnt64 += a.cnt;
     }
-    if (threadIdx.x == 0) {
+    // (a share may hold more than 2^32 terminators: the counts go through the 64-bit channel of a second scan)
+    uint32_t z = 0;
+    TileAgg tot;
+    block_scan_pair(sum, z, &tot, s_sum, s_cnt);
+    z = 0;
+    block_scan_pair(cnt64, z, &tot, s_sum, s_cnt);
+    uint64_t run_sum = sum, run_cnt = cnt64;
+    for (uint64_t i = lo; i < hi; i++) {
+        const TileAgg a = tiles[i];
+        tiles[i] = TileAgg{run_sum, run_cnt};
+        run_sum += a.sum;
+        run_cnt += a.cnt;
+    }
+    if (threadIdx.x == kScanThreads - 1) {
         totals->sum = run_sum;
         totals->count = run_cnt;
     }
@@ -1312,7 +1401,7 @@ constexpr uint32_t kCopySlice = 8u << 10;
 template <bool ASCII>
 __global__ __launch_bounds__(256) void k_copy_fill(const uint8_t *__restrict__ src, const CopyTask *__restrict__ tasks,
                                                    const uint64_t *__restrict__ blk_base, uint8_t *out, uint8_t *lit,
-                                                   uint32_t t_char, const uint32_t *status) {
+                                                   uint32_t t_char, const uint8_t *__restrict__ mask_bits, const uint32_t *status) {
     if (status[0] != 0) return;
     const CopyTask t = tasks[blockIdx.x];
     const bool fill = (t.flags & 2) != 0;
@@ -1322,9 +1411,17 @@ __global__ __launch_bounds__(256) void k_copy_fill(const uint8_t *__restrict__ s
     const uint32_t lo = blockIdx.y * kCopySlice;
     const uint32_t hi = lo + kCopySlice < t.len ? lo + kCopySlice : t.len;
     if (ASCII && !(t.flags & 1)) {                       // nucleotide section: expand while copying
-        uint16_t *d = reinterpret_cast<uint16_t *>(out) + blk_base[t.blk] + t.dst;
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
-            d[i] = static_cast<uint16_t>(byte_chars(fill ? fv : s[i], t_char));
+        const uint64_t e0 = blk_base[t.blk] + t.dst;
+        uint16_t *d = reinterpret_cast<uint16_t *>(out) + e0;
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            uint32_t ch = byte_chars(fill ? fv : s[i], t_char);
+            if (mask_bits) {                             // soft mask fused into the writers (see k_mask_apply<true>): bit x = output byte x
+                const uint64_t x = 2 * (e0 + i);
+                const uint32_t m = mask_bits[x >> 3] >> (x & 7);
+                ch |= ((m & 1u) << 5) | ((m & 2u) << 12);
+            }
+            d[i] = static_cast<uint16_t>(ch);
+        }
     } else {
         uint8_t *d = (t.flags & 1) ? lit + t.dst : out + blk_base[t.blk] + t.dst;
         for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) d[i] = fill ? fv : s[i];
@@ -2177,10 +2274,32 @@ __device__ inline uint32_t lower4(uint32_t w) {
     return w | (up >> 2);
 }
 
+// marks[0..n]: ascending base positions; bounds[i] = the run that holds base marks[i] (first run whose end is beyond it)
+__global__ void k_mask_bounds(const uint64_t *__restrict__ mask_ends, const ScanTotals *mask_totals, const uint64_t *marks, uint32_t n,
+                              uint64_t *bounds) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t w = marks[i];
+    uint64_t lo = 0, hi = mask_totals->count;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (mask_ends[mid] > w)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    bounds[i] = lo;
+}
+
+// BITS: instead of lower-casing characters the kernel sets, in a bit map that was zeroed before, the bits of the bases
+// to lower-case (bit x = base `shift` + x; `ascii` is the map): what k_huf_decode's flush and k_copy_fill then OR
+// into the characters as they write them, so that the sequence is not read and written a second time.
+template <bool BITS>
 __global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_bases, uint64_t lo_clamp, uint64_t hi_clamp,
                                                     const uint64_t *__restrict__ mask_ends,
                                                     const ScanTotals *mask_totals, const uint64_t *__restrict__ rec_ends,
-                                                    const ScanTotals *rec_totals, int spec_mask, const uint32_t *status) {
+                                                    const ScanTotals *rec_totals, int spec_mask, uint64_t shift,
+                                                    const uint64_t *__restrict__ run_bounds, const uint32_t *status) {
     // A workgroup takes 256 consecutive masked runs.  Phase 1: one run per thread -- clamp it and
     // (reference behaviour) find the record that holds its last base with a binary search, 256
     // searches in flight at once.  Phase 2: the runs are cut into 16-byte aligned chunks, an exclusive
@@ -2194,21 +2313,25 @@ __global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_b
     const uint64_t n_runs = mask_totals->count;
     const uint64_t n_rec = rec_totals->count;
     const uint32_t tid = threadIdx.x;
-    const uint64_t skew = reinterpret_cast<uintptr_t>(ascii) & 15;   // a shard's base pointer need not be 16-byte aligned
+    const uint64_t skew = BITS ? 0 : reinterpret_cast<uintptr_t>(ascii) & 15;   // a shard's base pointer need not be 16-byte aligned
     uint8_t *const abase = ascii - skew;
-    for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * 256; 2 * base + 1 < n_runs && !abort_now;
+    constexpr uint32_t kChunkShift = BITS ? 7 : 4;         // a chunk: 16 characters, or 128 bits of the map
+    // run_bounds (or null: all runs): the runs that hold the first and the last base of [lo_clamp, hi_clamp) (k_mask_bounds)
+    const uint64_t k0 = run_bounds ? (run_bounds[0] | 1ull) : 1ull;
+    const uint64_t k_end = run_bounds && run_bounds[1] + 1 < n_runs ? run_bounds[1] + 1 : n_runs;
+    for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * 256; k0 + 2 * base < k_end && !abort_now;
          base += static_cast<uint64_t>(gridDim.x) * 256) {
-        const uint64_t k = 2 * (base + tid) + 1;           // odd runs are the masked ones
+        const uint64_t k = k0 + 2 * (base + tid);          // odd runs are the masked ones
         uint64_t s = 0, e = 0;
-        if (k < n_runs) {
+        if (k < k_end) {
             s = mask_ends[k - 1];
             e = mask_ends[k];
             if (s >= n_bases) {
                 s = e = 0;
             } else if (e > n_bases) {                      // MaskReader stops at `total`: the overshoot is never applied
-                e = (spec_mask & 0xFF) ? n_bases : s;
+                e = spec_mask ? n_bases : s;
             }
-            if (e > s && !(spec_mask & 0x2FF)) {
+            if (e > s && !spec_mask) {
                 uint64_t lo = 0, hi = n_rec;               // first record whose end is > e - 1
                 while (lo < hi) {
                     const uint64_t mid = (lo + hi) >> 1;
@@ -2232,11 +2355,15 @@ __global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_b
             if (s < lo_clamp) s = lo_clamp;
             if (e > hi_clamp) e = hi_clamp;
             if (e < s) e = s;
+            if (BITS) {                                    // map coordinates (the host passes lo_clamp >= shift)
+                s -= shift;
+                e -= shift;
+            }
         }
         __syncthreads();                                   // previous round's readers are done
         s_lo[tid] = s;
         s_hi[tid] = e;
-        s_pre[0][tid + 1] = e > s ? ((e + skew + 15) >> 4) - ((s + skew) >> 4) : 0;
+        s_pre[0][tid + 1] = e > s ? ((e + skew + (1u << kChunkShift) - 1) >> kChunkShift) - ((s + skew) >> kChunkShift) : 0;
         if (tid == 0) s_pre[0][0] = s_pre[1][0] = 0;
         __syncthreads();
         uint32_t cur = 0;
@@ -2247,7 +2374,37 @@ __global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_b
             __syncthreads();
         }
         const uint64_t *pre = s_pre[cur];                  // pre[r] = chunks of runs 0..r-1
-        const uint64_t total = (spec_mask & 0x100) ? 0 : pre[256];
+        const uint64_t total = pre[256];
+        if constexpr (BITS) {
+            for (uint64_t c = tid; c < total; c += 256) {
+                uint32_t lo = 0, hi = 256;                 // largest r with pre[r] <= c
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (pre[mid] <= c)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                const uint64_t rs = s_lo[lo], re = s_hi[lo];
+                const uint64_t a = ((rs >> 7) + (c - pre[lo])) << 7;
+                const uint64_t e0 = a > rs ? a : rs, e1 = a + 128 < re ? a + 128 : re;
+                uint32_t *wp = reinterpret_cast<uint32_t *>(abase) + (a >> 5);
+                if (e1 - e0 == 128) {                      // a chunk inside the run: nobody else writes it
+                    *reinterpret_cast<uint4 *>(wp) = make_uint4(~0u, ~0u, ~0u, ~0u);
+                } else {                                   // shared with a neighbour
+#pragma unroll
+                    for (uint32_t d = 0; d < 4; d++) {
+                        const uint64_t w0 = a + 32 * d;
+                        const uint64_t b0 = e0 > w0 ? e0 : w0, b1 = e1 < w0 + 32 ? e1 : w0 + 32;
+                        if (b1 > b0) {
+                            const uint32_t n = static_cast<uint32_t>(b1 - b0);
+                            atomicOr(wp + d, (n == 32 ? ~0u : (1u << n) - 1u) << static_cast<uint32_t>(b0 - w0));
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         // four chunks per thread and step: the loads of all four are in flight before the first store
         for (uint64_t c0 = tid; c0 < total; c0 += 4 * 256) {
             uint64_t addr[4], e0[4], e1[4];
@@ -2565,37 +2722,40 @@ void launch_fmt_write(hipStream_t stream, const FmtText &t, const uint64_t *off,
 
 void launch_copy_fill(hipStream_t stream, const uint8_t *src, const CopyTask *tasks, uint32_t n_tasks,
                       const uint64_t *blk_base, uint8_t *out, uint8_t *lit, bool ascii, uint32_t t_char,
-                      uint32_t *status) {
+                      const uint8_t *mask_bits, uint32_t *status) {
     if (!n_tasks) return;
     if (ascii)
         hipLaunchKernelGGL(k_copy_fill<true>, dim3(n_tasks, kBlockMax / kCopySlice), dim3(256), 0, stream, src, tasks, blk_base, out, lit, t_char,
-                           status);
+                           mask_bits, status);
     else
         hipLaunchKernelGGL(k_copy_fill<false>, dim3(n_tasks, kBlockMax / kCopySlice), dim3(256), 0, stream, src, tasks, blk_base, out, lit, t_char,
-                           status);
+                           static_cast<const uint8_t *>(nullptr), status);
 }
 
 void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *tasks, const HufClass &cls,
                        const HufTblCopy *copies, const HufStream *streams, const uint16_t *pool,
                        const uint64_t *blk_base, uint8_t *out, uint8_t *lit, const SeqBlock *seq_blocks, const Seq *seqs,
-                       const uint8_t *dicts, bool ascii, uint32_t t_char, uint32_t *status) {
+                       const uint8_t *dicts, bool ascii, uint32_t t_char, const uint8_t *mask_bits, uint32_t *status) {
     if (!cls.n_tasks) return;
     const uint32_t lds = (cls.lds_bytes + 15u) & ~15u;
     const bool a = ascii && !cls.to_lit;                   // the literal buffer always holds packed bytes
+    const bool masked = mask_bits && a && !cls.seg;        // (the host only passes a bit map for sections without sequences)
     const HufTask *t0 = tasks + cls.first_task;
-#define NAFGPU_LAUNCH_HUF(A, T, S)                                                                                            \
-    hipLaunchKernelGGL((k_huf_decode<A, T, S>), dim3(cls.n_tasks), dim3(64), lds, stream, src, t0, copies, streams, pool,     \
-                       blk_base, out, lit, seq_blocks, seqs, dicts, t_char, status)
+#define NAFGPU_LAUNCH_HUF(A, T, S, M)                                                                                         \
+    hipLaunchKernelGGL((k_huf_decode<A, T, S, M>), dim3(cls.n_tasks), dim3(64), lds, stream, src, t0, copies, streams, pool,  \
+                       blk_base, out, lit, seq_blocks, seqs, dicts, t_char, mask_bits, status)
 #define NAFGPU_LAUNCH_HUF_T(T)                       \
     do {                                             \
-        if (a && cls.seg)                            \
-            NAFGPU_LAUNCH_HUF(true, T, true);        \
+        if (masked)                                  \
+            NAFGPU_LAUNCH_HUF(true, T, false, true); \
+        else if (a && cls.seg)                       \
+            NAFGPU_LAUNCH_HUF(true, T, true, false); \
         else if (a)                                  \
-            NAFGPU_LAUNCH_HUF(true, T, false);       \
+            NAFGPU_LAUNCH_HUF(true, T, false, false);\
         else if (cls.seg)                            \
-            NAFGPU_LAUNCH_HUF(false, T, true);       \
+            NAFGPU_LAUNCH_HUF(false, T, true, false);\
         else                                         \
-            NAFGPU_LAUNCH_HUF(false, T, false);      \
+            NAFGPU_LAUNCH_HUF(false, T, false, false);\
     } while (0)
     if (cls.tbl == kTblBaked)
         NAFGPU_LAUNCH_HUF_T(kTblBaked);
@@ -2703,20 +2863,36 @@ void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed
                        n_bases, t_char, status);
 }
 
-void launch_mask_apply(hipStream_t stream, uint8_t *ascii, uint64_t n_bases, uint64_t lo_clamp, uint64_t hi_clamp,
-                       const uint64_t *mask_ends, const ScanTotals *mask_totals, const uint64_t *rec_ends,
-                       const ScanTotals *rec_totals, uint64_t max_runs, int spec_mask, uint32_t *status) {
-    if (!n_bases || !max_runs || hi_clamp <= lo_clamp) return;
+static uint32_t mask_grid(uint64_t max_runs) {
     const uint64_t masked_runs = (max_runs + 1) / 2;
     uint64_t blocks = (masked_runs + 255) / 256;
     if (blocks > 256u * 8u) blocks = 256u * 8u;
-    if (blocks == 0) blocks = 1;
-    static const int dbg = [] {                          // timing ablations only; results are wrong when set
-        const char *e = std::getenv("NAFGPU_MASK_DEBUG");
-        return e ? std::atoi(e) : 0;
-    }();
-    hipLaunchKernelGGL(k_mask_apply, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, ascii, n_bases, lo_clamp,
-                       hi_clamp, mask_ends, mask_totals, rec_ends, rec_totals, spec_mask | (dbg << 8), status);
+    return blocks ? static_cast<uint32_t>(blocks) : 1u;
+}
+
+void launch_mask_apply(hipStream_t stream, uint8_t *ascii, uint64_t n_bases, uint64_t lo_clamp, uint64_t hi_clamp,
+                       const uint64_t *mask_ends, const ScanTotals *mask_totals, const uint64_t *rec_ends,
+                       const ScanTotals *rec_totals, uint64_t max_runs, int spec_mask, uint32_t *status, const uint64_t *run_bounds,
+                       uint32_t grid_div) {
+    if (!n_bases || !max_runs || hi_clamp <= lo_clamp) return;
+    uint32_t grid = mask_grid(max_runs);
+    if (grid_div > 1) grid = grid / grid_div > 64 ? grid / grid_div : (grid < 64 ? grid : 64);
+    hipLaunchKernelGGL(k_mask_apply<false>, dim3(grid), dim3(256), 0, stream, ascii, n_bases, lo_clamp, hi_clamp,
+                       mask_ends, mask_totals, rec_ends, rec_totals, spec_mask, 0ull, run_bounds, status);
+}
+
+void launch_mask_bounds(hipStream_t stream, const uint64_t *mask_ends, const ScanTotals *mask_totals, const uint64_t *marks, uint32_t n,
+                        uint64_t *bounds) {
+    if (n) hipLaunchKernelGGL(k_mask_bounds, dim3((n + 63) / 64), dim3(64), 0, stream, mask_ends, mask_totals, marks, n, bounds);
+}
+
+void launch_mask_bits(hipStream_t stream, uint8_t *bits, size_t bits_bytes, uint64_t n_bases, uint64_t lo_clamp, uint64_t hi_clamp,
+                      const uint64_t *mask_ends, const ScanTotals *mask_totals, const uint64_t *rec_ends,
+                      const ScanTotals *rec_totals, uint64_t max_runs, int spec_mask, uint32_t *status) {
+    (void)hipMemsetAsync(bits, 0, bits_bytes, stream);
+    if (!n_bases || !max_runs || hi_clamp <= lo_clamp) return;
+    hipLaunchKernelGGL(k_mask_apply<true>, dim3(mask_grid(max_runs)), dim3(256), 0, stream, bits, n_bases, lo_clamp, hi_clamp,
+                       mask_ends, mask_totals, rec_ends, rec_totals, spec_mask, lo_clamp, static_cast<const uint64_t *>(nullptr), status);
 }
 
 void launch_xxh64_frames(hipStream_t stream, const XxhSeg *segs, uint32_t n_segs, const uint64_t *blk_base, const uint8_t *out,

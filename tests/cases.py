@@ -104,6 +104,7 @@ def build_cases(scale=1):
     # that resolves one must still produce no more than the row holds)
     dense = "".join(skewed(262144 + i, np.array([0.4 - 0.1 * i, 0.2, 0.1 + 0.1 * i, 0.3]), "NRY", 0.012) for i in range(3))
     add("dna_dense_escapes_dict", nw.write_naf([{"id": "e", "sequence": dense}], level=1))
+    dense_dna = dense
     # every IUPAC code in use: more than 64 byte values between the trees -> compact tables
     add("dna_multi_tree_compact", nw.write_naf(make_records(rng, [700001 * scale], iupac=0.05), level=1))
     # text with ~40 symbols, several blocks: dictionary tables without the ASCII expansion
@@ -145,6 +146,26 @@ def build_cases(scale=1):
     long_run = make_records(rng, [70000 * scale + 3, 40000])
     lt = sum(len(r["sequence"]) for r in long_run)
     add("mask_run_gt_65535", nw.write_naf(long_run, mask_runs=[10, 66000, lt - 66010]))
+
+    # the mask applied by the sequence's own writers (sections without LZ sequences: ArchiveJob::decode builds a bit map
+    # and k_huf_decode / k_copy_fill OR it in): each table format of K1, raw and RLE blocks, several blocks and tasks,
+    # runs of every length against unit and block boundaries; and a sequence WITH matches, which takes the separate pass
+    def random_runs(total, mean):
+        runs, left = [], total
+        while left > 0:
+            v = int(min(left, rng.integers(0, mean) if rng.random() < 0.7 else rng.integers(0, 40 * mean)))
+            runs.append(v)
+            left -= v
+        return runs
+    for nm, seq in (("mask_dict_tables", dense_dna),
+                    ("mask_compact_tables", rand_dna(rng, 700001 * scale, "ACGT", 0.05)),
+                    ("mask_raw_rle_blocks", "".join(rng.choice(list(nw.NUC), 262144)) + "C" * (524288 * scale) +     # raw and RLE blocks only
+                                            "".join(rng.choice(list(nw.NUC), 262144))),
+                    ("mask_with_matches", rand_dna(rng, 5000) * (40 * scale))):
+        cut = len(seq) // 3
+        recs_m = [{"id": "m0", "sequence": seq[:cut]}, {"id": "m1", "sequence": seq[cut:cut + 151]}, {"id": "m2", "sequence": seq[cut + 151:]}]
+        add(nm, nw.write_naf(recs_m, level=1, mask_runs=random_runs(len(seq), 60)))
+    add("mask_dict_tables_spec", nw.write_naf([{"id": "e", "sequence": dense_dna}], level=1, mask_runs=random_runs(len(dense_dna), 700)), spec_mask=True)
 
     # ---- field selection ---------------------------------------------------------------------
     fq = nw.write_naf(make_records(rng, [151] * 9, quality=True), quality=True, mask_runs=[100, 20, 151 * 9 - 120])

@@ -282,36 +282,6 @@ Failure SectionJob::load_tile(uint32_t t, hipStream_t stream) {
     if (!ok) return Failure::make(NAFGPU_E_DEVICE, "out of device memory while preparing a section");
     // the host vectors were consumed by asynchronous copies: keep them until the stream drains
     if (!hip_ok(hipStreamSynchronize(stream))) return Failure::make(NAFGPU_E_DEVICE, "upload of task lists failed");
-    // ---- segments (see set_segment_hook): block ranges of about equal size; a task belongs to the first segment
-    // that holds all of its streams, and a segment's mark is where the first task left for later starts writing
-    seg_mark_.clear();
-    seg_tasks_.clear();
-    const char *seg_env = std::getenv("NAFGPU_SEG_TASKS");                 // tests: tasks per segment (default 1024: half a chip-full)
-    const uint64_t seg_tasks = seg_env ? std::max<uint64_t>(1, std::strtoull(seg_env, nullptr, 10)) : 1024;
-    if (tiles_.size() == 1 && t_char_ != 0 && !has_lz_ && n_tasks_ >= 2 * seg_tasks && n_blocks_ >= 2) {
-        const uint32_t n_seg = static_cast<uint32_t>(std::min<uint64_t>(8, n_tasks_ / seg_tasks));
-        std::vector<uint64_t> blk_off(n_blocks_ + 1, 0);
-        for (size_t b = 0; b < n_blocks_; b++) blk_off[b + 1] = blk_off[b] + plan_.blk_size[b];
-        seg_tasks_.assign(classes_.size(), std::vector<uint32_t>(n_seg, 0));
-        for (uint32_t i = 0; i < n_seg; i++) {
-            const uint64_t b_end = i + 1 == n_seg ? n_blocks_ : n_blocks_ * (i + 1) / n_seg;
-            uint64_t mark = blk_off[b_end];
-            for (size_t c = 0; c < classes_.size(); c++) {
-                const HufClass &cl = classes_[c];
-                uint32_t k = i ? seg_tasks_[c][i - 1] : 0;
-                while (k < cl.n_tasks) {
-                    const HufTask &tk = plan_.tasks[cl.first_task + k];
-                    if (plan_.streams[tk.first_stream + tk.n_streams - 1].blk >= b_end) break;
-                    k++;
-                }
-                seg_tasks_[c][i] = k;
-                if (k < cl.n_tasks) mark = std::min(mark, blk_off[plan_.streams[plan_.tasks[cl.first_task + k].first_stream].blk]);
-            }
-            seg_mark_.push_back(mark);
-        }
-    }
-    if (std::getenv("NAFGPU_DEBUG_PLAN") && !seg_mark_.empty())
-        std::fprintf(stderr, "[nafgpu] section plan: %zu segments, first mark %llu\n", seg_mark_.size(), static_cast<unsigned long long>(seg_mark_[0]));
     // only the counts are needed from here on
     std::vector<HufStream>().swap(plan_.streams);
     std::vector<HufTableRef>().swap(plan_.stream_ref);
@@ -413,7 +383,7 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
     // kernels address the output as base + position inside the loaded selection
     uint8_t *const out_base = tile_out_base();
     launch_copy_fill(stream, d_src_, d_copies_.as<CopyTask>(), static_cast<uint32_t>(n_copies_),
-                     d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(), ascii, t_char_, mask_bits_, status);
+                     d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(), ascii, t_char_, status);
     if (timer) timer->end(stream);
     // K1, one launch per class.  Streams that write the section output (blocks without sequences, and -- segment by
     // segment -- blocks with a few) and streams that feed the literal buffer (blocks with many sequences).  When
@@ -422,43 +392,19 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
     auto launch_class = [&](const HufClass &c, hipStream_t st) {
         launch_huf_decode(st, d_src_, d_tasks_.as<HufTask>(), c, d_tbl_copies_.as<HufTblCopy>(), d_streams_.as<HufStream>(),
                           d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(), d_seq_blocks_.as<SeqBlock>(),
-                          d_seqs_.as<Seq>(), d_dicts_.bytes(), ascii, t_char_, mask_bits_, status);
+                          d_seqs_.as<Seq>(), d_dicts_.bytes(), ascii, t_char_, status);
     };
     bool have_direct = false, have_lit = false;
     for (const HufClass &c : classes_) (c.to_lit ? have_lit : have_direct) = true;
     if (have_direct || have_lit) {
         if (timer) timer->begin(stream, StageTimer::kHuf);
         bool forked = false;
-        const bool segmented = seg_hook_ && seg_mark_.size() > 1 && !have_lit;
-        if (segmented) {
-            if (!ev_fork_) (void)hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming);
-            if (!ev_join_) (void)hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming);
-            const bool two = aux && ev_fork_ && ev_join_ && hip_ok(hipEventRecord(ev_fork_, stream)) && hip_ok(hipStreamWaitEvent(aux, ev_fork_, 0));
-            uint64_t lo = 0;
-            for (uint32_t i = 0; i < seg_mark_.size(); i++) {
-                hipStream_t st = (two && (i & 1u)) ? aux : stream;
-                for (size_t c = 0; c < classes_.size(); c++) {
-                    const uint32_t t0 = i ? seg_tasks_[c][i - 1] : 0, t1 = seg_tasks_[c][i];
-                    if (t1 <= t0) continue;
-                    HufClass part = classes_[c];
-                    part.first_task += t0;
-                    part.n_tasks = t1 - t0;
-                    launch_class(part, st);
-                }
-                seg_hook_(i, lo, seg_mark_[i], st);
-                lo = seg_mark_[i];
-            }
-            if (two) {
-                (void)hipEventRecord(ev_join_, aux);
-                (void)hipStreamWaitEvent(stream, ev_join_, 0);
-            }
-        } else if (have_direct && have_lit && aux) {
+        if (have_direct && have_lit && aux) {
             if (!ev_fork_) (void)hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming);
             if (!ev_join_) (void)hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming);
             forked = ev_fork_ && ev_join_ && hip_ok(hipEventRecord(ev_fork_, stream)) && hip_ok(hipStreamWaitEvent(aux, ev_fork_, 0));
         }
-        if (segmented) {
-        } else if (forked) {
+        if (forked) {
             for (const HufClass &c : classes_)
                 if (c.to_lit) launch_class(c, aux);
             (void)hipEventRecord(ev_join_, aux);
@@ -561,9 +507,6 @@ Failure SectionJob::check(hipStream_t stream) {
 ArchiveJob::~ArchiveJob() {
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
-    for (hipEvent_t e : seg_ev_)
-        if (e) (void)hipEventDestroy(e);
-    if (mask_stream_) (void)hipStreamDestroy(mask_stream_);
     if (aux_stream_) (void)hipStreamDestroy(aux_stream_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -584,7 +527,6 @@ Failure ArchiveJob::init(int device) {
         e = hipStreamCreate(&stream_);
         if (!hip_ok(e)) return dev_fail("hipStreamCreate", e);
         if (!hip_ok(hipStreamCreate(&aux_stream_))) aux_stream_ = nullptr;   // optional: K1 then stays on one stream
-        if (!hip_ok(hipStreamCreate(&mask_stream_))) mask_stream_ = nullptr;  // optional: the mask then waits for the whole sequence
     }
     return Failure();
 }
@@ -678,56 +620,7 @@ Failure ArchiveJob::decode() {
         scans_forked = ev_fork_ && ev_join_ && hip_ok(hipEventRecord(ev_fork_, stream_)) &&
                        hip_ok(hipStreamWaitEvent(aux_stream_, ev_fork_, 0));
     }
-    // A nucleotide sequence without LZ sequences (what `ennaf` writes at its default level for genomes that do not
-    // repeat inside the window): the run tables first, then the mask as a bit map that the sequence's own writers
-    // apply -- the characters are not read and written a second time (mod.rs:386-388, 402-441 fused into the decode).
-    // Large ones are decoded in segments and the mask pass FOLLOWS the decode on its own stream, segment by segment:
-    // K1 does not saturate HBM, so the read-modify-write of the masked runs rides along and only the last
-    // segment's share of it is left when the decode ends.
-    const char *mode = std::getenv("NAFGPU_MASK_MODE");     // tests: "pass" (after the decode), "fused", "chase"
-    bool chase_mask = want_mask && is_nuc_ && mask_stream_ && job_[kSequence].segments() > 1 && (!mode || mode[0] == 'c');
-    if (chase_mask) {
-        for (uint32_t i = 0; i < job_[kSequence].segments() && chase_mask; i++)
-            if (!seg_ev_[i] && !hip_ok(hipEventCreateWithFlags(&seg_ev_[i], hipEventDisableTiming))) chase_mask = false;
-        if (!ev_fork_) (void)hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming);
-        if (!ev_join_) (void)hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming);
-        chase_mask = chase_mask && ev_fork_ && ev_join_ && d_seg_marks_.alloc(18 * sizeof(uint64_t));
-    }
-    const bool fuse_mask = !chase_mask && want_mask && is_nuc_ && job_[kSequence].can_fuse_mask() && mode && mode[0] == 'f' &&
-                           d_mask_bits_.alloc(static_cast<size_t>(job_[kSequence].out_bytes() / 8 + 64));
-    job_[kSequence].set_mask_bits(nullptr);
-    job_[kSequence].set_segment_hook(nullptr);
-    if (chase_mask) {
-        SectionJob &j = job_[kSequence];
-        const uint32_t n_seg = j.segments();
-        const uint64_t base0 = j.shard_out0() * 2;
-        seg_marks_host_[0] = base0;
-        for (uint32_t i = 0; i < n_seg; i++) seg_marks_host_[i + 1] = base0 + 2 * j.segment_mark(i);
-        uint64_t *d_marks = d_seg_marks_.as<uint64_t>(), *d_bounds = d_marks + 9;
-        scans_forked = false;
-        (void)hipEventRecord(ev_fork_, stream_);
-        (void)hipStreamWaitEvent(mask_stream_, ev_fork_, 0);
-        (void)hipMemcpyAsync(d_marks, seg_marks_host_, (n_seg + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, mask_stream_);
-        scans(mask_stream_);
-        launch_mask_bounds(mask_stream_, d_mask_ends_.as<uint64_t>(), &totals[1], d_marks, n_seg + 1, d_bounds);
-        uint8_t *seq = j.out_mut() - base0;                 // addressed by global base index
-        j.set_segment_hook([this, seq, base0, d_bounds, totals, status, n_seg](uint32_t i, uint64_t lo, uint64_t hi, hipStream_t done_on) {
-            (void)hipEventRecord(seg_ev_[i], done_on);
-            (void)hipStreamWaitEvent(mask_stream_, seg_ev_[i], 0);
-            launch_mask_apply(mask_stream_, seq, mask_total_bases_, base0 + 2 * lo, base0 + 2 * hi, d_mask_ends_.as<uint64_t>(), &totals[1],
-                              d_rec_ends_.as<uint64_t>(), &totals[0], mask_cap_, opt_.spec_mask ? 1 : 0, status, d_bounds + i, n_seg);
-        });
-    } else if (fuse_mask) {
-        scans_forked = false;
-        timer_.begin(stream_, StageTimer::kOther);
-        scans(stream_);
-        const SectionJob &j = job_[kSequence];
-        launch_mask_bits(stream_, d_mask_bits_.bytes(), d_mask_bits_.size(), mask_total_bases_, j.shard_out0() * 2, j.shard_out1() * 2,
-                         d_mask_ends_.as<uint64_t>(), &totals[1], d_rec_ends_.as<uint64_t>(), &totals[0], mask_cap_,
-                         opt_.spec_mask ? 1 : 0, status);
-        timer_.end(stream_);
-        job_[kSequence].set_mask_bits(d_mask_bits_.bytes());
-    } else if (scans_forked) {
+    if (scans_forked) {
         scans(aux_stream_);
         (void)hipEventRecord(ev_join_, aux_stream_);
     }
@@ -751,19 +644,14 @@ Failure ArchiveJob::decode() {
         }
     }
     timer_.begin(stream_, StageTimer::kOther);
-    if (chase_mask) {
-        job_[kSequence].set_segment_hook(nullptr);
-        (void)hipEventRecord(ev_join_, mask_stream_);
+    if (scans_forked)
         (void)hipStreamWaitEvent(stream_, ev_join_, 0);
-    } else if (scans_forked) {
-        (void)hipStreamWaitEvent(stream_, ev_join_, 0);
-    } else if (!fuse_mask) {
+    else
         scans(stream_);
-    }
     // (nucleotide sequence sections come out of their SectionJob already expanded to ASCII:
     //  SequenceReader::read_nucleotide, reader.rs:121-172, is fused into the zstd kernels)
     want_mask_ = want_mask;
-    if (want_mask && !fuse_mask && !chase_mask) apply_mask_to_held();                           // mod.rs:386-388, 402-441
+    if (want_mask) apply_mask_to_held();                           // mod.rs:386-388, 402-441
     timer_.end(stream_);
     // ids / comments: CStringReader (reader.rs:22-30) as a scan; UTF-8 validity of every text section
     // (into_string().expect at mod.rs:362,368; from_utf8 at reader.rs:108-109) as one flag word

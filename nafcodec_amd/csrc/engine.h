@@ -17,7 +17,6 @@
 
 #include <cstdint>
 #include <string>
-#include <functional>
 #include <vector>
 
 #include "container.h"
@@ -103,18 +102,6 @@ public:
     void run(hipStream_t stream, StageTimer *timer, hipStream_t aux = nullptr);
     // After synchronisation: device status -> Failure
     Failure check(hipStream_t stream);
-    // Nucleotide sections whose every byte is written by K1 or the raw/RLE copy (no LZ sequences, one resident tile):
-    // the writers can apply the soft mask from a bit map (one bit per output byte of this process's range) on the way.
-    bool can_fuse_mask() const { return ready_ && t_char_ != 0 && !has_lz_ && tiles_.size() == 1; }
-    void set_mask_bits(const uint8_t *bits) { mask_bits_ = bits; }
-    // The same kind of section, decoded in a few SEGMENTS (consecutive block ranges, their Huffman tasks launched
-    // one segment after the other on alternating streams): after the launches of segment i the hook is told which
-    // decoded bytes [lo, hi) of this process's range are final once `done_on` has drained -- whoever post-processes
-    // the output (the soft mask) can then follow the decode segment by segment instead of waiting for all of it.
-    using SegmentHook = std::function<void(uint32_t seg, uint64_t lo, uint64_t hi, hipStream_t done_on)>;
-    uint32_t segments() const { return static_cast<uint32_t>(seg_mark_.size()); }
-    uint64_t segment_mark(uint32_t i) const { return seg_mark_[i]; }
-    void set_segment_hook(SegmentHook hook) { seg_hook_ = std::move(hook); }
     // Tiles: uploads tile t (they are decoded in order), decodes it, synchronises, keeps what the next one needs
     // (repeat offsets, position, the LZ window).  Tile t's output then is tile_data() .. + tile_len() elements.
     uint32_t n_tiles() const { return static_cast<uint32_t>(tiles_.size()); }
@@ -179,10 +166,6 @@ private:
     DevBuf d_xxh_segs_, d_xxh_carry_;
     DevBuf d_pj_dist_, d_pj_tiles_;               // dense LZ sections: one word per output element + one per tile (allocated on first use, kept)
     bool lz_dense_ = false;
-    const uint8_t *mask_bits_ = nullptr;
-    std::vector<uint64_t> seg_mark_;                      // segment i: decoded bytes below seg_mark_[i] are final when its tasks are done
-    std::vector<std::vector<uint32_t>> seg_tasks_;        // [class][i]: tasks of the class launched by the end of segment i
-    SegmentHook seg_hook_;
     DevBuf d_streams_, d_tasks_, d_tbl_copies_, d_pool_, d_dicts_, d_copies_, d_seq_blocks_, d_cells_;
 };
 
@@ -243,11 +226,8 @@ public:
 
 private:
     int device_ = -1;
-    hipStream_t stream_ = nullptr, aux_stream_ = nullptr, mask_stream_ = nullptr;
+    hipStream_t stream_ = nullptr, aux_stream_ = nullptr;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;   // record / mask table scans beside the sequence decode
-    hipEvent_t seg_ev_[8] = {};                          // the soft mask following the sequence decode segment by segment
-    uint64_t seg_marks_host_[9] = {};
-    DevBuf d_seg_marks_;                                 // 9 marks + 9 run bounds
     StageTimer timer_;
     StageTimes times_;
     nafgpu_header h_{};
@@ -258,7 +238,6 @@ private:
     SectionJob job_[kNumSections];
     Failure fail_[kNumSections];
     DevBuf d_rec_ends_, d_mask_ends_, d_scan_tmp_, d_totals_, d_status_, d_hash_;
-    DevBuf d_mask_bits_;                        // soft mask as a bit map, when the sequence's writers apply it (decode())
     DevBuf d_id_ends_, d_com_ends_, d_fmt_sizes_, d_fmt_off_, d_text_;
     uint64_t id_cap_ = 0, com_cap_ = 0;
     ScanTotals id_totals_{0, 0}, com_totals_{0, 0};

@@ -64,18 +64,16 @@ void launch_fmt_write(hipStream_t stream, const FmtText &t, const uint64_t *off,
 // characters each on the way (t_char = 'T' DNA / 'U' RNA); bytes bound for `lit` stay packed.
 void launch_copy_fill(hipStream_t stream, const uint8_t *src, const CopyTask *tasks, uint32_t n_tasks,
                       const uint64_t *blk_base, uint8_t *out, uint8_t *lit, bool ascii, uint32_t t_char,
-                      const uint8_t *mask_bits, uint32_t *status);
+                      uint32_t *status);
 
 // K1: Huffman literal streams, one lane per stream, one wave per task.  One launch per class (plan.h:
 // HufClass): `tasks` is the section's whole task list, cls names the run to launch, its table format,
 // destination and whether the segment-aware variant is needed (streams of blocks with a few sequences:
 // seq_blocks / seqs are then read, so k_seq_decode must have run).
-// mask_bits (or null): one bit per output byte of a nucleotide section without sequences, set where the soft mask
-// lower-cases it (launch_mask_bits); K1 and launch_copy_fill then apply the mask as they write.
 void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *tasks, const HufClass &cls,
                        const HufTblCopy *copies, const HufStream *streams, const uint16_t *pool,
                        const uint64_t *blk_base, uint8_t *out, uint8_t *lit, const SeqBlock *seq_blocks, const Seq *seqs,
-                       const uint8_t *dicts, bool ascii, uint32_t t_char, const uint8_t *mask_bits, uint32_t *status);
+                       const uint8_t *dicts, bool ascii, uint32_t t_char, uint32_t *status);
 
 // K4: LZ77 sequence execution: repeat-offset chain, parallel literal scatter, then -- all enqueued at once, no host
 // round trip: every stage returns at once when the one before it left nothing --
@@ -122,23 +120,13 @@ void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed
 void launch_mask_apply(hipStream_t stream, uint8_t *ascii, uint64_t n_bases, uint64_t lo_clamp, uint64_t hi_clamp,
                        const uint64_t *mask_ends, const ScanTotals *mask_totals, const uint64_t *rec_ends,
                        const ScanTotals *rec_totals,
-                       uint64_t max_runs, int spec_mask, uint32_t *status, const uint64_t *run_bounds = nullptr, uint32_t grid_div = 1);
-// run_bounds (device, 2 entries, or null): the runs that hold bases lo_clamp and hi_clamp -- a pass over PART of the
-// sequence then only visits its own runs (launch_mask_bounds: bounds[i] = run holding base marks[i], both on the device)
-void launch_mask_bounds(hipStream_t stream, const uint64_t *mask_ends, const ScanTotals *mask_totals, const uint64_t *marks, uint32_t n,
-                        uint64_t *bounds);
+                       uint64_t max_runs, int spec_mask, uint32_t *status);
 
 // Content_Checksum of the frames (pieces of frames) in `segs`: XXH64 over the decoded bytes at out + blk_base[..]
 // (ascii: the section output holds two characters per decoded byte, packed again on the fly); a mismatch flags
 // kStChecksum.  carry_in / carry_out: running state of a frame that spans tiles.
 void launch_xxh64_frames(hipStream_t stream, const XxhSeg *segs, uint32_t n_segs, const uint64_t *blk_base, const uint8_t *out,
                          bool ascii, uint32_t t_char, const XxhCarry *carry_in, XxhCarry *carry_out, uint32_t *status);
-
-// the soft mask as a bit map over bases [lo_clamp, hi_clamp) (bit 0 = base lo_clamp) for the writers of the sequence
-// section to apply on the fly; same rules as launch_mask_apply.  bits_bytes >= (hi_clamp - lo_clamp) / 8 + 64, 16-byte aligned.
-void launch_mask_bits(hipStream_t stream, uint8_t *bits, size_t bits_bytes, uint64_t n_bases, uint64_t lo_clamp, uint64_t hi_clamp,
-                      const uint64_t *mask_ends, const ScanTotals *mask_totals, const uint64_t *rec_ends,
-                      const ScanTotals *rec_totals, uint64_t max_runs, int spec_mask, uint32_t *status);
 
 // order-sensitive checksum of a device buffer (see hash64.h); *result must be zeroed first.
 // first_chunk: index of the buffer's first 4 KiB chunk in the whole object (shards add up)

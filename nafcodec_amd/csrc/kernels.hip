@@ -29,8 +29,7 @@ namespace {
 #define NAFGPU_ABLATE 0
 #endif
 constexpr uint32_t kAblate = NAFGPU_ABLATE;   // k_huf_decode: 1 no output stores, 2 no look-ups (rows fill instantly), 4 no input loads,
-                                              // 8 no table staging, 16 stores only to a small window, 32 no dictionary reads,
-                                              // (fused mask) 64 no bit loads, 128 bits not applied in the flush, 256 bits not posted / rows not sorted
+                                              // 8 no table staging, 16 stores only to a small window, 32 no dictionary reads
 
 __device__ inline void flag_error(uint32_t *status, uint32_t code, uint32_t detail) {
     if (kAblate) return;
@@ -159,19 +158,14 @@ struct HufLook {           // what one table look-up says about the next one or 
     uint32_t first;        // format-specific handle for "bits of the first symbol alone" (stream tail only)
 };
 
-// MASK: the soft mask is applied as the characters leave (flush): `mask_bits` holds one bit per output byte of the
-// section (k_mask_apply<true>), the owner of a row keeps the bits of its row's current unit in registers (loaded a round
-// ahead) and publishes them with the row.
-template <bool ASCII, int TBL, bool SEG, bool MASK>
+template <bool ASCII, int TBL, bool SEG>
 __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ src, const HufTask *__restrict__ tasks,
                                                    const HufTblCopy *__restrict__ copies,
                                                    const HufStream *__restrict__ streams,
                                                    const uint16_t *__restrict__ pool,
                                                    const uint64_t *__restrict__ blk_base, uint8_t *out, uint8_t *lit,
                                                    const SeqBlock *__restrict__ sblocks, const Seq *__restrict__ seqs,
-                                                   const uint8_t *__restrict__ dicts, uint32_t t_char,
-                                                   const uint8_t *__restrict__ mask_bits, uint32_t *status) {
-    static_assert(!MASK || (ASCII && !SEG), "the fused mask is for nucleotide sections without LZ sequences");
+                                                   const uint8_t *__restrict__ dicts, uint32_t t_char, uint32_t *status) {
     using G = HufGeom<TBL>;
     constexpr uint32_t kUnit = G::kUnit, kPitch = G::kPitch, kLanesPerRow = G::kLanesPerRow;
     constexpr uint32_t kRowsPerStore = G::kRowsPerStore, kStoreIters = G::kStoreIters, kUnitShift = G::kUnitShift;
@@ -181,8 +175,6 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     __shared__ __attribute__((aligned(16))) uint8_t s_out[64 * kPitch];
     __shared__ __attribute__((aligned(16))) uint32_t s_cunit[64];   // per round: descriptors of the ready rows, compacted (see publish)
     __shared__ uint32_t s_pv[64];      // incomplete units (publish): first valid byte of the row | bytes in the row << 8
-    constexpr uint32_t kMaskWords = G::kUnit / 32;         // mask bits of one unit
-    __shared__ __attribute__((aligned(16))) uint32_t s_mask[MASK ? 64 * kMaskWords : 4];
 
     // compact tables: characters of a packed byte, shared by all the trees of the task
     __shared__ uint16_t s_lut[(TBL == kTblCompact && ASCII) ? 256 : 2];
@@ -443,34 +435,6 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     const __amdgpu_buffer_rsrc_t rs_src =
         __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(static_cast<uintptr_t>(sbase)), 0, static_cast<int>(kBufRange), kBufWord3);
 
-    // ---- soft mask (MASK): bits of the unit this lane's row is filling
-    uint32_t mreg[kMaskWords] = {};
-    auto load_mask = [&](uint32_t ahead) {
-        if constexpr (MASK && !(kAblate & 64u)) {
-            const uint8_t *mp = mask_bits + ((dbase + dst_rel + rbase + ahead) >> 3);   // unit-aligned position: 16- (8-) byte aligned address
-            if constexpr (kMaskWords == 4) {
-                const uint4 m = *reinterpret_cast<const uint4 *>(mp);
-                mreg[0] = m.x;
-                mreg[1] = m.y;
-                mreg[2] = m.z;
-                mreg[3] = m.w;
-            } else {
-                const uint2 m = *reinterpret_cast<const uint2 *>(mp);
-                mreg[0] = m.x;
-                mreg[1] = m.y;
-            }
-        }
-    };
-    auto post_mask = [&]() {                               // the row's bits where the flush finds them
-        if constexpr (MASK && !(kAblate & 256u)) {
-            if constexpr (kMaskWords == 4)
-                *reinterpret_cast<uint4 *>(&s_mask[4 * lane]) = make_uint4(mreg[0], mreg[1], mreg[2], mreg[3]);
-            else
-                *reinterpret_cast<uint2 *>(&s_mask[2 * lane]) = make_uint2(mreg[0], mreg[1]);
-        }
-    };
-    if (MASK && have) load_mask(0);
-    post_mask();
     // ---- input.  The stream is consumed in 32-byte aligned PIECES, numbered backwards from the one
     // that holds its last byte (piece j = bytes [ptop - 32 j, ptop - 32 j + 32); ring word 8 j + i is the
     // dword at offset 28 - 4 i of piece j).  Pieces come out of a whole 128-byte LINE that the lane keeps
@@ -524,7 +488,6 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     // The first and last unit of a stream or segment (bytes of a neighbour / not produced yet) are
     // written byte-wise.
     const uint32_t oct = lane % kLanesPerRow, grp = lane / kLanesPerRow;
-    uint32_t n_cls0 = 0, n_cls01 = 0;                      // set by publish (MASK): ready rows the mask leaves alone; those plus the rows it covers whole
     uint32_t n_part = 0;                                   // set by publish: rows whose unit is incomplete (uniform)
     bool took_partial = false;                             // set by publish: this lane's row goes out as an incomplete unit
     auto publish = [&](bool lane_final) -> uint32_t {      // returns the number of ready rows
@@ -532,31 +495,10 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         const bool ready = have && (avail >= kUnit || (lane_final && avail > 0));
         const bool full = rbase >= h && avail >= kUnit;
         const unsigned long long m = __ballot(ready ? 1 : 0);
-        uint32_t rank = static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
-        if constexpr (MASK && !(kAblate & 256u)) {
-            // rows are listed by what the mask does to their unit -- nothing, all of it, part of it -- so that most
-            // store instructions of the flush meet one kind only: the bit-to-character expansion is then run for the
-            // few instructions that hold a unit with a run boundary inside, not for all of them
-            uint32_t any = mreg[0] | mreg[1], all = mreg[0] & mreg[1];
-            if constexpr (kMaskWords == 4) {
-                any |= mreg[2] | mreg[3];
-                all &= mreg[2] & mreg[3];
-            }
-            const uint32_t cls = any == 0 ? 0u : (all == ~0u ? 1u : 2u);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            const unsigned long long m1 = __ballot(ready && cls == 1u ? 1 : 0), m2 = __ballot(ready && cls == 2u ? 1 : 0);
-            const unsigned long long m0 = m & ~m1 & ~m2;
-            n_cls0 = static_cast<uint32_t>(__popcll(m0));
-            n_cls01 = n_cls0 + static_cast<uint32_t>(__popcll(m1));
-            rank = cls == 0 ? static_cast<uint32_t>(__popcll(m0 & below))
-                            : (cls == 1 ? n_cls0 + static_cast<uint32_t>(__popcll(m1 & below)) : n_cls01 + static_cast<uint32_t>(__popcll(m2 & below)));
-        }
+        const uint32_t rank = static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
         if (ready)
             s_cunit[(rank % kRowsPerStore) * kStoreIters + (rank / kRowsPerStore)] =
                 (((dst_rel + rbase) >> kUnitShift) << 7) | (lane << 1) | (full ? 1u : 0u);
-        // (MASK) s_mask already holds the bits of every row's current unit (post_mask); a row that is about to give
-        // its unit away asks for the bits of the one behind it now, a whole round before they are wanted
-        if (MASK && ready && avail >= kUnit) load_mask(kUnit);
         took_partial = ready && avail < kUnit;
         n_part = static_cast<uint32_t>(__popcll(__ballot(ready && !full ? 1 : 0)));
         if (n_part) s_pv[lane] = (h > rbase ? h - rbase : 0u) | (avail << 8);   // only the byte-wise path needs these
@@ -589,28 +531,18 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
                 const uint32_t v_lo = lo_x > rh ? lo_x : rh, v_hi = hi_x < rq ? hi_x : rq;
                 uint8_t *d = obase + pos + 16 * oct;
                 const uint8_t *rowp = s_out + row * kPitch + 16 * oct;
-                const uint32_t mb = MASK ? reinterpret_cast<const uint16_t *>(s_mask)[row * kLanesPerRow + oct] : 0u;
 #pragma clang loop vectorize(disable) unroll(disable)
-                for (uint32_t x = v_lo; x < v_hi; x++)
-                    d[x - lo_x] = static_cast<uint8_t>(rowp[x - lo_x] | (((mb >> (x - lo_x)) & 1u) << 5));
+                for (uint32_t x = v_lo; x < v_hi; x++) d[x - lo_x] = rowp[x - lo_x];
             }
         }
         uint2 w[kStoreIters][2];                           // all LDS reads first: the stores then go out back to back
-        uint32_t mbits[kStoreIters];
 #pragma unroll
         for (uint32_t k = 0; k < kStoreIters; k++) {
             if (kRowsPerStore * k >= n_ready) break;       // uniform
-            const uint32_t row = (c[k] >> 1) & 63u;
-            const uint8_t *rowp = s_out + row * kPitch + 16 * oct;
+            const uint8_t *rowp = s_out + ((c[k] >> 1) & 63u) * kPitch + 16 * oct;
             w[k][0] = *reinterpret_cast<const uint2 *>(rowp);
             w[k][1] = *reinterpret_cast<const uint2 *>(rowp + 8);
-            if constexpr (MASK && !(kAblate & 128u)) {
-                if (kRowsPerStore * (k + 1) > n_cls0)      // (uniform) some row of this instruction is masked
-                    mbits[k] = reinterpret_cast<const uint16_t *>(s_mask)[row * kLanesPerRow + oct];
-            }
         }
-        // four mask bits -> bit 5 of four characters
-        auto spread = [](uint32_t nib) -> uint32_t { return ((__umul24(nib, 0x00204081u) & 0x01010101u) << 5); };
 #pragma unroll
         for (uint32_t k = 0; k < kStoreIters; k++) {
             if (kRowsPerStore * k >= n_ready) break;       // uniform
@@ -622,20 +554,6 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
             v[1] = w[k][0].y;
             v[2] = w[k][1].x;
             v[3] = w[k][1].y;
-            if constexpr (MASK && !(kAblate & 128u)) {
-                if (kRowsPerStore * (k + 1) > n_cls01) {   // (uniform) a unit with a run boundary inside
-                    v[0] |= spread(mbits[k] & 15u);
-                    v[1] |= spread((mbits[k] >> 4) & 15u);
-                    v[2] |= spread((mbits[k] >> 8) & 15u);
-                    v[3] |= spread(mbits[k] >> 12);
-                } else if (kRowsPerStore * (k + 1) > n_cls0) {   // whole units only: all of the 16 characters or none
-                    const uint32_t mm = mbits[k] ? 0x20202020u : 0u;
-                    v[0] |= mm;
-                    v[1] |= mm;
-                    v[2] |= mm;
-                    v[3] |= mm;
-                }
-            }
             __builtin_amdgcn_raw_buffer_store_b128(v, rs_dst, voff, 0, 0);
         }
     };
@@ -847,8 +765,6 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         else if (TBL == kTblCompact) decode_round_compact(std::false_type{});
         else if (task_esc) decode_round(std::true_type{});
         else decode_round(std::false_type{});
-        // (waits for the mask bits requested at the start of the round -- where the wait for the line below is anyway)
-        post_mask();
         // ---- land the next piece, if the ring has room for it.
         // d = words between the oldest ring slot and the cursor; staged past the cursor = 16 - d;
         // 8 words fit once d >= 8.  A round uses <= 6 words + 2 of look-ahead, and d >= 8 whenever
@@ -866,7 +782,6 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         flush(n_ready);
         wave_sync();
         const uint32_t avail = static_cast<uint32_t>(wa - orow);
-        post_mask();
         if (avail > kUnit) {
             for (uint32_t j = 0; j < 64; j += 8) *reinterpret_cast<uint2 *>(orow + j) = *reinterpret_cast<const uint2 *>(orow + kUnit + j);
             wa -= kUnit;
@@ -1401,7 +1316,7 @@ constexpr uint32_t kCopySlice = 8u << 10;
 template <bool ASCII>
 __global__ __launch_bounds__(256) void k_copy_fill(const uint8_t *__restrict__ src, const CopyTask *__restrict__ tasks,
                                                    const uint64_t *__restrict__ blk_base, uint8_t *out, uint8_t *lit,
-                                                   uint32_t t_char, const uint8_t *__restrict__ mask_bits, const uint32_t *status) {
+                                                   uint32_t t_char, const uint32_t *status) {
     if (status[0] != 0) return;
     const CopyTask t = tasks[blockIdx.x];
     const bool fill = (t.flags & 2) != 0;
@@ -1411,17 +1326,9 @@ __global__ __launch_bounds__(256) void k_copy_fill(const uint8_t *__restrict__ s
     const uint32_t lo = blockIdx.y * kCopySlice;
     const uint32_t hi = lo + kCopySlice < t.len ? lo + kCopySlice : t.len;
     if (ASCII && !(t.flags & 1)) {                       // nucleotide section: expand while copying
-        const uint64_t e0 = blk_base[t.blk] + t.dst;
-        uint16_t *d = reinterpret_cast<uint16_t *>(out) + e0;
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-            uint32_t ch = byte_chars(fill ? fv : s[i], t_char);
-            if (mask_bits) {                             // soft mask fused into the writers (see k_mask_apply<true>): bit x = output byte x
-                const uint64_t x = 2 * (e0 + i);
-                const uint32_t m = mask_bits[x >> 3] >> (x & 7);
-                ch |= ((m & 1u) << 5) | ((m & 2u) << 12);
-            }
-            d[i] = static_cast<uint16_t>(ch);
-        }
+        uint16_t *d = reinterpret_cast<uint16_t *>(out) + blk_base[t.blk] + t.dst;
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
+            d[i] = static_cast<uint16_t>(byte_chars(fill ? fv : s[i], t_char));
     } else {
         uint8_t *d = (t.flags & 1) ? lit + t.dst : out + blk_base[t.blk] + t.dst;
         for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) d[i] = fill ? fv : s[i];
@@ -2274,32 +2181,48 @@ __device__ inline uint32_t lower4(uint32_t w) {
     return w | (up >> 2);
 }
 
-// marks[0..n]: ascending base positions; bounds[i] = the run that holds base marks[i] (first run whose end is beyond it)
-__global__ void k_mask_bounds(const uint64_t *__restrict__ mask_ends, const ScanTotals *mask_totals, const uint64_t *marks, uint32_t n,
-                              uint64_t *bounds) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t w = marks[i];
-    uint64_t lo = 0, hi = mask_totals->count;
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (mask_ends[mid] > w)
-            hi = mid;
-        else
-            lo = mid + 1;
+// masked run k (odd) -> the bases [s, e) it lower-cases, inside [lo_clamp, hi_clamp); e == s: nothing
+__device__ inline void masked_run_range(uint64_t k, uint64_t n_bases, uint64_t lo_clamp, uint64_t hi_clamp,
+                                        const uint64_t *__restrict__ mask_ends, const uint64_t *__restrict__ rec_ends, uint64_t n_rec,
+                                        int spec_mask, uint64_t *s_out, uint64_t *e_out) {
+    uint64_t s = mask_ends[k - 1], e = mask_ends[k];
+    if (s >= n_bases) {
+        s = e = 0;
+    } else if (e > n_bases) {                          // MaskReader stops at `total`: the overshoot is never applied
+        e = spec_mask ? n_bases : s;
     }
-    bounds[i] = lo;
+    if (e > s && !spec_mask) {
+        uint64_t lo = 0, hi = n_rec;                   // first record whose end is > e - 1
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (rec_ends[mid] > e - 1)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        if (lo >= n_rec) {
+            e = s;                                     // beyond the last record
+        } else {
+            const uint64_t rend = rec_ends[lo];
+            const uint64_t rstart = lo ? rec_ends[lo - 1] : 0;
+            if (e >= rend)
+                e = s;                                 // run reaches the record end: stays upper case
+            else if (s < rstart)
+                s = rstart;
+        }
+    }
+    // a shard holds bases [lo_clamp, hi_clamp) only
+    if (s < lo_clamp) s = lo_clamp;
+    if (e > hi_clamp) e = hi_clamp;
+    if (e < s) e = s;
+    *s_out = s;
+    *e_out = e;
 }
 
-// BITS: instead of lower-casing characters the kernel sets, in a bit map that was zeroed before, the bits of the bases
-// to lower-case (bit x = base `shift` + x; `ascii` is the map): what k_huf_decode's flush and k_copy_fill then OR
-// into the characters as they write them, so that the sequence is not read and written a second time.
-template <bool BITS>
 __global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_bases, uint64_t lo_clamp, uint64_t hi_clamp,
                                                     const uint64_t *__restrict__ mask_ends,
                                                     const ScanTotals *mask_totals, const uint64_t *__restrict__ rec_ends,
-                                                    const ScanTotals *rec_totals, int spec_mask, uint64_t shift,
-                                                    const uint64_t *__restrict__ run_bounds, const uint32_t *status) {
+                                                    const ScanTotals *rec_totals, int spec_mask, const uint32_t *status) {
     // A workgroup takes 256 consecutive masked runs.  Phase 1: one run per thread -- clamp it and
     // (reference behaviour) find the record that holds its last base with a binary search, 256
     // searches in flight at once.  Phase 2: the runs are cut into 16-byte aligned chunks, an exclusive
@@ -2313,57 +2236,17 @@ __global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_b
     const uint64_t n_runs = mask_totals->count;
     const uint64_t n_rec = rec_totals->count;
     const uint32_t tid = threadIdx.x;
-    const uint64_t skew = BITS ? 0 : reinterpret_cast<uintptr_t>(ascii) & 15;   // a shard's base pointer need not be 16-byte aligned
+    const uint64_t skew = reinterpret_cast<uintptr_t>(ascii) & 15;   // a shard's base pointer need not be 16-byte aligned
     uint8_t *const abase = ascii - skew;
-    constexpr uint32_t kChunkShift = BITS ? 7 : 4;         // a chunk: 16 characters, or 128 bits of the map
-    // run_bounds (or null: all runs): the runs that hold the first and the last base of [lo_clamp, hi_clamp) (k_mask_bounds)
-    const uint64_t k0 = run_bounds ? (run_bounds[0] | 1ull) : 1ull;
-    const uint64_t k_end = run_bounds && run_bounds[1] + 1 < n_runs ? run_bounds[1] + 1 : n_runs;
-    for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * 256; k0 + 2 * base < k_end && !abort_now;
+    for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * 256; 2 * base + 1 < n_runs && !abort_now;
          base += static_cast<uint64_t>(gridDim.x) * 256) {
-        const uint64_t k = k0 + 2 * (base + tid);          // odd runs are the masked ones
+        const uint64_t k = 2 * (base + tid) + 1;           // odd runs are the masked ones
         uint64_t s = 0, e = 0;
-        if (k < k_end) {
-            s = mask_ends[k - 1];
-            e = mask_ends[k];
-            if (s >= n_bases) {
-                s = e = 0;
-            } else if (e > n_bases) {                      // MaskReader stops at `total`: the overshoot is never applied
-                e = spec_mask ? n_bases : s;
-            }
-            if (e > s && !spec_mask) {
-                uint64_t lo = 0, hi = n_rec;               // first record whose end is > e - 1
-                while (lo < hi) {
-                    const uint64_t mid = (lo + hi) >> 1;
-                    if (rec_ends[mid] > e - 1)
-                        hi = mid;
-                    else
-                        lo = mid + 1;
-                }
-                if (lo >= n_rec) {
-                    e = s;                                 // beyond the last record
-                } else {
-                    const uint64_t rend = rec_ends[lo];
-                    const uint64_t rstart = lo ? rec_ends[lo - 1] : 0;
-                    if (e >= rend)
-                        e = s;                             // run reaches the record end: stays upper case
-                    else if (s < rstart)
-                        s = rstart;
-                }
-            }
-            // a shard holds bases [lo_clamp, hi_clamp) only
-            if (s < lo_clamp) s = lo_clamp;
-            if (e > hi_clamp) e = hi_clamp;
-            if (e < s) e = s;
-            if (BITS) {                                    // map coordinates (the host passes lo_clamp >= shift)
-                s -= shift;
-                e -= shift;
-            }
-        }
+        if (k < n_runs) masked_run_range(k, n_bases, lo_clamp, hi_clamp, mask_ends, rec_ends, n_rec, spec_mask, &s, &e);
         __syncthreads();                                   // previous round's readers are done
         s_lo[tid] = s;
         s_hi[tid] = e;
-        s_pre[0][tid + 1] = e > s ? ((e + skew + (1u << kChunkShift) - 1) >> kChunkShift) - ((s + skew) >> kChunkShift) : 0;
+        s_pre[0][tid + 1] = e > s ? ((e + skew + 15) >> 4) - ((s + skew) >> 4) : 0;
         if (tid == 0) s_pre[0][0] = s_pre[1][0] = 0;
         __syncthreads();
         uint32_t cur = 0;
@@ -2375,36 +2258,6 @@ __global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_b
         }
         const uint64_t *pre = s_pre[cur];                  // pre[r] = chunks of runs 0..r-1
         const uint64_t total = pre[256];
-        if constexpr (BITS) {
-            for (uint64_t c = tid; c < total; c += 256) {
-                uint32_t lo = 0, hi = 256;                 // largest r with pre[r] <= c
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (pre[mid] <= c)
-                        lo = mid;
-                    else
-                        hi = mid;
-                }
-                const uint64_t rs = s_lo[lo], re = s_hi[lo];
-                const uint64_t a = ((rs >> 7) + (c - pre[lo])) << 7;
-                const uint64_t e0 = a > rs ? a : rs, e1 = a + 128 < re ? a + 128 : re;
-                uint32_t *wp = reinterpret_cast<uint32_t *>(abase) + (a >> 5);
-                if (e1 - e0 == 128) {                      // a chunk inside the run: nobody else writes it
-                    *reinterpret_cast<uint4 *>(wp) = make_uint4(~0u, ~0u, ~0u, ~0u);
-                } else {                                   // shared with a neighbour
-#pragma unroll
-                    for (uint32_t d = 0; d < 4; d++) {
-                        const uint64_t w0 = a + 32 * d;
-                        const uint64_t b0 = e0 > w0 ? e0 : w0, b1 = e1 < w0 + 32 ? e1 : w0 + 32;
-                        if (b1 > b0) {
-                            const uint32_t n = static_cast<uint32_t>(b1 - b0);
-                            atomicOr(wp + d, (n == 32 ? ~0u : (1u << n) - 1u) << static_cast<uint32_t>(b0 - w0));
-                        }
-                    }
-                }
-            }
-            continue;
-        }
         // four chunks per thread and step: the loads of all four are in flight before the first store
         for (uint64_t c0 = tid; c0 < total; c0 += 4 * 256) {
             uint64_t addr[4], e0[4], e1[4];
@@ -2722,40 +2575,37 @@ void launch_fmt_write(hipStream_t stream, const FmtText &t, const uint64_t *off,
 
 void launch_copy_fill(hipStream_t stream, const uint8_t *src, const CopyTask *tasks, uint32_t n_tasks,
                       const uint64_t *blk_base, uint8_t *out, uint8_t *lit, bool ascii, uint32_t t_char,
-                      const uint8_t *mask_bits, uint32_t *status) {
+                      uint32_t *status) {
     if (!n_tasks) return;
     if (ascii)
         hipLaunchKernelGGL(k_copy_fill<true>, dim3(n_tasks, kBlockMax / kCopySlice), dim3(256), 0, stream, src, tasks, blk_base, out, lit, t_char,
-                           mask_bits, status);
+                           status);
     else
         hipLaunchKernelGGL(k_copy_fill<false>, dim3(n_tasks, kBlockMax / kCopySlice), dim3(256), 0, stream, src, tasks, blk_base, out, lit, t_char,
-                           static_cast<const uint8_t *>(nullptr), status);
+                           status);
 }
 
 void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *tasks, const HufClass &cls,
                        const HufTblCopy *copies, const HufStream *streams, const uint16_t *pool,
                        const uint64_t *blk_base, uint8_t *out, uint8_t *lit, const SeqBlock *seq_blocks, const Seq *seqs,
-                       const uint8_t *dicts, bool ascii, uint32_t t_char, const uint8_t *mask_bits, uint32_t *status) {
+                       const uint8_t *dicts, bool ascii, uint32_t t_char, uint32_t *status) {
     if (!cls.n_tasks) return;
     const uint32_t lds = (cls.lds_bytes + 15u) & ~15u;
     const bool a = ascii && !cls.to_lit;                   // the literal buffer always holds packed bytes
-    const bool masked = mask_bits && a && !cls.seg;        // (the host only passes a bit map for sections without sequences)
     const HufTask *t0 = tasks + cls.first_task;
-#define NAFGPU_LAUNCH_HUF(A, T, S, M)                                                                                         \
-    hipLaunchKernelGGL((k_huf_decode<A, T, S, M>), dim3(cls.n_tasks), dim3(64), lds, stream, src, t0, copies, streams, pool,  \
-                       blk_base, out, lit, seq_blocks, seqs, dicts, t_char, mask_bits, status)
+#define NAFGPU_LAUNCH_HUF(A, T, S)                                                                                            \
+    hipLaunchKernelGGL((k_huf_decode<A, T, S>), dim3(cls.n_tasks), dim3(64), lds, stream, src, t0, copies, streams, pool,     \
+                       blk_base, out, lit, seq_blocks, seqs, dicts, t_char, status)
 #define NAFGPU_LAUNCH_HUF_T(T)                       \
     do {                                             \
-        if (masked)                                  \
-            NAFGPU_LAUNCH_HUF(true, T, false, true); \
-        else if (a && cls.seg)                       \
-            NAFGPU_LAUNCH_HUF(true, T, true, false); \
+        if (a && cls.seg)                            \
+            NAFGPU_LAUNCH_HUF(true, T, true);        \
         else if (a)                                  \
-            NAFGPU_LAUNCH_HUF(true, T, false, false);\
+            NAFGPU_LAUNCH_HUF(true, T, false);       \
         else if (cls.seg)                            \
-            NAFGPU_LAUNCH_HUF(false, T, true, false);\
+            NAFGPU_LAUNCH_HUF(false, T, true);       \
         else                                         \
-            NAFGPU_LAUNCH_HUF(false, T, false, false);\
+            NAFGPU_LAUNCH_HUF(false, T, false);      \
     } while (0)
     if (cls.tbl == kTblBaked)
         NAFGPU_LAUNCH_HUF_T(kTblBaked);
@@ -2863,36 +2713,16 @@ void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed
                        n_bases, t_char, status);
 }
 
-static uint32_t mask_grid(uint64_t max_runs) {
+void launch_mask_apply(hipStream_t stream, uint8_t *ascii, uint64_t n_bases, uint64_t lo_clamp, uint64_t hi_clamp,
+                       const uint64_t *mask_ends, const ScanTotals *mask_totals, const uint64_t *rec_ends,
+                       const ScanTotals *rec_totals, uint64_t max_runs, int spec_mask, uint32_t *status) {
+    if (!n_bases || !max_runs || hi_clamp <= lo_clamp) return;
     const uint64_t masked_runs = (max_runs + 1) / 2;
     uint64_t blocks = (masked_runs + 255) / 256;
     if (blocks > 256u * 8u) blocks = 256u * 8u;
-    return blocks ? static_cast<uint32_t>(blocks) : 1u;
-}
-
-void launch_mask_apply(hipStream_t stream, uint8_t *ascii, uint64_t n_bases, uint64_t lo_clamp, uint64_t hi_clamp,
-                       const uint64_t *mask_ends, const ScanTotals *mask_totals, const uint64_t *rec_ends,
-                       const ScanTotals *rec_totals, uint64_t max_runs, int spec_mask, uint32_t *status, const uint64_t *run_bounds,
-                       uint32_t grid_div) {
-    if (!n_bases || !max_runs || hi_clamp <= lo_clamp) return;
-    uint32_t grid = mask_grid(max_runs);
-    if (grid_div > 1) grid = grid / grid_div > 64 ? grid / grid_div : (grid < 64 ? grid : 64);
-    hipLaunchKernelGGL(k_mask_apply<false>, dim3(grid), dim3(256), 0, stream, ascii, n_bases, lo_clamp, hi_clamp,
-                       mask_ends, mask_totals, rec_ends, rec_totals, spec_mask, 0ull, run_bounds, status);
-}
-
-void launch_mask_bounds(hipStream_t stream, const uint64_t *mask_ends, const ScanTotals *mask_totals, const uint64_t *marks, uint32_t n,
-                        uint64_t *bounds) {
-    if (n) hipLaunchKernelGGL(k_mask_bounds, dim3((n + 63) / 64), dim3(64), 0, stream, mask_ends, mask_totals, marks, n, bounds);
-}
-
-void launch_mask_bits(hipStream_t stream, uint8_t *bits, size_t bits_bytes, uint64_t n_bases, uint64_t lo_clamp, uint64_t hi_clamp,
-                      const uint64_t *mask_ends, const ScanTotals *mask_totals, const uint64_t *rec_ends,
-                      const ScanTotals *rec_totals, uint64_t max_runs, int spec_mask, uint32_t *status) {
-    (void)hipMemsetAsync(bits, 0, bits_bytes, stream);
-    if (!n_bases || !max_runs || hi_clamp <= lo_clamp) return;
-    hipLaunchKernelGGL(k_mask_apply<true>, dim3(mask_grid(max_runs)), dim3(256), 0, stream, bits, n_bases, lo_clamp, hi_clamp,
-                       mask_ends, mask_totals, rec_ends, rec_totals, spec_mask, lo_clamp, static_cast<const uint64_t *>(nullptr), status);
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_mask_apply, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, ascii, n_bases, lo_clamp,
+                       hi_clamp, mask_ends, mask_totals, rec_ends, rec_totals, spec_mask, status);
 }
 
 void launch_xxh64_frames(hipStream_t stream, const XxhSeg *segs, uint32_t n_segs, const uint64_t *blk_base, const uint8_t *out,

@@ -42,6 +42,9 @@ def parse_args():
     ap.add_argument("--cpu-sample-bases", type=float, default=0,
                     help="size of the CPU-baseline sample (0 = auto, about 15 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--real-copies", type=int, default=400,
+                    help="N=1 only: also time an archive shaped like a real genome (the reference's NZ_AAEN01000029 fixture tiled "
+                         "this many times, libzstd level 1) and report it as path.real_genome; 0 skips it")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--rehearsal-lib", default="",
                     help="tests only: run the control flow against another build of the library (the CPU harness); "
@@ -123,6 +126,87 @@ def cpu_baseline(lib, n_bases_target, mask, device):
     if all_cores:
         out["all_cores"] = all_cores
     return out, want.n_bases
+
+
+def real_genome_leg(lib, device, copies):
+    """Second measured workload (reported beside the headline, never as `value`): an archive with the block structure
+    `ennaf` gives real genomes -- the sequence of tests/golden/NZ_AAEN01000029.naf (the reference's own fixture: 5.5 Mbases,
+    IUPAC codes besides ACGT) tiled `copies` times and compressed by the system libzstd at level 1 in streaming mode: one
+    Huffman tree per 128 KiB block, a few LZ sequences per block.  The fixture is decoded by the HIP path itself; the
+    expected output of the tiled archive is the tiled output of the fixture (checksum compared)."""
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "tests"))
+    import zstd_ref                                                   # ctypes binding of libzstd.so.1 (test helper, no oracle)
+    if not zstd_ref.available():
+        return None
+    ffi = _ffi_mod()
+
+    def decode(blob):
+        opts = ffi.Opts()
+        lib.c.nafgpu_opts_default(ctypes.byref(opts))
+        opts.device = device
+        h, err, res = ctypes.c_void_p(), ffi.Error(), ffi.DeviceResult()
+        if lib.c.nafgpu_open_bytes(blob, len(blob), ctypes.byref(opts), ctypes.byref(h), ctypes.byref(err)) != 0:
+            raise RuntimeError("open failed: %s" % err.message.decode())
+        if lib.c.nafgpu_decode_all_device(h, ctypes.byref(res)) != 0:
+            lib.c.nafgpu_last_error(h, ctypes.byref(err))
+            raise RuntimeError("decode failed: %s" % err.message.decode())
+        return h, res
+
+    blob = open(os.path.join(here, "tests", "golden", "NZ_AAEN01000029.naf"), "rb").read()
+    h, res = decode(blob)
+    seq = ctypes.create_string_buffer(int(res.n_bases))
+    lib.c.nafgpu_copy_to_host(h, res.d_sequence, int(res.n_bases), ctypes.cast(seq, ctypes.c_void_p))
+    lib.c.nafgpu_close(h)
+    chars = np.frombuffer(seq.raw[:int(res.n_bases) & ~1], dtype=np.uint8)
+    chars = chars & 0xDF | (chars == 0x2D) * 0x2D                      # upper case ('-' stays): the tiled archive carries no mask
+    code = np.zeros(256, dtype=np.uint8)
+    for i, c in enumerate(b"-TGKCYSBAWRDMHVN"):
+        code[c] = i
+    nib = code[chars]
+    one = (nib[0::2] | (nib[1::2] << 4)).astype(np.uint8)
+    packed = np.tile(one, copies).tobytes()
+    n_bases = 2 * len(packed)
+
+    def varint(v):
+        out = [v & 0x7F]
+        v >>= 7
+        while v:
+            out.append(0x80 | (v & 0x7F))
+            v >>= 7
+        return bytes(reversed(out))
+
+    payload = zstd_ref.compress_magicless(packed, 1, True)
+    lens = b"".join((0xFFFFFFFF).to_bytes(4, "little") for _ in range(n_bases // 0xFFFFFFFF)) + (n_bases % 0xFFFFFFFF).to_bytes(4, "little")
+    lenp = zstd_ref.compress_magicless(lens, 1, True)
+    arc = (bytes([1, 0xF9, 0xEC, 1, 0x0A, 0x20]) + varint(60) + varint(1) + varint(len(lens)) + varint(len(lenp)) + lenp +
+           varint(n_bases) + varint(len(payload)) + payload)
+    want = np.tile(np.frombuffer(b"-TGKCYSBAWRDMHVN", dtype=np.uint8)[np.stack([one & 15, one >> 4], axis=1).reshape(-1)], copies).tobytes()
+    want_hash = lib.c.nafgpu_hash64_host(want, len(want))
+    del want, packed
+    h, res = decode(arc)
+    try:
+        best = None
+        for _ in range(4):
+            if lib.c.nafgpu_decode_all_device(h, ctypes.byref(res)) != 0:
+                raise RuntimeError("decode failed")
+            if best is None or res.ms_total < best[0]:
+                best = (res.ms_total, res.ms_huf, res.ms_seq_lz, res.ms_other)
+        hs = ctypes.c_uint64()
+        lib.c.nafgpu_hash64_device(h, res.d_sequence, res.n_bases, ctypes.byref(hs))
+        if int(res.n_bases) != n_bases or hs.value != want_hash:
+            raise RuntimeError("real-genome leg: GPU output differs from the tiled fixture")
+        alg = len(payload) + n_bases                                   # compressed bytes in, characters out
+        gbs = alg / (best[0] * 1e-3) / 1e9
+        return {"workload": "sequence of the reference fixture NZ_AAEN01000029 x %d, libzstd level 1 streaming (%d zstd blocks, one Huffman "
+                            "tree each, %d Huffman streams), bit-exact check passed" % (copies, res.n_zstd_blocks, res.n_huf_streams),
+                "bases": n_bases, "ms_per_step": round(best[0], 3), "value": round(n_bases / best[0] / 1e6, 1), "unit": "Gbases/s",
+                "ms_huf": round(best[1], 3), "ms_seq_lz": round(best[2], 3), "ms_other": round(best[3], 3),
+                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": int(alg)}}
+    finally:
+        lib.c.nafgpu_close(h)
 
 
 def _ffi_mod():
@@ -338,6 +422,8 @@ def main():
                      "host_plan_ms": round(res.ms_host_plan, 1), "h2d_ms": round(res.ms_h2d, 1),
                      "synth_s": round(t_gen, 1), "upload_s": round(t_upload, 2)},
         }
+        if args.real_copies and world == 1 and not args.rehearsal_lib:
+            line["path"]["real_genome"] = real_genome_leg(lib, device, args.real_copies)
         if not args.no_cpu and world == 1:       # reported baseline, rank 0 at N=1 only
             line["cpu_baseline"], checked = cpu_baseline(lib, args.cpu_sample_bases, args.mask, device)
             line["config"]["oracle_checked_bases"] = checked

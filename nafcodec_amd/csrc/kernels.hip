@@ -808,6 +808,9 @@ __device__ inline uint32_t rep_minus_one(uint32_t r) {      // rep - 1 for a con
     return r + ((r & kRepToken) ? 1u : 0xFFFFFFFFu);
 }
 
+// (Measured and dropped: the three FSE tables of a block staged in LDS, 15 blocks per workgroup.  The chain of one sequence
+//  is "state -> cell -> bits -> next state" AND the 16-byte window of the bitstream, which still comes from memory: level-3
+//  DNA went from 16.2 to 18.2 ms.  It would take the bitstream in LDS as well.)
 __global__ __launch_bounds__(64) void k_seq_decode(const uint8_t *__restrict__ src, const SeqBlock *__restrict__ blocks,
                                                    uint32_t n_blocks, const SeqCell *__restrict__ cells, Seq *seqs,
                                                    uint32_t *blk_size, uint32_t *rep_final, uint32_t *status) {
@@ -1992,8 +1995,7 @@ __global__ __launch_bounds__(256) void k_pj_sweep(uint32_t *D, uint8_t *out_byte
                                                   uint64_t n_elems, uint32_t sweep, uint32_t max_dist, const uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
-    __shared__ uint32_t s_red[256];
-    __shared__ uint32_t s_skip;
+    __shared__ uint32_t s_cnt[3];                          // pending elements of the tile, three counters in rotation (one barrier per tile)
     const uint32_t tid = threadIdx.x;
     // pcount[s % 3] = elements still pending after sweep s (pcount[0] != 0 before the first one)
     const unsigned long long before = pcount[(sweep + 2u) % 3u];
@@ -2002,58 +2004,78 @@ __global__ __launch_bounds__(256) void k_pj_sweep(uint32_t *D, uint8_t *out_byte
         if (before == 0 || status[0] != 0) pcount[sweep % 3u] = 0;
     }
     if (before == 0 || status[0] != 0) return;
+    if (tid < 3) s_cnt[tid] = 0;
+    __syncthreads();
     const uint32_t mark = kPjFinal | (sweep & 0xFFu);
     const uint64_t n_tiles = (n_elems + kPjTile - 1) / kPjTile;
+    uint32_t flip = 0;
     for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        if (tid == 0) s_skip = sweep > 1 && tile_pending[t] == 0;
-        __syncthreads();
-        const bool skip = s_skip != 0;
-        __syncthreads();
-        if (skip) continue;
-        uint32_t remaining = 0;
-        const uint64_t p0 = t * kPjTile + tid * 4;
+        if (sweep > 1 && tile_pending[t] == 0) continue;    // (the same word for every thread: uniform)
+        // Two runs of four consecutive elements per thread.  All the look-ups of a thread are issued before any of its
+        // stores: a source read a moment too early is still a valid ancestor in the chain (its old distance points
+        // further back), so the order inside a sweep does not matter -- but eight dependent round trips to memory do.
+        uint64_t p[2];
+        uint32_t v[2][4], w[2][4];
+        Elem e[2][4];
 #pragma unroll
-        for (uint32_t half = 0; half < 2; half++) {        // two runs of four consecutive elements per thread: 16-byte loads of D
-            const uint64_t p = p0 + half * (kPjTile / 2);
-            if (p >= n_elems) continue;
-            uint32_t v[4] = {0, 0, 0, 0};
-            const uint32_t n = n_elems - p < 4 ? static_cast<uint32_t>(n_elems - p) : 4u;
-            if (n == 4) {
-                const uint4 w = *reinterpret_cast<const uint4 *>(D + p);   // D is 16-byte aligned, p a multiple of 4
-                v[0] = w.x;
-                v[1] = w.y;
-                v[2] = w.z;
-                v[3] = w.w;
+        for (uint32_t half = 0; half < 2; half++) {
+            p[half] = t * kPjTile + tid * 4 + half * (kPjTile / 2);
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) v[half][k] = 0;
+            if (p[half] >= n_elems) continue;
+            if (n_elems - p[half] >= 4) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(D + p[half]);   // D is 16-byte aligned, p a multiple of 4
+                v[half][0] = x.x;
+                v[half][1] = x.y;
+                v[half][2] = x.z;
+                v[half][3] = x.w;
             } else {
-                for (uint32_t k = 0; k < n; k++) v[k] = D[p + k];
+                for (uint32_t k = 0; k < static_cast<uint32_t>(n_elems - p[half]); k++) v[half][k] = D[p[half] + k];
             }
+        }
+#pragma unroll
+        for (uint32_t half = 0; half < 2; half++)
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {
-                if (v[k] == 0 || v[k] >= kPjFinal) continue;         // literal / final already
-                const uint64_t q = p + k - v[k];
-                const uint32_t w = D[q];
-                if (w == 0 || (w >= kPjFinal && w != mark)) {        // the source was final before this sweep began
-                    out[p + k] = out[q];
-                    D[p + k] = mark;
-                } else if (w >= kPjFinal) {                          // became final during this sweep: its byte may not be visible yet
+                const bool pending = v[half][k] != 0 && v[half][k] < kPjFinal;   // else: literal / final already
+                w[half][k] = pending ? D[p[half] + k - v[half][k]] : 1u;
+            }
+#pragma unroll
+        for (uint32_t half = 0; half < 2; half++)
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const bool pending = v[half][k] != 0 && v[half][k] < kPjFinal;
+                const uint32_t ws = w[half][k];
+                const bool take = pending && (ws == 0 || (ws >= kPjFinal && ws != mark));   // the source was final before this sweep began
+                if (take) e[half][k] = out[p[half] + k - v[half][k]];
+            }
+        uint32_t remaining = 0;
+#pragma unroll
+        for (uint32_t half = 0; half < 2; half++)
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const bool pending = v[half][k] != 0 && v[half][k] < kPjFinal;
+                if (!pending) continue;
+                const uint32_t ws = w[half][k];
+                if (ws == 0 || (ws >= kPjFinal && ws != mark)) {
+                    out[p[half] + k] = e[half][k];
+                    D[p[half] + k] = mark;
+                } else if (ws >= kPjFinal) {                         // became final during this sweep: its byte may not be visible yet
                     remaining++;
                 } else {
-                    if (static_cast<uint64_t>(v[k]) + w < max_dist) D[p + k] = v[k] + w;   // (a distance that cannot grow waits for its source)
+                    if (static_cast<uint64_t>(v[half][k]) + ws < max_dist) D[p[half] + k] = v[half][k] + ws;   // (a distance that cannot grow waits for its source)
                     remaining++;
                 }
             }
-        }
-        s_red[tid] = remaining;
+        if (remaining) atomicAdd(&s_cnt[flip], remaining);
         __syncthreads();
-        for (uint32_t d = 128; d > 0; d >>= 1) {
-            if (tid < d) s_red[tid] += s_red[tid + d];
-            __syncthreads();
-        }
         if (tid == 0) {
-            tile_pending[t] = s_red[0];
-            if (s_red[0]) atomicAdd(&pcount[sweep % 3u], static_cast<unsigned long long>(s_red[0]));
+            const uint32_t c = s_cnt[flip];
+            tile_pending[t] = c;
+            if (c) atomicAdd(&pcount[sweep % 3u], static_cast<unsigned long long>(c));
+            s_cnt[(flip + 2u) % 3u] = 0;                   // (the counter of the tile after next: nobody adds to it before the next barrier)
         }
-        __syncthreads();
+        flip = (flip + 1u) % 3u;
     }
 }
 

@@ -1924,10 +1924,10 @@ __global__ __launch_bounds__(1024) void k_lz_finish_small(uint64_t *l0, uint64_t
 // inside the window, nothing but D and the output is touched (no per-match records), tiles without
 // pending elements cost one word, and after ~log2(longest chain) sweeps everything is final.  The
 // host enqueues a fixed number of sweeps; each returns at once when the one before left nothing.
-// "Final" must mean final BEFORE this launch (another workgroup may be writing the byte right now):
-// elements finalised by sweep s carry kPjFinal | s until a later sweep looks at them.
+// The word of an element that became final holds the element itself beside the mark (one 32-bit store):
+// whoever finds its source final has the value in the same look-up, whenever that source was written.
 constexpr uint32_t kPjTile = 2048;           // elements per tile (256 threads x 8)
-constexpr uint32_t kPjFinal = 0xFFFFFF00u;   // D >= kPjFinal: final, low byte = the sweep that made it so
+constexpr uint32_t kPjFinal = 0xFFFF0000u;   // D >= kPjFinal: final, and the low 16 bits ARE the element (byte / two characters)
 constexpr uint32_t kPjSweeps = 40;           // 2^40 > any chain; what is left after them goes to the frame-order walk
 
 template <bool ASCII>
@@ -2006,9 +2006,9 @@ __global__ __launch_bounds__(256) void k_pj_sweep(uint32_t *D, uint8_t *out_byte
     if (before == 0 || status[0] != 0) return;
     if (tid < 3) s_cnt[tid] = 0;
     __syncthreads();
-    const uint32_t mark = kPjFinal | (sweep & 0xFFu);
     const uint64_t n_tiles = (n_elems + kPjTile - 1) / kPjTile;
     uint32_t flip = 0;
+    unsigned long long wg_pending = 0;                     // (thread 0)
     for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         if (sweep > 1 && tile_pending[t] == 0) continue;    // (the same word for every thread: uniform)
         // Two runs of four consecutive elements per thread.  All the look-ups of a thread are issued before any of its
@@ -2043,39 +2043,88 @@ __global__ __launch_bounds__(256) void k_pj_sweep(uint32_t *D, uint8_t *out_byte
 #pragma unroll
         for (uint32_t half = 0; half < 2; half++)
 #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
+            for (uint32_t k = 0; k < 4; k++) {             // a literal as the source (D == 0): its element is in the output only
                 const bool pending = v[half][k] != 0 && v[half][k] < kPjFinal;
-                const uint32_t ws = w[half][k];
-                const bool take = pending && (ws == 0 || (ws >= kPjFinal && ws != mark));   // the source was final before this sweep began
-                if (take) e[half][k] = out[p[half] + k - v[half][k]];
+                if (pending && w[half][k] == 0) e[half][k] = out[p[half] + k - v[half][k]];
             }
         uint32_t remaining = 0;
 #pragma unroll
-        for (uint32_t half = 0; half < 2; half++)
+        for (uint32_t half = 0; half < 2; half++) {
+            bool changed = false;
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {
                 const bool pending = v[half][k] != 0 && v[half][k] < kPjFinal;
                 if (!pending) continue;
                 const uint32_t ws = w[half][k];
-                if (ws == 0 || (ws >= kPjFinal && ws != mark)) {
-                    out[p[half] + k] = e[half][k];
-                    D[p[half] + k] = mark;
-                } else if (ws >= kPjFinal) {                         // became final during this sweep: its byte may not be visible yet
-                    remaining++;
+                if (ws == 0 || ws >= kPjFinal) {
+                    // final: the word of a final element carries the element itself, so ONE look-up both tells that the
+                    // source is final and fetches it (and there is no "became final a moment ago, is its byte visible?")
+                    const Elem el = ws == 0 ? e[half][k] : static_cast<Elem>(ws & 0xFFFFu);
+                    v[half][k] = kPjFinal | el;            // (the output gets it from here when the sweeps are over: k_pj_emit)
+                    changed = true;
                 } else {
-                    if (static_cast<uint64_t>(v[half][k]) + ws < max_dist) D[p[half] + k] = v[half][k] + ws;   // (a distance that cannot grow waits for its source)
+                    if (static_cast<uint64_t>(v[half][k]) + ws < max_dist) {   // (a distance that cannot grow waits for its source)
+                        v[half][k] += ws;
+                        changed = true;
+                    }
                     remaining++;
                 }
             }
+            // the thread's four words go back as one store (nobody else writes them; readers take the old or the new value)
+            if (changed) {
+                if (n_elems - p[half] >= 4) {
+                    *reinterpret_cast<uint4 *>(D + p[half]) = make_uint4(v[half][0], v[half][1], v[half][2], v[half][3]);
+                } else {
+                    for (uint32_t k = 0; k < static_cast<uint32_t>(n_elems - p[half]); k++) D[p[half] + k] = v[half][k];
+                }
+            }
+        }
         if (remaining) atomicAdd(&s_cnt[flip], remaining);
         __syncthreads();
         if (tid == 0) {
             const uint32_t c = s_cnt[flip];
             tile_pending[t] = c;
-            if (c) atomicAdd(&pcount[sweep % 3u], static_cast<unsigned long long>(c));
+            wg_pending += c;
             s_cnt[(flip + 2u) % 3u] = 0;                   // (the counter of the tile after next: nobody adds to it before the next barrier)
         }
         flip = (flip + 1u) % 3u;
+    }
+    // (one addition per workgroup, not per tile: 700 k additions to one word serialise)
+    if (tid == 0 && wg_pending) atomicAdd(&pcount[sweep % 3u], wg_pending);
+}
+
+// After the sweeps: every element that a sweep made final goes from its word of D to the output (the sweeps themselves
+// do not write the output: one sequential pass here instead of a scattered one-element store per element and sweep).
+template <bool ASCII>
+__global__ __launch_bounds__(256) void k_pj_emit(const uint32_t *__restrict__ D, uint8_t *out_bytes, uint64_t n_elems, const uint32_t *status) {
+    using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
+    Elem *out = reinterpret_cast<Elem *>(out_bytes);
+    if (status[0] != 0) return;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256 * 4;
+    for (uint64_t p = (static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x) * 4; p < n_elems; p += stride) {
+        if (n_elems - p >= 4) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(D + p);
+            const uint32_t v[4] = {w.x, w.y, w.z, w.w};
+            const bool all = v[0] >= kPjFinal && v[1] >= kPjFinal && v[2] >= kPjFinal && v[3] >= kPjFinal;
+            if (all) {                                     // (inside a match: the usual case) one store
+                if (ASCII) {                               // (the output of a tile need not be aligned: memcpy)
+                    const uint32_t x[2] = {(v[0] & 0xFFFFu) | (v[1] << 16), (v[2] & 0xFFFFu) | (v[3] << 16)};
+                    __builtin_memcpy(out + p, x, 8);
+                } else {
+                    const uint32_t x = (v[0] & 0xFFu) | ((v[1] & 0xFFu) << 8) | ((v[2] & 0xFFu) << 16) | (v[3] << 24);
+                    __builtin_memcpy(out + p, &x, 4);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++)
+                    if (v[k] >= kPjFinal) out[p + k] = static_cast<Elem>(v[k] & 0xFFFFu);
+            }
+        } else {
+            for (uint32_t k = 0; k < static_cast<uint32_t>(n_elems - p); k++) {
+                const uint32_t v = D[p + k];
+                if (v >= kPjFinal) out[p + k] = static_cast<Elem>(v & 0xFFFFu);
+            }
+        }
     }
 }
 
@@ -2672,6 +2721,11 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
         for (uint32_t sweep = 1; sweep <= kPjSweeps; sweep++)
             hipLaunchKernelGGL(k_pj_sweep<ASCII>, dim3(static_cast<uint32_t>(tiles)), dim3(256), 0, stream, a.pj_dist, a.out,
                                a.pj_tiles, pcount, a.n_elems, sweep, max_dist, a.status);
+        {
+            uint64_t eg = (a.n_elems / 4 + 255) / 256;
+            if (eg > 256u * 16u) eg = 256u * 16u;
+            hipLaunchKernelGGL(k_pj_emit<ASCII>, dim3(static_cast<uint32_t>(eg ? eg : 1)), dim3(256), 0, stream, a.pj_dist, a.out, a.n_elems, a.status);
+        }
         // anything still pending (a distance that would not fit 32 bits): frame order
         hipLaunchKernelGGL(k_lz_matches_ordered<ASCII>, dim3(1), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.meta,
                            a.blk_pending, a.rep_init, a.blk_base, a.out, pcount + kPjSweeps % 3u, a.status);

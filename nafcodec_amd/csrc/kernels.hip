@@ -1928,6 +1928,7 @@ __global__ __launch_bounds__(1024) void k_lz_finish_small(uint64_t *l0, uint64_t
 // whoever finds its source final has the value in the same look-up, whenever that source was written.
 constexpr uint32_t kPjTile = 2048;           // elements per tile (256 threads x 8)
 constexpr uint32_t kPjFinal = 0xFFFF0000u;   // D >= kPjFinal: final, and the low 16 bits ARE the element (byte / two characters)
+constexpr uint32_t kPjLocal = 4;             // jumps inside the tile (LDS) before a sweep looks into memory
 constexpr uint32_t kPjSweeps = 40;           // 2^40 > any chain; what is left after them goes to the frame-order walk
 
 template <bool ASCII>
@@ -1995,7 +1996,8 @@ __global__ __launch_bounds__(256) void k_pj_sweep(uint32_t *D, uint8_t *out_byte
                                                   uint64_t n_elems, uint32_t sweep, uint32_t max_dist, const uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
-    __shared__ uint32_t s_cnt[3];                          // pending elements of the tile, three counters in rotation (one barrier per tile)
+    __shared__ uint32_t s_cnt[3];                          // pending elements of the tile, three counters in rotation
+    __shared__ uint32_t s_D[kPjTile];                      // the tile's words: the first few jumps of a sweep stay inside the tile
     const uint32_t tid = threadIdx.x;
     // pcount[s % 3] = elements still pending after sweep s (pcount[0] != 0 before the first one)
     const unsigned long long before = pcount[(sweep + 2u) % 3u];
@@ -2033,6 +2035,48 @@ __global__ __launch_bounds__(256) void k_pj_sweep(uint32_t *D, uint8_t *out_byte
                 for (uint32_t k = 0; k < static_cast<uint32_t>(n_elems - p[half]); k++) v[half][k] = D[p[half] + k];
             }
         }
+        // Jumps whose source lies in the same tile are taken in LDS first, kPjLocal times over: quality strings and
+        // tandem repeats copy from a few hundred elements back, so a sweep advances a chain by up to 2^kPjLocal doublings for
+        // one pass over D in memory.  No barriers between the rounds: a thread writes its own eight words only, and a word
+        // read a moment early or late is a valid ancestor (or the final value) either way.
+        uint32_t v0[2][4];                                 // as loaded: what differs at the end is stored
+#pragma unroll
+        for (uint32_t half = 0; half < 2; half++) {
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) v0[half][k] = v[half][k];
+            // literals (0: final, element in the output) become final WORDS the first time a sweep sees them: from then on
+            // whoever copies from them -- in this tile's LDS rounds right away -- needs no second look-up
+            if ((v[half][0] == 0 || v[half][1] == 0 || v[half][2] == 0 || v[half][3] == 0) && p[half] < n_elems) {
+                Elem el[4] = {0, 0, 0, 0};
+                if (n_elems - p[half] >= 4)
+                    __builtin_memcpy(el, out + p[half], 4 * sizeof(Elem));
+                else
+                    for (uint32_t k = 0; k < static_cast<uint32_t>(n_elems - p[half]); k++) el[k] = out[p[half] + k];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++)
+                    if (v[half][k] == 0 && p[half] + k < n_elems) v[half][k] = kPjFinal | el[k];
+            }
+            *reinterpret_cast<uint4 *>(&s_D[tid * 4 + half * (kPjTile / 2)]) = make_uint4(v[half][0], v[half][1], v[half][2], v[half][3]);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t it = 0; it < kPjLocal; it++) {
+#pragma unroll
+            for (uint32_t half = 0; half < 2; half++)
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t li = tid * 4 + half * (kPjTile / 2) + k, d = v[half][k];
+                    if (d == 0 || d >= kPjFinal || d > li) continue;           // literal / final / source outside the tile
+                    const uint32_t ws = s_D[li - d];
+                    if (ws >= kPjFinal) {
+                        v[half][k] = ws;                                        // (mark and element of the source: ours too)
+                        s_D[li] = ws;
+                    } else if (ws != 0 && static_cast<uint64_t>(d) + ws < max_dist) {
+                        v[half][k] = d + ws;
+                        s_D[li] = d + ws;
+                    }                                                           // (a literal in the tile: its element is in the output -- below)
+                }
+        }
 #pragma unroll
         for (uint32_t half = 0; half < 2; half++)
 #pragma unroll
@@ -2050,7 +2094,7 @@ __global__ __launch_bounds__(256) void k_pj_sweep(uint32_t *D, uint8_t *out_byte
         uint32_t remaining = 0;
 #pragma unroll
         for (uint32_t half = 0; half < 2; half++) {
-            bool changed = false;
+            bool changed = v[half][0] != v0[half][0] || v[half][1] != v0[half][1] || v[half][2] != v0[half][2] || v[half][3] != v0[half][3];
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {
                 const bool pending = v[half][k] != 0 && v[half][k] < kPjFinal;

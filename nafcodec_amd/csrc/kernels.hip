@@ -29,7 +29,8 @@ namespace {
 #define NAFGPU_ABLATE 0
 #endif
 constexpr uint32_t kAblate = NAFGPU_ABLATE;   // k_huf_decode: 1 no output stores, 2 no look-ups (rows fill instantly), 4 no input loads,
-                                              // 8 no table staging, 16 stores only to a small window, 32 no dictionary reads
+                                              // 8 no table staging, 16 stores only to a small window, 32 no dictionary reads;
+                                              // k_mask_apply: 512 no atomics on shared chunks, 1024 no record search
 
 __device__ inline void flag_error(uint32_t *status, uint32_t code, uint32_t detail) {
     if (kAblate) return;
@@ -2306,7 +2307,7 @@ __device__ inline void masked_run_range(uint64_t k, uint64_t n_bases, uint64_t l
     } else if (e > n_bases) {                          // MaskReader stops at `total`: the overshoot is never applied
         e = spec_mask ? n_bases : s;
     }
-    if (e > s && !spec_mask) {
+    if (e > s && !spec_mask && !(kAblate & 1024u)) {
         uint64_t lo = 0, hi = n_rec;                   // first record whose end is > e - 1
         while (lo < hi) {
             const uint64_t mid = (lo + hi) >> 1;
@@ -2415,7 +2416,7 @@ __global__ __launch_bounds__(256) void k_mask_apply(uint8_t *ascii, uint64_t n_b
                     for (int d = 0; d < 4; d++) {
                         const uint32_t sel = (((in_range >> (4 * d)) & 0xFu) * 0x00204081u & 0x01010101u) * 0xFFu;
                         const uint32_t m = (lower4(w[d]) ^ w[d]) & sel;
-                        if (m) atomicOr(reinterpret_cast<uint32_t *>(abase + addr[u]) + d, m);
+                        if (m && !(kAblate & 512u)) atomicOr(reinterpret_cast<uint32_t *>(abase + addr[u]) + d, m);
                     }
                 }
             }

@@ -166,4 +166,67 @@ private:
 
 inline Decoder Decoder::from_path(const std::string &path) { return DecoderBuilder().with_path(path); }
 
+// ---- Encoder (encoder/mod.rs:46-384).  Host code, as in the reference; see include/nafgpu.h for what is written.
+class Encoder {      // mod.rs:215-384 (Memory storage)
+public:
+    Encoder(Encoder &&o) noexcept : e_(o.e_) { o.e_ = nullptr; }
+    Encoder(const Encoder &) = delete;
+    ~Encoder() { if (e_) nafgpu_encoder_free(e_); }
+    void push(const Record &r) {                                                     // mod.rs:236-323
+        nafgpu_record c{};
+        auto field = [](const std::optional<std::string> &s, nafgpu_field *f) {
+            if (!s) return;
+            f->ptr = reinterpret_cast<const uint8_t *>(s->data());
+            f->len = s->size();
+            f->present = 1;
+        };
+        field(r.id, &c.id);
+        field(r.comment, &c.comment);
+        field(r.sequence, &c.sequence);
+        field(r.quality, &c.quality);
+        if (r.length) {
+            c.length = *r.length;
+            c.has_length = 1;
+        }
+        nafgpu_error err{};
+        if (nafgpu_encoder_push(e_, &c, &err) != NAFGPU_OK) throw Error(err);
+    }
+    std::string write() {                                                            // mod.rs:325-384 into a string
+        const uint8_t *p = nullptr;
+        uint64_t n = 0;
+        nafgpu_error err{};
+        if (nafgpu_encoder_finish(e_, &p, &n, &err) != NAFGPU_OK) throw Error(err);
+        return std::string(reinterpret_cast<const char *>(p), n);
+    }
+
+private:
+    friend class EncoderBuilder;
+    explicit Encoder(nafgpu_encoder *e) : e_(e) {}
+    nafgpu_encoder *e_ = nullptr;
+};
+
+class EncoderBuilder {   // mod.rs:46-213
+public:
+    explicit EncoderBuilder(SequenceType t) { nafgpu_encoder_opts_default(static_cast<uint8_t>(t), &o_); }   // mod.rs:81-90
+    static EncoderBuilder from_flags(SequenceType t, Flags f) {                      // mod.rs:92-110
+        EncoderBuilder b(t);
+        nafgpu_encoder_opts_from_flags(static_cast<uint8_t>(t), f.as_byte(), &b.o_);
+        return b;
+    }
+    EncoderBuilder &id(bool v) { o_.id = v; return *this; }
+    EncoderBuilder &comment(bool v) { o_.comment = v; return *this; }
+    EncoderBuilder &sequence(bool v) { o_.sequence = v; return *this; }
+    EncoderBuilder &quality(bool v) { o_.quality = v; return *this; }
+    EncoderBuilder &compression_level(int v) { o_.compression_level = v; return *this; }
+    Encoder with_memory() const {                                                    // mod.rs:161-163
+        nafgpu_encoder *e = nullptr;
+        nafgpu_error err{};
+        if (nafgpu_encoder_new(&o_, &e, &err) != NAFGPU_OK) throw Error(err);
+        return Encoder(e);
+    }
+
+private:
+    nafgpu_encoder_opts o_{};
+};
+
 }  // namespace nafcodec

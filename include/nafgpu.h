@@ -40,7 +40,10 @@ typedef enum {
     NAFGPU_E_UTF8 = -3,          /* Error::Utf8 */
     NAFGPU_E_PANIC = -4,         /* the reference panics / never returns on this input */
     NAFGPU_E_DEVICE = -5,        /* HIP runtime failure, no usable GPU, out of device memory */
-    NAFGPU_E_INVALID_ARG = -6
+    NAFGPU_E_INVALID_ARG = -6,
+    NAFGPU_E_MISSING_FIELD = -7,     /* Error::MissingField (encoder/mod.rs:254,265,298,316) */
+    NAFGPU_E_INVALID_LENGTH = -8,    /* Error::InvalidLength (encoder/mod.rs:273-276,303-306) */
+    NAFGPU_E_INVALID_SEQUENCE = -9   /* Error::InvalidSequence (encoder/mod.rs:284-290, writer.rs:31-56) */
 } nafgpu_status;
 
 typedef enum {                   /* std::io::ErrorKind values used on the path */
@@ -260,6 +263,35 @@ int nafgpu_synth_write(const nafgpu_synth_spec *spec, nafgpu_synth_archive *out)
  * that head; the archive is head followed by part 0, part 1, ...; seq_hash is 0 (the parts' values add up). */
 int nafgpu_synth_head(const nafgpu_synth_spec *spec, uint64_t seq_part_bytes, nafgpu_synth_archive *out);
 void nafgpu_synth_free(nafgpu_synth_archive *a);
+
+/* ---- Encoder (EncoderBuilder / Encoder, encoder/mod.rs:46-384, writer.rs) ----------------
+ * Host code: the reference's encoder is CPU code too, and the decode path above is what runs on the GPU.  Same
+ * surface and checks as the reference; every section is written as one magicless Zstandard frame of 128 KiB
+ * Huffman-literal blocks (no LZ matching: `compression_level` is accepted and ignored), which the reference's
+ * decoder, libzstd and this library all read.  Sections are kept in memory until the archive is written (the
+ * reference's `Memory` storage, storage.rs).  Like the reference's encoder it never writes a Mask section and
+ * accepts upper-case IUPAC letters only. */
+typedef struct {
+    uint8_t sequence_type;       /* 0 dna, 1 rna, 2 protein, 3 text (EncoderBuilder::new, mod.rs:81-90) */
+    uint8_t id, comment, sequence, quality;   /* opt-in fields (mod.rs:112-145); all 0 by default */
+    uint8_t reserved[3];
+    int32_t compression_level;   /* mod.rs:147-157; ignored (see above) */
+    uint32_t threads;            /* blocks are encoded in parallel when the archive is written; 0 = hardware concurrency */
+} nafgpu_encoder_opts;
+typedef struct nafgpu_encoder nafgpu_encoder;
+
+void nafgpu_encoder_opts_default(uint8_t sequence_type, nafgpu_encoder_opts *opts);
+/* EncoderBuilder::from_flags (mod.rs:92-110): NAF flag bits 0x20 id, 0x10 comment, 0x02 sequence, 0x01 quality */
+void nafgpu_encoder_opts_from_flags(uint8_t sequence_type, uint8_t flags, nafgpu_encoder_opts *opts);
+/* EncoderBuilder::with_memory (mod.rs:161-163) */
+int nafgpu_encoder_new(const nafgpu_encoder_opts *opts, nafgpu_encoder **out, nafgpu_error *err);
+/* Encoder::push (mod.rs:236-323).  Only the enabled fields are read.  A record that is refused (missing field,
+ * inconsistent length, invalid letter) leaves the encoder as it was -- the reference has by then written the
+ * fields in front of the offending one. */
+int nafgpu_encoder_push(nafgpu_encoder *enc, const nafgpu_record *rec, nafgpu_error *err);
+/* Encoder::write (mod.rs:325-384) into memory: *bytes stays valid until nafgpu_encoder_free; no push afterwards */
+int nafgpu_encoder_finish(nafgpu_encoder *enc, const uint8_t **bytes, uint64_t *n, nafgpu_error *err);
+void nafgpu_encoder_free(nafgpu_encoder *enc);
 
 /* order-sensitive 64-bit checksum used for full-size parity checks: sum over the 8-byte words w_j of
  * mix64(w_j ^ (j + 1) * K) -- every word is mixed non-linearly with its position before it is added, so

@@ -4,7 +4,8 @@ Python mirror of the reference's public surface for the decode path
 (nafcodec-py/nafcodec/lib.pyi:18-67 and __init__.py:3-9): `Decoder`, `Record`, `open`.
 All decoding happens on the GPU inside libnafgpu.so (include/nafgpu.h); there is no CPU path."""
 from .decoder import Decoder, Record, open  # noqa: F401
+from .encoder import Encoder  # noqa: F401
 from ._ffi import NafError  # noqa: F401
 
 __version__ = "0.1.0"
-__all__ = ["Decoder", "Record", "open", "NafError"]
+__all__ = ["Decoder", "Encoder", "Record", "open", "NafError"]

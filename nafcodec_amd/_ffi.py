@@ -13,6 +13,7 @@ DEFAULT_PATH = os.path.join(_HERE, "libnafgpu.so")
 
 OK, END = 0, 1
 E_IO, E_NOM, E_UTF8, E_PANIC, E_DEVICE, E_INVALID_ARG = -1, -2, -3, -4, -5, -6
+E_MISSING_FIELD, E_INVALID_LENGTH, E_INVALID_SEQUENCE = -7, -8, -9
 IO_UNEXPECTED_EOF, IO_INVALID_DATA, IO_NOT_FOUND, IO_IS_A_DIRECTORY, IO_PERMISSION_DENIED, IO_OTHER = 1, 2, 3, 4, 5, 6
 NOM_VERIFY, NOM_MAPRES, NOM_TOOLARGE = 1, 2, 3
 
@@ -75,6 +76,11 @@ class SynthArchive(Structure):
                 ("seq_hash", c_uint64), ("offsets_hash", c_uint64)]
 
 
+class EncoderOpts(Structure):
+    _fields_ = [("sequence_type", c_uint8), ("id", c_uint8), ("comment", c_uint8), ("sequence", c_uint8), ("quality", c_uint8),
+                ("reserved", c_uint8 * 3), ("compression_level", ctypes.c_int32), ("threads", c_uint32)]
+
+
 READ_FN = ctypes.CFUNCTYPE(c_int64, c_void_p, POINTER(c_uint8), c_uint64)
 SEEK_FN = ctypes.CFUNCTYPE(c_int64, c_void_p, c_int64, c_int)
 
@@ -86,6 +92,8 @@ EXPORTS = [
     "nafgpu_hash64_host", "nafgpu_hash64_device", "nafgpu_abi_version", "nafgpu_device_info",
     "nafgpu_upload", "nafgpu_device_synchronize", "nafgpu_hash64_device_at",
     "nafgpu_format_device", "nafgpu_copy_to_host", "nafgpu_synth_head",
+    "nafgpu_encoder_opts_default", "nafgpu_encoder_opts_from_flags", "nafgpu_encoder_new", "nafgpu_encoder_push",
+    "nafgpu_encoder_finish", "nafgpu_encoder_free",
 ]
 
 
@@ -118,6 +126,15 @@ class Library:
         L.nafgpu_device_synchronize.argtypes = [c_int]
         L.nafgpu_zstd_decompress.argtypes = [c_char_p, c_size_t, c_void_p, c_size_t, POINTER(c_size_t), c_int,
                                              POINTER(Error)]
+        L.nafgpu_encoder_opts_default.argtypes = [c_uint8, POINTER(EncoderOpts)]
+        L.nafgpu_encoder_opts_default.restype = None
+        L.nafgpu_encoder_opts_from_flags.argtypes = [c_uint8, c_uint8, POINTER(EncoderOpts)]
+        L.nafgpu_encoder_opts_from_flags.restype = None
+        L.nafgpu_encoder_new.argtypes = [POINTER(EncoderOpts), POINTER(c_void_p), POINTER(Error)]
+        L.nafgpu_encoder_push.argtypes = [c_void_p, POINTER(Record), POINTER(Error)]
+        L.nafgpu_encoder_finish.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_uint64), POINTER(Error)]
+        L.nafgpu_encoder_free.argtypes = [c_void_p]
+        L.nafgpu_encoder_free.restype = None
         L.nafgpu_synth_write.argtypes = [POINTER(SynthSpec), POINTER(SynthArchive)]
         L.nafgpu_synth_head.argtypes = [POINTER(SynthSpec), c_uint64, POINTER(SynthArchive)]
         L.nafgpu_synth_free.argtypes = [POINTER(SynthArchive)]

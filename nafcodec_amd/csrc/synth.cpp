@@ -11,8 +11,10 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -352,6 +354,14 @@ void encode_block(const uint8_t *data, size_t n, bool last, HufCode *prev, std::
     if (n < 64) return raw_block();
     uint32_t count[256] = {0};
     for (size_t i = 0; i < n; i++) count[data[i]]++;
+    if (count[data[0]] == n) {                                   // one byte value: an RLE block (Huffman needs two symbols)
+        const uint32_t bh = static_cast<uint32_t>(n << 3) | (1u << 1) | (last ? 1u : 0u);
+        out.push_back(bh & 0xFF);
+        out.push_back((bh >> 8) & 0xFF);
+        out.push_back((bh >> 16) & 0xFF);
+        out.push_back(data[0]);
+        return;
+    }
     HufCode cur{};
     std::vector<uint8_t> tree;
     bool have_new = build_lengths(count, cur.len);
@@ -666,3 +676,231 @@ extern "C" void nafgpu_synth_free(nafgpu_synth_archive *a) {
     if (a && a->bytes) std::free(a->bytes);
     if (a) std::memset(a, 0, sizeof *a);
 }
+
+// ======================================================================================
+// Encoder (EncoderBuilder / Encoder / SequenceWriter: encoder/mod.rs:46-384, writer.rs:6-100)
+// ======================================================================================
+namespace {
+
+// one section -> one magicless frame of 128 KiB Huffman-literal blocks; chunks of kChunkBlocks blocks in parallel
+void compress_section(const std::vector<uint8_t> &data, unsigned n_threads, std::vector<uint8_t> &out) {
+    if (data.size() < 64) {                       // nothing to gain: raw blocks (an empty section is one empty last block)
+        raw_frame(data, out);
+        return;
+    }
+    const uint64_t n_blocks = (data.size() + kBlockMax - 1) / kBlockMax;
+    const uint64_t n_chunks = (n_blocks + kChunkBlocks - 1) / kChunkBlocks;
+    std::vector<std::vector<uint8_t>> chunk_out(n_chunks);
+    std::atomic<uint64_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const uint64_t c = next.fetch_add(1);
+            if (c >= n_chunks) break;
+            HufCode prev{};
+            for (uint64_t b = c * kChunkBlocks; b < std::min(n_blocks, (c + 1) * kChunkBlocks); b++) {
+                const size_t p0 = static_cast<size_t>(b * kBlockMax);
+                encode_block(data.data() + p0, std::min<size_t>(kBlockMax, data.size() - p0), b == n_blocks - 1, &prev, chunk_out[c]);
+            }
+        }
+    };
+    if (n_threads == 0) n_threads = std::max(1u, std::thread::hardware_concurrency());
+    n_threads = static_cast<unsigned>(std::min<uint64_t>(n_threads, n_chunks));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < n_threads; t++) pool.emplace_back(worker);
+    worker();
+    for (auto &t : pool) t.join();
+    out.push_back(0x00);   // FHD: no content size, no checksum, no dictionary
+    out.push_back(0x48);   // window 512 KiB (no block refers back)
+    for (auto &c : chunk_out) out.insert(out.end(), c.begin(), c.end());
+}
+
+// SequenceWriter::encode (writer.rs:31-56): upper-case IUPAC, '-' = 0; T for DNA, U for RNA
+int nucleotide_code(uint8_t c, uint8_t sequence_type) {
+    switch (c) {
+    case 'A': return 0x08;
+    case 'C': return 0x04;
+    case 'G': return 0x02;
+    case 'T': return sequence_type == 0 ? 0x01 : -1;
+    case 'U': return sequence_type == 1 ? 0x01 : -1;
+    case 'R': return 0x0A;
+    case 'Y': return 0x05;
+    case 'S': return 0x06;
+    case 'W': return 0x09;
+    case 'K': return 0x03;
+    case 'M': return 0x0C;
+    case 'B': return 0x07;
+    case 'D': return 0x0B;
+    case 'H': return 0x0D;
+    case 'V': return 0x0E;
+    case 'N': return 0x0F;
+    case '-': return 0x00;
+    default: return -1;
+    }
+}
+
+void put_length_words(std::vector<uint8_t> &out, uint64_t l) {   // write_length, encoder/mod.rs:37-44
+    auto word = [&](uint32_t w) {
+        for (int k = 0; k < 4; k++) out.push_back(static_cast<uint8_t>(w >> (8 * k)));
+    };
+    while (l >= 0xFFFFFFFFull) {
+        word(0xFFFFFFFFu);
+        l -= 0xFFFFFFFFull;
+    }
+    word(static_cast<uint32_t>(l));
+}
+
+int enc_fail(nafgpu_error *err, int status, const char *msg) {
+    if (err) {
+        std::memset(err, 0, sizeof *err);
+        err->status = status;
+        std::snprintf(err->message, sizeof err->message, "%s", msg);
+    }
+    return status;
+}
+
+}  // namespace
+
+struct nafgpu_encoder {
+    nafgpu_encoder_opts opt{};
+    std::vector<uint8_t> ids, coms, lens, seq, qual;   // section contents, uncompressed (Memory storage: storage.rs)
+    uint64_t seq_letters = 0;                           // what the reference's WriteCounter counts for the sequence: letters
+    int cache = -1;                                     // a nucleotide waiting for its partner (writer.rs:9,69-77)
+    uint64_t n_records = 0;
+    std::vector<uint8_t> archive;
+    bool finished = false;
+};
+
+extern "C" void nafgpu_encoder_opts_default(uint8_t sequence_type, nafgpu_encoder_opts *opts) {
+    if (!opts) return;
+    std::memset(opts, 0, sizeof *opts);
+    opts->sequence_type = sequence_type;
+}
+
+extern "C" void nafgpu_encoder_opts_from_flags(uint8_t sequence_type, uint8_t flags, nafgpu_encoder_opts *opts) {
+    nafgpu_encoder_opts_default(sequence_type, opts);
+    if (!opts) return;
+    opts->id = (flags & 0x20) != 0;
+    opts->comment = (flags & 0x10) != 0;
+    opts->sequence = (flags & 0x02) != 0;
+    opts->quality = (flags & 0x01) != 0;
+}
+
+extern "C" int nafgpu_encoder_new(const nafgpu_encoder_opts *opts, nafgpu_encoder **out, nafgpu_error *err) {
+    if (!opts || !out || opts->sequence_type > 3) return enc_fail(err, NAFGPU_E_INVALID_ARG, "invalid encoder options");
+    nafgpu_encoder *e = new (std::nothrow) nafgpu_encoder();
+    if (!e) return enc_fail(err, NAFGPU_E_IO, "out of memory");
+    e->opt = *opts;
+    *out = e;
+    return NAFGPU_OK;
+}
+
+extern "C" int nafgpu_encoder_push(nafgpu_encoder *e, const nafgpu_record *r, nafgpu_error *err) {
+    if (!e || !r) return enc_fail(err, NAFGPU_E_INVALID_ARG, "null argument");
+    if (e->finished) return enc_fail(err, NAFGPU_E_INVALID_ARG, "the archive has been written already");
+    const bool nuc = e->opt.sequence_type <= 1;
+    // ---- every check first (mod.rs:236-317 checks field by field, writing as it goes)
+    if (e->opt.id && !r->id.present) return enc_fail(err, NAFGPU_E_MISSING_FIELD, "missing record field: \"id\"");
+    if (e->opt.comment && !r->comment.present) return enc_fail(err, NAFGPU_E_MISSING_FIELD, "missing record field: \"comment\"");
+    if (e->opt.sequence && !r->sequence.present) return enc_fail(err, NAFGPU_E_MISSING_FIELD, "missing record field: \"sequence\"");
+    if (e->opt.sequence && r->has_length && r->length != r->sequence.len)
+        return enc_fail(err, NAFGPU_E_INVALID_LENGTH, "inconsistent sequence length");
+    if (e->opt.sequence && nuc)
+        for (uint64_t i = 0; i < r->sequence.len; i++)
+            if (nucleotide_code(r->sequence.ptr[i], e->opt.sequence_type) < 0)
+                return enc_fail(err, NAFGPU_E_INVALID_SEQUENCE, "invalid character in sequence");
+    if (e->opt.quality && !r->quality.present) return enc_fail(err, NAFGPU_E_MISSING_FIELD, "missing record field: \"quality\"");
+    bool have_len = r->has_length != 0;
+    uint64_t len = r->length;
+    if (e->opt.sequence && !have_len) {
+        have_len = true;
+        len = r->sequence.len;
+    }
+    if (e->opt.quality && have_len && len != r->quality.len) return enc_fail(err, NAFGPU_E_INVALID_LENGTH, "inconsistent sequence length");
+    // ---- commit
+    if (r->has_length) put_length_words(e->lens, r->length);                         // mod.rs:239-242
+    if (e->opt.id) {
+        e->ids.insert(e->ids.end(), r->id.ptr, r->id.ptr + r->id.len);
+        e->ids.push_back(0);
+    }
+    if (e->opt.comment) {
+        e->coms.insert(e->coms.end(), r->comment.ptr, r->comment.ptr + r->comment.len);
+        e->coms.push_back(0);
+    }
+    bool wrote_len = r->has_length != 0;
+    if (e->opt.sequence) {
+        if (!wrote_len) {
+            put_length_words(e->lens, r->sequence.len);                              // mod.rs:278-282
+            wrote_len = true;
+        }
+        const uint8_t *s = r->sequence.ptr;
+        uint64_t n = r->sequence.len;
+        e->seq_letters += n;
+        if (!nuc) {
+            e->seq.insert(e->seq.end(), s, s + n);
+        } else if (n) {                                                              // writer.rs:60-93: two letters per byte, first in the low nibble
+            if (e->cache >= 0) {
+                e->seq.push_back(static_cast<uint8_t>((nucleotide_code(s[0], e->opt.sequence_type) << 4) | e->cache));
+                e->cache = -1;
+                s++;
+                n--;
+            }
+            for (uint64_t i = 0; i + 1 < n; i += 2)
+                e->seq.push_back(static_cast<uint8_t>((nucleotide_code(s[i + 1], e->opt.sequence_type) << 4) |
+                                                      nucleotide_code(s[i], e->opt.sequence_type)));
+            if (n & 1) e->cache = nucleotide_code(s[n - 1], e->opt.sequence_type);
+        }
+    }
+    if (e->opt.quality) {
+        if (!wrote_len) put_length_words(e->lens, r->quality.len);                   // mod.rs:308-312
+        e->qual.insert(e->qual.end(), r->quality.ptr, r->quality.ptr + r->quality.len);
+    }
+    e->n_records++;
+    return NAFGPU_OK;
+}
+
+extern "C" int nafgpu_encoder_finish(nafgpu_encoder *e, const uint8_t **bytes, uint64_t *n, nafgpu_error *err) {
+    if (!e || !bytes || !n) return enc_fail(err, NAFGPU_E_INVALID_ARG, "null argument");
+    if (!e->finished) {
+        if (e->cache >= 0) {                                                         // SequenceWriter::into_inner, writer.rs:21-28
+            e->seq.push_back(static_cast<uint8_t>(e->cache));
+            e->cache = -1;
+        }
+        std::vector<uint8_t> &o = e->archive;
+        o.insert(o.end(), {0x01, 0xF9, 0xEC});                                       // mod.rs:327
+        uint8_t flags = 0;                                                           // mod.rs:176-193
+        if (e->opt.id) flags |= 0x20;
+        if (e->opt.comment) flags |= 0x10;
+        if (e->opt.sequence) flags |= 0x02 | 0x08;
+        if (e->opt.quality) flags |= 0x01 | 0x08;
+        if (e->opt.sequence_type == 0) {                                             // V1 for DNA, V2 else (mod.rs:169-173, 329-342)
+            o.insert(o.end(), {0x01, flags, ' '});
+        } else {
+            o.insert(o.end(), {0x02, e->opt.sequence_type, flags, ' '});
+        }
+        put_varint(o, 60);                                                           // Header::default().line_length (data.rs:246)
+        put_varint(o, e->n_records);
+        auto block = [&](const std::vector<uint8_t> &data, uint64_t original) {      // write_block!, mod.rs:349-367
+            std::vector<uint8_t> frame;
+            compress_section(data, e->opt.threads, frame);
+            put_varint(o, original);
+            put_varint(o, frame.size());
+            o.insert(o.end(), frame.begin(), frame.end());
+        };
+        if (e->opt.id) block(e->ids, e->ids.size());
+        if (e->opt.comment) block(e->coms, e->coms.size());
+        block(e->lens, e->lens.size());                                              // always, whatever the flags say (mod.rs:371)
+        if (e->opt.sequence) block(e->seq, e->seq_letters);                          // letters, not bytes (the counter wraps the SequenceWriter)
+        if (e->opt.quality) block(e->qual, e->qual.size());
+        e->finished = true;
+        std::vector<uint8_t>().swap(e->ids);
+        std::vector<uint8_t>().swap(e->coms);
+        std::vector<uint8_t>().swap(e->lens);
+        std::vector<uint8_t>().swap(e->seq);
+        std::vector<uint8_t>().swap(e->qual);
+    }
+    *bytes = e->archive.data();
+    *n = e->archive.size();
+    return NAFGPU_OK;
+}
+
+extern "C" void nafgpu_encoder_free(nafgpu_encoder *e) { delete e; }

@@ -230,7 +230,10 @@ class Decoder:
 
 
 def open(file, mode="r", **options):
-    """nafcodec.open (lib.pyi:92-108).  Only mode "r" exists here: the encoder is outside the hot path."""
-    if mode != "r":
-        raise ValueError("invalid mode: %r (nafcodec_amd implements the decode path only)" % (mode,))
-    return Decoder(file, **options)
+    """nafcodec.open (lib.pyi:89-108, nafcodec/__init__.py): "r" -> Decoder, "w" -> Encoder."""
+    if mode == "r":
+        return Decoder(file, **options)
+    if mode == "w":
+        from .encoder import Encoder
+        return Encoder(file, **options)
+    raise ValueError("invalid mode: %r" % (mode,))

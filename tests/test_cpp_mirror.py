@@ -67,6 +67,30 @@ int main(int argc, char **argv) {
         } catch (const Error &e) {
             std::printf("open error io=%d\n", (int)e.is_io());
         }
+        // EncoderBuilder / Encoder (encoder/mod.rs:46-384; nafcodec/tests/encoder.rs): written, then read back by the Decoder
+        {
+            Encoder enc = EncoderBuilder::from_flags(SequenceType::Dna, Flag::Id | Flag::Sequence).quality(true).with_memory();
+            Record a, b;
+            a.id = "r1"; a.comment = "record 1"; a.sequence = "NGCTCTTAAACCTGCTA"; a.quality = "#8CCCGGGGGGGGGGGG"; a.length = 17;
+            b.id = "r2"; b.sequence = "NTAATAAGCAATGACGGCAGC"; b.quality = "#8AACCFF<FFGGFGE@@@@@";
+            enc.push(a);
+            enc.push(b);
+            int refused = 0;
+            try { Record c; c.id = "r3"; c.sequence = "ACGX"; c.quality = "IIII"; enc.push(c); } catch (const Error &e) { refused += e.raw.status == NAFGPU_E_INVALID_SEQUENCE; }
+            try { Record c; c.id = "r3"; c.sequence = "ACG"; c.quality = "IIII"; enc.push(c); } catch (const Error &e) { refused += e.raw.status == NAFGPU_E_INVALID_LENGTH; }
+            try { Record c; c.sequence = "ACG"; c.quality = "III"; enc.push(c); } catch (const Error &e) { refused += e.raw.status == NAFGPU_E_MISSING_FIELD; }
+            const std::string archive = enc.write();
+            Decoder back = DecoderBuilder().with_bytes(reinterpret_cast<const uint8_t *>(archive.data()), archive.size());
+            size_t k = 0;
+            bool same = true;
+            while (auto rec = back.next()) {
+                const Record &w = k == 0 ? a : b;
+                same = same && rec->id == w.id && !rec->comment && rec->sequence == w.sequence && rec->quality == w.quality &&
+                       rec->length == std::optional<uint64_t>(w.sequence->size());
+                k++;
+            }
+            std::printf("encoder %zu records back, same %d, refused %d\n", k, (int)same, refused);
+        }
     } catch (const Error &e) {
         std::printf("Error: %s\n", e.what());
         return 1;
@@ -92,6 +116,7 @@ def build_and_run(tmp_path, libdir, libname, extra_env=None):
     assert lines[2] == "text equal"
     assert lines[3] == "reader 42 records, 0 with sequence, lengths 12436, seeks>0 1"
     assert lines[4] == "open error io=1"
+    assert lines[5] == "encoder 2 records back, same 1, refused 3"
 
 
 def test_cpp_mirror_on_the_cpu_harness(tmp_path):

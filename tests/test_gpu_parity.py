@@ -282,3 +282,24 @@ def test_device_string_tables_and_utf8_flags(lib):
         assert Decoder(io.BytesIO(bad), **({})).decode_all_device().utf8_invalid == 1 << bit, (section, payload)
     good = nw.write_naf(recs, raw_sections={"comments": "é\u20ac\U0001F600\x00y\x00".encode()})
     assert Decoder(io.BytesIO(good), **({})).decode_all_device().utf8_invalid == 0
+
+
+def test_encoder_output_decodes_on_the_gpu(lib):
+    """Archives written by nafcodec_amd.Encoder (nafgpu_encoder_*: SURVEY 8f-1) come back unchanged through the HIP path:
+    every sequence type, records across many zstd blocks, single-symbol sections (RLE blocks), an odd total of nucleotides."""
+    import nafcodec_amd
+    rng = np.random.default_rng(23)
+    for st, alphabet, iupac in (("dna", "ACGT", 0.02), ("rna", "ACGU", 0.01), ("protein", "ACDEFGHIKLMNPQRSTVWY", 0.0), ("text", "abc xyz,.", 0.0)):
+        recs = []
+        for i, n in enumerate([0, 1, 2, 151, 0, 700001, 3000003, 3, 999]):
+            recs.append(nafcodec_amd.Record(id="rec%d" % i, comment="comment %d é" % i if i % 3 else "",
+                                            sequence=cases.rand_dna(rng, n, alphabet, iupac), quality="I" * n if i % 2 else
+                                            "".join(rng.choice(list("#8CGGGGGG<AFFJJ"), n))))
+        buf = io.BytesIO()
+        with nafcodec_amd.Encoder(buf, st, id=True, comment=True, sequence=True, quality=True) as enc:
+            for r in recs:
+                enc.write(r)
+        got = list(nafcodec_amd.Decoder(io.BytesIO(buf.getvalue())))
+        assert len(got) == len(recs)
+        for a, b in zip(got, recs):
+            assert (a.id, a.comment, a.sequence, a.quality, a.length) == (b.id, b.comment, b.sequence, b.quality, len(b.sequence)), (st, b.id)

@@ -809,9 +809,10 @@ __device__ inline uint32_t rep_minus_one(uint32_t r) {      // rep - 1 for a con
     return r + ((r & kRepToken) ? 1u : 0xFFFFFFFFu);
 }
 
-// (Measured and dropped: the three FSE tables of a block staged in LDS, 15 blocks per workgroup.  The chain of one sequence
-//  is "state -> cell -> bits -> next state" AND the 16-byte window of the bitstream, which still comes from memory: level-3
-//  DNA went from 16.2 to 18.2 ms.  It would take the bitstream in LDS as well.)
+// (Measured and dropped, twice: the three FSE tables of a block staged in LDS, 15 blocks per workgroup -- level-3 DNA went
+//  from 16.2 to 18.2 ms, because the 16-byte window of the bitstream still came from memory; then the bitstream too, through a
+//  256-byte ring per block fed by loads issued a chunk ahead: 16.4 -> 19.0 ms.  With one wave per CU nothing hides the
+//  ~250 dependent instructions of a sequence; the version below runs every block of the section at once and waits on L2.)
 __global__ __launch_bounds__(64) void k_seq_decode(const uint8_t *__restrict__ src, const SeqBlock *__restrict__ blocks,
                                                    uint32_t n_blocks, const SeqCell *__restrict__ cells, Seq *seqs,
                                                    uint32_t *blk_size, uint32_t *rep_final, uint32_t *status) {

@@ -306,6 +306,14 @@ def main():
         t_gen = time.perf_counter() - t0
         opts.shard_rank, opts.shard_count = rank, world
         rc = lib.c.nafgpu_open_path(shared_path.encode(), ctypes.byref(opts), ctypes.byref(h), ctypes.byref(err))
+        # every rank has the file mapped now (or has failed): the name can go -- the pages stay for as long as the
+        # mappings do, and nothing is left behind in /dev/shm (which is memory) if a later step raises
+        flag = torch.tensor([1 if rc == 0 else 0], dtype=torch.int64, device=tdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if rank == 0 and os.path.exists(shared_path):
+            os.unlink(shared_path)
+        if int(flag.item()) == 0 and rc == 0:
+            raise RuntimeError("another rank could not open the shared archive")
     if rc != 0:
         raise RuntimeError("open failed: %s" % err.message.decode())
     t0 = time.perf_counter()

@@ -394,22 +394,26 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
                           d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(), d_seq_blocks_.as<SeqBlock>(),
                           d_seqs_.as<Seq>(), d_dicts_.bytes(), ascii, t_char_, status);
     };
-    bool have_direct = false, have_lit = false;
-    for (const HufClass &c : classes_) (c.to_lit ? have_lit : have_direct) = true;
-    if (have_direct || have_lit) {
+    // The classes are independent of each other.  The one with the most tasks goes to `stream`, the others to `aux`
+    // beside it: a class of a few tasks (the tail of a section; streams bound for the literal buffer) takes a whole
+    // task's time -- 2.5 ms on one CU for 64 streams -- which back to back was a fifth of a real-genome decode, and
+    // two large classes share the chip instead of each ending in a half-empty tail.  K4 waits for both.
+    if (!classes_.empty()) {
         if (timer) timer->begin(stream, StageTimer::kHuf);
+        size_t big = 0;
+        for (size_t c = 1; c < classes_.size(); c++)
+            if (classes_[c].n_tasks > classes_[big].n_tasks) big = c;
         bool forked = false;
-        if (have_direct && have_lit && aux) {
+        if (classes_.size() > 1 && aux) {
             if (!ev_fork_) (void)hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming);
             if (!ev_join_) (void)hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming);
             forked = ev_fork_ && ev_join_ && hip_ok(hipEventRecord(ev_fork_, stream)) && hip_ok(hipStreamWaitEvent(aux, ev_fork_, 0));
         }
         if (forked) {
-            for (const HufClass &c : classes_)
-                if (c.to_lit) launch_class(c, aux);
+            for (size_t c = 0; c < classes_.size(); c++)
+                if (c != big) launch_class(classes_[c], aux);
             (void)hipEventRecord(ev_join_, aux);
-            for (const HufClass &c : classes_)
-                if (!c.to_lit) launch_class(c, stream);
+            launch_class(classes_[big], stream);
             (void)hipStreamWaitEvent(stream, ev_join_, 0);
         } else {
             for (const HufClass &c : classes_) launch_class(c, stream);

@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--cpu-sample-bases", type=float, default=0,
                     help="size of the CPU-baseline sample (0 = auto, about 15 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--real-copies", type=int, default=2000,
+    ap.add_argument("--real-copies", type=int, default=3000,
                     help="N=1 only: also time an archive shaped like a real genome (the reference's NZ_AAEN01000029 fixture tiled "
                          "this many times, libzstd level 1) and report it as path.real_genome; 0 skips it")
     ap.add_argument("--no-verify", action="store_true")

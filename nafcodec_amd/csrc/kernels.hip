@@ -845,7 +845,12 @@ __global__ __launch_bounds__(64) void k_seq_decode(const uint8_t *__restrict__ s
         __device__ uint32_t read(uint32_t nb) {          // nb <= 31; the window holds the bits [pos - nb, pos)
             pos -= nb;
             const uint32_t a = static_cast<uint32_t>(pos - base) & 127u;   // bit index of the field's lowest bit inside the window
-            const uint64_t v = a >= 64 ? hi >> (a - 64) : ((lo >> a) | (a ? hi << (64 - a) : 0ull));
+            // branch-free (the lanes of a wave stand at 64 different bit positions: every branch is taken both ways, and
+            // with one wave per SIMD nothing hides the instructions of either side)
+            const bool up = a >= 64;
+            const uint64_t x = up ? hi : lo, y = up ? 0ull : hi;
+            const uint32_t t = a & 63u;
+            const uint64_t v = (x >> t) | ((y << 1) << (63u - t));
             return static_cast<uint32_t>(v) & ((1u << nb) - 1u);
         }
     };

@@ -282,6 +282,24 @@ def test_device_string_tables_and_utf8_flags(lib):
         assert Decoder(io.BytesIO(bad), **({})).decode_all_device().utf8_invalid == 1 << bit, (section, payload)
     good = nw.write_naf(recs, raw_sections={"comments": "é\u20ac\U0001F600\x00y\x00".encode()})
     assert Decoder(io.BytesIO(good), **({})).decode_all_device().utf8_invalid == 0
+    # sections longer than the 16-byte chunks of k_utf8_check: multi-byte characters across chunk borders, one byte
+    # overwritten at every position around them -- the verdict must be Python's
+    rng = np.random.default_rng(9)
+    text = "".join(rng.choice(list("abcdefghij é\u20ac\U0001F600z"), 150))
+    base = b"x\x00" + text.encode() + b"\x00"
+    for pos in list(range(10, 70)) + [len(base) - 2]:
+        for byte in (0x80, 0xC3, 0xE2, 0xF0, 0xFF, 0x41):
+            payload = bytearray(base)
+            payload[pos] = byte
+            try:
+                bytes(payload).decode("utf-8")
+                want = 0
+            except UnicodeDecodeError:
+                want = 2
+            if payload.count(0) != 2:
+                continue
+            arc = nw.write_naf(recs, raw_sections={"comments": bytes(payload)})
+            assert Decoder(io.BytesIO(arc)).decode_all_device().utf8_invalid == want, (pos, hex(byte))
 
 
 def test_encoder_output_decodes_on_the_gpu(lib):

@@ -450,8 +450,9 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
         const uint64_t sec_known = sec_known_, sec_seqs = sec_seqs_;                            // (the whole section's figures: every tile decides alike)
         const uint64_t match_elems = expect_ > sec_known ? expect_ - sec_known : 0;             // known_out = everything but the match bytes
         const char *force = std::getenv("NAFGPU_LZ_MODE");                                      // tests: "dense" / "sparse"
-        bool dense = sec_seqs >= 4096 && match_elems * 2 >= expect_;                      // (level-3 DNA, a quarter of it matches at random
-                                                                                                   //  distances, is faster match by match: 38 against 46 ms)
+        bool dense = sec_seqs >= 4096 && match_elems * 5 >= expect_;                      // (a fifth: level-3 DNA, a quarter of it matches at random
+                                                                                                   //  distances, 16.3 ms swept against 17.5 match by match -- before
+                                                                                                   //  the sweeps carried the values in D it was the other way round)
         if (force) dense = force[0] == 'd';
         lz_dense_ = false;
         if (dense && d_pj_dist_.alloc_items(la.n_elems, sizeof(uint32_t), 64) && d_pj_tiles_.alloc_items(lz_pj_tiles(la.n_elems), sizeof(uint32_t), 64)) {

@@ -619,7 +619,9 @@ Failure ArchiveJob::decode() {
             launch_scan_runs_u8(st, job_[kMask].out(), mask_cap_, d_mask_ends_.as<uint64_t>(), mask_cap_, d_scan_tmp_.bytes(),
                                 &totals[1], status);
     };
-    if (aux_stream_ && job_[kSequence].ready()) {
+    // (with a Mask section the run table is tens of megabytes: its scan beside the sequence decode slows K1 down by more
+    //  than the scan takes alone -- 12.8 against 11.95 + 0.5 ms -- so then the scans wait until the sequence is done)
+    if (aux_stream_ && job_[kSequence].ready() && !want_mask) {
         if (!ev_fork_) (void)hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming);
         if (!ev_join_) (void)hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming);
         scans_forked = ev_fork_ && ev_join_ && hip_ok(hipEventRecord(ev_fork_, stream_)) &&

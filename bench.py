@@ -288,8 +288,15 @@ def main():
         dist.all_gather_into_tensor(sizes, mine)
         sizes = [int(x) for x in sizes.cpu()]
         head = lib.synth_head(total_bases, sum(sizes), seed=0x4E4146, with_mask=args.mask, iupac_permille=args.iupac)
-        shared_path = "/dev/shm/nafgpu_bench_%s.naf" % os.environ.get("MASTER_PORT", "0")
         archive_bytes = head.n + sum(sizes)
+        # /dev/shm when it has room for the archive (rank 0 looks, everybody follows), else the temporary directory
+        import shutil
+        import tempfile
+        where = torch.tensor([1 if rank == 0 and shutil.disk_usage("/dev/shm").free > 1.05 * archive_bytes else 0],
+                             dtype=torch.int64, device=tdev)
+        dist.broadcast(where, src=0)
+        shared_path = os.path.join("/dev/shm" if int(where.item()) else tempfile.gettempdir(),
+                                   "nafgpu_bench_%s.naf" % os.environ.get("MASTER_PORT", "0"))
         if rank == 0:
             with open(shared_path, "wb") as f:
                 f.truncate(archive_bytes)

@@ -450,9 +450,11 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
         const uint64_t sec_known = sec_known_, sec_seqs = sec_seqs_;                            // (the whole section's figures: every tile decides alike)
         const uint64_t match_elems = expect_ > sec_known ? expect_ - sec_known : 0;             // known_out = everything but the match bytes
         const char *force = std::getenv("NAFGPU_LZ_MODE");                                      // tests: "dense" / "sparse"
-        bool dense = sec_seqs >= 4096 && match_elems * 5 >= expect_;                      // (a fifth: level-3 DNA, a quarter of it matches at random
-                                                                                                   //  distances, 16.3 ms swept against 17.5 match by match -- before
-                                                                                                   //  the sweeps carried the values in D it was the other way round)
+        // Swept: matches are a fifth of the output or more (level-3 DNA, a quarter of it matches at random distances: 16.3 ms
+        // swept against 17.5 match by match) and there is enough of them to pay for the sweeps -- many sequences, or a
+        // megabyte of match bytes in a few long ones (the Length section of equal-length reads is one block-long run per
+        // block, each copying from the block before: a chain no fixed number of passes gets through).
+        bool dense = (sec_seqs >= 4096 || match_elems >= (1u << 20)) && match_elems * 5 >= expect_;
         if (force) dense = force[0] == 'd';
         lz_dense_ = false;
         if (dense && d_pj_dist_.alloc_items(la.n_elems, sizeof(uint32_t), 64) && d_pj_tiles_.alloc_items(lz_pj_tiles(la.n_elems), sizeof(uint32_t), 64)) {

@@ -2011,7 +2011,11 @@ __global__ __launch_bounds__(256) void k_pj_fill(const SeqBlock *__restrict__ bl
                     else
                         hi = mid;
                 }
-                D[s_pos[lo] + (e - pre[lo])] = s_off[lo];
+                // element k of a match at distance off copies element k - off; where the match reaches into itself
+                // (off < ml: a run) that is an element of the same match, and so on down to the `off` elements in front of
+                // it -- point there at once instead of leaving k / off hops to the sweeps
+                const uint32_t k = e - pre[lo], off = s_off[lo];
+                D[s_pos[lo] + k] = k < off ? off : off * (k / off + 1u);
             }
             __syncthreads();
         }

@@ -1955,6 +1955,7 @@ __global__ __launch_bounds__(1024) void k_lz_finish_small(uint64_t *l0, uint64_t
 // whoever finds its source final has the value in the same look-up, whenever that source was written.
 constexpr uint32_t kPjTile = 2048;           // elements per tile (256 threads x 8)
 constexpr uint32_t kPjFinal = 0xFFFF0000u;   // D >= kPjFinal: final, and the low 16 bits ARE the element (byte / two characters)
+constexpr uint32_t kPjShort = 16;            // k_pj_fill: matches up to this long are filled by the thread that looked at them
 constexpr uint32_t kPjLocal = 4;             // jumps inside the tile (LDS) before a sweep looks into memory
 constexpr uint32_t kPjSweeps = 40;           // 2^40 > any chain; what is left after them goes to the frame-order walk
 
@@ -1965,11 +1966,15 @@ __global__ __launch_bounds__(256) void k_pj_fill(const SeqBlock *__restrict__ bl
     __shared__ uint64_t s_pos[256];
     __shared__ uint32_t s_off[256];
     __shared__ uint32_t s_pre[2][257];                     // element-count prefix sums (ping-pong for the scan)
-    __shared__ uint32_t s_abort;
+    __shared__ uint32_t s_abort, s_long[2];                // s_long[round & 1]: some match of the round is long
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) s_abort = status[0];
+    if (tid == 0) {
+        s_abort = status[0];
+        s_long[0] = s_long[1] = 0;
+    }
     __syncthreads();
     if (s_abort) return;
+    uint32_t round = 0;
     for (uint32_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
         const SeqBlock sb = blocks[b];
         const uint64_t obase = blk_base[sb.blk], fstart = blk_base[sb.frame_first_blk];
@@ -1983,6 +1988,8 @@ __global__ __launch_bounds__(256) void k_pj_fill(const SeqBlock *__restrict__ bl
                 const uint64_t mpos = obase + q.opos + q.ll;
                 if (bad || off > mpos - fstart || off >= kPjFinal) {   // reaches before the frame (corrupt) / beyond any legal window
                     flag_error(status, kStBadOffset, sb.blk);
+                } else if (q.ml <= kPjShort) {              // a short match (the usual kind in quality strings): its own thread
+                    for (uint32_t k = 0; k < q.ml; k++) D[mpos + k] = k < off ? off : off * (k / off + 1u);
                 } else {
                     ml = q.ml;
                     s_pos[tid] = mpos;
@@ -1991,8 +1998,15 @@ __global__ __launch_bounds__(256) void k_pj_fill(const SeqBlock *__restrict__ bl
             }
             __syncthreads();                               // previous round's readers are done (first round: nothing to wait for)
             s_pre[0][tid + 1] = ml;
-            if (tid == 0) s_pre[0][0] = s_pre[1][0] = 0;
+            if (ml) s_long[round & 1u] = 1;
+            if (tid == 0) {
+                s_pre[0][0] = s_pre[1][0] = 0;
+                s_long[(round + 1u) & 1u] = 0;             // (the next round's flag: nobody reads or sets it before the next barrier)
+            }
             __syncthreads();
+            const bool any_long = s_long[round & 1u] != 0;
+            round++;
+            if (!any_long) continue;                       // (uniform) short matches only: nothing left to do for this round
             uint32_t cur = 0;
             for (uint32_t d = 1; d < 256; d <<= 1) {       // inclusive scan of entries 1..256
                 const uint32_t v = s_pre[cur][tid + 1] + (tid >= d ? s_pre[cur][tid + 1 - d] : 0);

@@ -52,3 +52,19 @@ def test_bench_contract(world):
     else:
         assert "ONE archive" in j["config"]["sharding"]      # configs[4]: block ranges of one archive, not one archive per rank
     assert "passed" in j["config"]["workload"]  # the full-size checksum check ran and held on every rank
+
+
+def test_real_genome_leg_runs_and_checks_itself():
+    """bench.py's second workload (path.real_genome): the reference's NZ_AAEN01000029 fixture tiled and recompressed by
+    libzstd, decoded by the library it is given (here the CPU harness), compared with the tiled fixture."""
+    import zstd_ref
+    if not zstd_ref.available():
+        pytest.skip("libzstd not loadable")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "nafcodec_amd", "csrc"), "emu"],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    sys.path.insert(0, ROOT)
+    import bench
+    from nafcodec_amd import _ffi
+    leg = bench.real_genome_leg(_ffi.Library(os.path.join(ROOT, "tests", "emu", "_build", "libnafgpu_emu.so")), 0, 1)
+    assert leg["bases"] == 5488676 and "bit-exact check passed" in leg["workload"]
+    assert set(leg["roofline"]) >= {"bound", "achieved", "peak", "frac", "algorithmic_bytes_per_step"}

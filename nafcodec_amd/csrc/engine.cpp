@@ -460,6 +460,14 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
         if (dense && d_pj_dist_.alloc_items(la.n_elems, sizeof(uint32_t), 64) && d_pj_tiles_.alloc_items(lz_pj_tiles(la.n_elems), sizeof(uint32_t), 64)) {
             la.pj_dist = d_pj_dist_.as<uint32_t>();
             la.pj_tiles = d_pj_tiles_.as<uint32_t>();
+            // the late sweeps work from lists of what is pending (a third of the elements at most); without memory for
+            // them the sweeps simply go on over all of D
+            la.pj_list_cap = la.n_elems / 3 + 4096;
+            if (la.n_elems < (1ull << 32) && d_pj_list_[0].alloc_items(la.pj_list_cap, sizeof(uint32_t), 64) &&
+                d_pj_list_[1].alloc_items(la.pj_list_cap, sizeof(uint32_t), 64)) {
+                la.pj_list[0] = d_pj_list_[0].as<uint32_t>();
+                la.pj_list[1] = d_pj_list_[1].as<uint32_t>();
+            }
             lz_dense_ = true;
         } else {
             // the pending lists are an accelerator: without memory for them every pass walks the blocks

@@ -164,6 +164,7 @@ private:
     std::vector<XxhSeg> xxh_segs_;                // frame checksums: the (pieces of) checksummed frames in the loaded tile
     bool xxh_live_ = false;                       // ... and whether the frame the next tile continues was begun in this process's range
     DevBuf d_xxh_segs_, d_xxh_carry_;
+    DevBuf d_pj_list_[2];                          // dense LZ sections: lists of pending elements for the late sweeps (optional)
     DevBuf d_pj_dist_, d_pj_tiles_;               // dense LZ sections: one word per output element + one per tile (allocated on first use, kept)
     bool lz_dense_ = false;
     DevBuf d_streams_, d_tasks_, d_tbl_copies_, d_pool_, d_dicts_, d_copies_, d_seq_blocks_, d_cells_;

@@ -103,6 +103,8 @@ struct LzArgs {
     uint64_t *plist[2];          // sparse: two lists of pending matches (n_sequences entries each; null: block-wise passes only)
     uint32_t *pj_dist;           // dense: D, one word per output element (n_elems, 16-byte aligned)
     uint32_t *pj_tiles;          // dense: pending elements per tile of 2048 (lz_pj_tiles(n_elems) words)
+    uint32_t *pj_list[2];        // dense, optional: two lists of pending element indices, pj_list_cap entries each (k_pj_list)
+    uint64_t pj_list_cap;
     unsigned long long *counters;// 8 words: [0] matches still pending (sparse), [1] matches left to the one-workgroup stage, [4..6] stage counters
     uint8_t *out;
     uint32_t t_char;

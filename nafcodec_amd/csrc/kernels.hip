@@ -2036,21 +2036,60 @@ __global__ __launch_bounds__(256) void k_pj_fill(const SeqBlock *__restrict__ bl
     }
 }
 
+// Once fewer than a third of the elements are pending, a sweep over all of D mostly reads words that are final.  The first
+// sweep that starts below that mark also LISTS what it leaves pending (indices, 32 bits: sections of 2^32 elements or more
+// keep sweeping), and from then on k_pj_list takes over: it walks the list, writes the survivors to a second list, and so
+// on -- a pass costs what is pending, not what there is.  Both kernels are enqueued for every sweep number; `lstate[3]`
+// (0: sweeping; s: listing since sweep s) tells each whether it is its turn.  lstate[s % 3] = entries listed by sweep s.
+// Survivors are gathered in LDS and handed to the list 2 048 at a time: one addition to the list's length per batch.
+constexpr uint32_t kPjBatch = 2048;
+template <uint32_t N>
+struct PjLister {                                          // (LDS state of one workgroup)
+    uint32_t buf[N];
+    uint32_t n, base;
+};
+// hands the gathered entries to the list when there are `limit` of them or more (limit 1: whatever there is)
+template <uint32_t N>
+__device__ inline void pj_list_flush(PjLister<N> *L, uint32_t *list_out, unsigned long long *len, uint64_t cap, uint32_t limit) {
+    // called by every thread of the workgroup with uniform arguments, at a point where L->n is stable
+    __syncthreads();
+    const uint32_t n = L->n;
+    if (n >= limit && n) {
+        if (threadIdx.x == 0) L->base = static_cast<uint32_t>(atomicAdd(len, static_cast<unsigned long long>(n)));
+        __syncthreads();
+        const uint64_t base = L->base;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+            if (base + i < cap) list_out[base + i] = L->buf[i];
+        __syncthreads();
+        if (threadIdx.x == 0) L->n = 0;
+    }
+    __syncthreads();
+}
+
 template <bool ASCII>
-__global__ __launch_bounds__(256) void k_pj_sweep(uint32_t *D, uint8_t *out_bytes, uint32_t *tile_pending, unsigned long long *pcount,
-                                                  uint64_t n_elems, uint32_t sweep, uint32_t max_dist, const uint32_t *status) {
+__global__ __launch_bounds__(256, 6) void k_pj_sweep(uint32_t *D, uint8_t *out_bytes, uint32_t *tile_pending, unsigned long long *pcount,
+                                                  uint64_t n_elems, uint32_t sweep, uint32_t max_dist, uint32_t *list_out,
+                                                  uint64_t list_cap, unsigned long long *lstate, const uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
     __shared__ uint32_t s_cnt[3];                          // pending elements of the tile, three counters in rotation
     __shared__ uint32_t s_D[kPjTile];                      // the tile's words: the first few jumps of a sweep stay inside the tile
+    __shared__ PjLister<kPjBatch> s_list;                  // (a tile's survivors at most: flushed before a tile that would not fit)
     const uint32_t tid = threadIdx.x;
     // pcount[s % 3] = elements still pending after sweep s (pcount[0] != 0 before the first one)
     const unsigned long long before = pcount[(sweep + 2u) % 3u];
+    const unsigned long long listing = lstate[3];
+    if (listing != 0 && listing < sweep) return;           // k_pj_list's turn (it keeps the counters from here on)
+    // (listing == sweep: workgroup 0 of THIS launch has set it already.  Sweep 1 starts from a placeholder count.)
+    const bool build = list_out != nullptr && sweep >= 2 && before != 0 && before * 3 < n_elems && before <= list_cap && status[0] == 0;
     if (blockIdx.x == 0 && tid == 0) {
         pcount[(sweep + 1u) % 3u] = 0;
+        lstate[(sweep + 1u) % 3u] = 0;
         if (before == 0 || status[0] != 0) pcount[sweep % 3u] = 0;
+        if (build) lstate[3] = sweep;                      // (read by the kernels launched after this one)
     }
     if (before == 0 || status[0] != 0) return;
+    if (tid == 0) s_list.n = 0;
     if (tid < 3) s_cnt[tid] = 0;
     __syncthreads();
     const uint64_t n_tiles = (n_elems + kPjTile - 1) / kPjTile;
@@ -2136,7 +2175,7 @@ __global__ __launch_bounds__(256) void k_pj_sweep(uint32_t *D, uint8_t *out_byte
                 const bool pending = v[half][k] != 0 && v[half][k] < kPjFinal;
                 if (pending && w[half][k] == 0) e[half][k] = out[p[half] + k - v[half][k]];
             }
-        uint32_t remaining = 0;
+        uint32_t remaining = 0, survivors = 0;
 #pragma unroll
         for (uint32_t half = 0; half < 2; half++) {
             bool changed = v[half][0] != v0[half][0] || v[half][1] != v0[half][1] || v[half][2] != v0[half][2] || v[half][3] != v0[half][3];
@@ -2157,6 +2196,7 @@ __global__ __launch_bounds__(256) void k_pj_sweep(uint32_t *D, uint8_t *out_byte
                         changed = true;
                     }
                     remaining++;
+                    survivors |= 1u << (4 * half + k);
                 }
             }
             // the thread's four words go back as one store (nobody else writes them; readers take the old or the new value)
@@ -2176,10 +2216,75 @@ __global__ __launch_bounds__(256) void k_pj_sweep(uint32_t *D, uint8_t *out_byte
             wg_pending += c;
             s_cnt[(flip + 2u) % 3u] = 0;                   // (the counter of the tile after next: nobody adds to it before the next barrier)
         }
+        if (build) {                                       // (uniform) the tile's survivors join the list
+            const uint32_t c = s_cnt[flip];                // (stable: thread 0 reset the OTHER counters only)
+            pj_list_flush(&s_list, list_out, &lstate[sweep % 3u], list_cap, s_list.n + c > kPjBatch ? 1u : kPjBatch);
+            if (remaining) {
+                uint32_t slot = atomicAdd(&s_list.n, remaining);
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++)
+                    if (survivors & (1u << j)) s_list.buf[slot++] = static_cast<uint32_t>(p[j >> 2] + (j & 3u));
+            }
+        }
         flip = (flip + 1u) % 3u;
     }
+    if (build) pj_list_flush(&s_list, list_out, &lstate[sweep % 3u], list_cap, 1u);
     // (one addition per workgroup, not per tile: 700 k additions to one word serialise)
     if (tid == 0 && wg_pending) atomicAdd(&pcount[sweep % 3u], wg_pending);
+}
+
+// A pass over the list of pending elements (see above): sweep `sweep` reads what sweep - 1 listed and lists what it leaves.
+template <bool ASCII>
+__global__ __launch_bounds__(256) void k_pj_list(uint32_t *D, const uint8_t *out_bytes, unsigned long long *pcount, const uint32_t *list_in,
+                                                 uint32_t *list_out, uint64_t list_cap, unsigned long long *lstate, uint32_t sweep,
+                                                 uint32_t max_dist, const uint32_t *status) {
+    using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
+    const Elem *out = reinterpret_cast<const Elem *>(out_bytes);
+    __shared__ PjLister<kPjBatch + 256> s_list;
+    const uint32_t tid = threadIdx.x;
+    const unsigned long long listing = lstate[3];
+    if (listing == 0 || sweep <= listing) return;          // still sweeping / the sweep that made the first list
+    const unsigned long long before = pcount[(sweep + 2u) % 3u];
+    unsigned long long n_in = lstate[(sweep + 2u) % 3u];
+    if (n_in > list_cap) n_in = list_cap;
+    if (blockIdx.x == 0 && tid == 0) {
+        pcount[(sweep + 1u) % 3u] = 0;
+        lstate[(sweep + 1u) % 3u] = 0;
+        if (before == 0 || status[0] != 0) pcount[sweep % 3u] = 0;
+    }
+    if (before == 0 || status[0] != 0) return;
+    if (tid == 0) s_list.n = 0;
+    __syncthreads();
+    unsigned long long mine = 0;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256;
+    const uint64_t rounds = (n_in + stride - 1) / stride;                        // (uniform: every thread takes part in every flush)
+    for (uint64_t r = 0; r < rounds; r++) {
+        const uint64_t i = r * stride + static_cast<uint64_t>(blockIdx.x) * 256 + tid;
+        if (i < n_in) {
+            const uint32_t p = list_in[i];
+            const uint32_t v = D[p];
+            if (v != 0 && v < kPjFinal) {
+                const uint32_t ws = D[p - v];
+                if (ws == 0 || ws >= kPjFinal) {
+                    const Elem el = ws == 0 ? out[p - v] : static_cast<Elem>(ws & 0xFFFFu);
+                    D[p] = kPjFinal | el;
+                } else {
+                    if (static_cast<uint64_t>(v) + ws < max_dist) D[p] = v + ws;
+                    mine++;
+                    s_list.buf[atomicAdd(&s_list.n, 1u)] = p;                    // (at most 256 a round on top of < 2 048)
+                }
+            }
+        }
+        pj_list_flush(&s_list, list_out, &lstate[sweep % 3u], list_cap, kPjBatch);
+    }
+    pj_list_flush(&s_list, list_out, &lstate[sweep % 3u], list_cap, 1u);
+    // pending after this pass, one addition per workgroup
+    __shared__ unsigned long long s_sum;
+    if (tid == 0) s_sum = 0;
+    __syncthreads();
+    if (mine) atomicAdd(&s_sum, mine);
+    __syncthreads();
+    if (tid == 0 && s_sum) atomicAdd(&pcount[sweep % 3u], s_sum);
 }
 
 // After the sweeps: every element that a sweep made final goes from its word of D to the output (the sweeps themselves
@@ -2808,9 +2913,20 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
         uint64_t tiles = (a.n_elems + kPjTile - 1) / kPjTile;
         if (tiles > 256u * 16u) tiles = 256u * 16u;
         unsigned long long *pcount = a.counters + 4;       // [4..6]: pending elements, rotating (k_pj_sweep)
-        for (uint32_t sweep = 1; sweep <= kPjSweeps; sweep++)
+        unsigned long long *lstate = a.counters + 10;      // [10..12]: lengths of the pending lists, rotating; [13]: listing since sweep ...
+        (void)hipMemsetAsync(lstate, 0, 4 * sizeof(unsigned long long), stream);
+        uint32_t *lists[2] = {a.pj_list[0], a.pj_list[1]};
+        const bool can_list = lists[0] && lists[1] && a.n_elems < (1ull << 32);
+        uint64_t lg = (a.pj_list_cap / 8 + 255) / 256;     // (a list is at most pj_list_cap long: eight entries per thread and round at that size)
+        const uint32_t list_grid = static_cast<uint32_t>(lg < 1 ? 1 : (lg > 256u * 8u ? 256u * 8u : lg));
+        for (uint32_t sweep = 1; sweep <= kPjSweeps; sweep++) {
             hipLaunchKernelGGL(k_pj_sweep<ASCII>, dim3(static_cast<uint32_t>(tiles)), dim3(256), 0, stream, a.pj_dist, a.out,
-                               a.pj_tiles, pcount, a.n_elems, sweep, max_dist, a.status);
+                               a.pj_tiles, pcount, a.n_elems, sweep, max_dist, can_list ? lists[sweep & 1u] : nullptr, a.pj_list_cap,
+                               lstate, a.status);
+            if (can_list && sweep >= 2)
+                hipLaunchKernelGGL(k_pj_list<ASCII>, dim3(list_grid), dim3(256), 0, stream, a.pj_dist, a.out, pcount,
+                                   lists[(sweep & 1u) ^ 1u], lists[sweep & 1u], a.pj_list_cap, lstate, sweep, max_dist, a.status);
+        }
         {
             uint64_t eg = (a.n_elems / 4 + 255) / 256;
             if (eg > 256u * 16u) eg = 256u * 16u;

@@ -24,11 +24,14 @@ for level in (1, 3):
     blob = bytearray([1, 0xF9, 0xEC, 1, 0x0B, 0x20]) + nw.varint(L) + nw.varint(n_reads)
     for _, orig, payload in secs:
         blob += nw.varint(orig) + nw.varint(len(payload)) + payload
-    dec = nafcodec_amd.Decoder(io.BytesIO(bytes(blob)))
-    res = dec.decode_all_device(); res = dec.decode_all_device()
-    lib = _ffi.default()
-    okq = dec.hash_device(res.d_quality, res.n_quality) == lib.c.nafgpu_hash64_host(qual, len(qual))
-    print("level", level, "reads", n_reads, "bases", n_bases, "archive MB %.1f" % (len(blob) / 1e6), "compress s %.1f" % tc,
-          "qual ok", okq, "records", res.n_records,
-          "ms total %.2f huf %.2f seq_lz %.2f other %.2f" % (res.ms_total, res.ms_huf, res.ms_seq_lz, res.ms_other),
-          "Gbases/s %.1f" % (n_bases / res.ms_total / 1e6), flush=True)
+    # NAFGPU_PROBE_LIBS: comma-separated experiment builds timed on the same archive after the product
+    for path in [None] + [x for x in os.environ.get("NAFGPU_PROBE_LIBS", "").split(",") if x]:
+        lib = _ffi.default() if path is None else _ffi.Library(os.path.join(R, path))
+        dec = nafcodec_amd.Decoder(io.BytesIO(bytes(blob)), _lib=lib)
+        res = dec.decode_all_device(); res = dec.decode_all_device()
+        okq = dec.hash_device(res.d_quality, res.n_quality) == lib.c.nafgpu_hash64_host(qual, len(qual))
+        print("level", level, "product" if path is None else path, "reads", n_reads, "bases", n_bases, "archive MB %.1f" % (len(blob) / 1e6),
+              "compress s %.1f" % tc, "qual ok", okq, "records", res.n_records,
+              "ms total %.2f huf %.2f seq_lz %.2f other %.2f" % (res.ms_total, res.ms_huf, res.ms_seq_lz, res.ms_other),
+              "Gbases/s %.1f" % (n_bases / res.ms_total / 1e6), flush=True)
+        dec.close()

@@ -813,11 +813,19 @@ __device__ inline uint32_t rep_minus_one(uint32_t r) {      // rep - 1 for a con
 //  from 16.2 to 18.2 ms, because the 16-byte window of the bitstream still came from memory; then the bitstream too, through a
 //  256-byte ring per block fed by loads issued a chunk ahead: 16.4 -> 19.0 ms.  With one wave per CU nothing hides the
 //  ~250 dependent instructions of a sequence; the version below runs every block of the section at once and waits on L2.)
+// Blocks per wave.  Every sequence ends in four loads per lane and the wave goes on when the slowest of them is back: with
+// 32 lanes instead of 64 that maximum is taken over half as many (FASTQ-like, 10 M reads: 52.7 -> 50.7 ms; 16 / 24 / 48
+// lanes: 53.3 / 49.2 / 49.9 at level 1, 110 / 110 / 104 at level 3 -- 32 and 48 are good at both).
+#ifndef NAFGPU_SEQ_LANES
+#define NAFGPU_SEQ_LANES 32
+#endif
+constexpr uint32_t kSeqLanes = NAFGPU_SEQ_LANES;
 __global__ __launch_bounds__(64) void k_seq_decode(const uint8_t *__restrict__ src, const SeqBlock *__restrict__ blocks,
                                                    uint32_t n_blocks, const SeqCell *__restrict__ cells, Seq *seqs,
                                                    uint32_t *blk_size, uint32_t *rep_final, uint32_t *status) {
     if (status[0] != 0) return;
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x >= kSeqLanes) return;
+    const uint32_t b = blockIdx.x * kSeqLanes + threadIdx.x;
     if (b >= n_blocks) return;
     const SeqBlock sb = blocks[b];
     const uint8_t *bits = src + sb.bits_off;
@@ -2766,7 +2774,7 @@ __global__ __launch_bounds__(256) void k_hash64(const uint8_t *__restrict__ p, u
 void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *blocks, uint32_t n_blocks,
                        const SeqCell *cells, Seq *seqs, uint32_t *blk_size, uint32_t *rep_final, uint32_t *status) {
     if (!n_blocks) return;
-    hipLaunchKernelGGL(k_seq_decode, dim3((n_blocks + 63) / 64), dim3(64), 0, stream, src, blocks, n_blocks, cells, seqs,
+    hipLaunchKernelGGL(k_seq_decode, dim3((n_blocks + kSeqLanes - 1) / kSeqLanes), dim3(64), 0, stream, src, blocks, n_blocks, cells, seqs,
                        blk_size, rep_final, status);
 }
 

@@ -813,19 +813,17 @@ __device__ inline uint32_t rep_minus_one(uint32_t r) {      // rep - 1 for a con
 //  from 16.2 to 18.2 ms, because the 16-byte window of the bitstream still came from memory; then the bitstream too, through a
 //  256-byte ring per block fed by loads issued a chunk ahead: 16.4 -> 19.0 ms.  With one wave per CU nothing hides the
 //  ~250 dependent instructions of a sequence; the version below runs every block of the section at once and waits on L2.)
-// Blocks per wave.  Every sequence ends in four loads per lane and the wave goes on when the slowest of them is back: with
-// 32 lanes instead of 64 that maximum is taken over half as many (FASTQ-like, 10 M reads: 52.7 -> 50.7 ms; 16 / 24 / 48
-// lanes: 53.3 / 49.2 / 49.9 at level 1, 110 / 110 / 104 at level 3 -- 32 and 48 are good at both).
-#ifndef NAFGPU_SEQ_LANES
-#define NAFGPU_SEQ_LANES 32
-#endif
-constexpr uint32_t kSeqLanes = NAFGPU_SEQ_LANES;
+// `lanes` = blocks per wave.  Every sequence ends in four loads per lane and the wave goes on when the slowest of them is
+// back: with fewer lanes in a wave each block runs closer to the mean latency than to the maximum.  Measured (ms per decode,
+// lanes = 4 / 8 / 16 / 32 / 64): level-3 DNA, 3 906 blocks: 17.0 / 14.8 / 13.5 / 14.0 / 15.4; FASTQ-like level 1, 11.5 k
+// blocks in the quality section: - / 58.7 / 53.3 / 50.5 / 52.7 -- very thin waves lose again (more waves than the memory
+// system likes).  The launcher aims at about one wave per CU and never goes below 16 lanes.
 __global__ __launch_bounds__(64) void k_seq_decode(const uint8_t *__restrict__ src, const SeqBlock *__restrict__ blocks,
                                                    uint32_t n_blocks, const SeqCell *__restrict__ cells, Seq *seqs,
-                                                   uint32_t *blk_size, uint32_t *rep_final, uint32_t *status) {
+                                                   uint32_t *blk_size, uint32_t *rep_final, uint32_t lanes, uint32_t *status) {
     if (status[0] != 0) return;
-    if (threadIdx.x >= kSeqLanes) return;
-    const uint32_t b = blockIdx.x * kSeqLanes + threadIdx.x;
+    if (threadIdx.x >= lanes) return;
+    const uint32_t b = blockIdx.x * lanes + threadIdx.x;
     if (b >= n_blocks) return;
     const SeqBlock sb = blocks[b];
     const uint8_t *bits = src + sb.bits_off;
@@ -2774,8 +2772,15 @@ __global__ __launch_bounds__(256) void k_hash64(const uint8_t *__restrict__ p, u
 void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *blocks, uint32_t n_blocks,
                        const SeqCell *cells, Seq *seqs, uint32_t *blk_size, uint32_t *rep_final, uint32_t *status) {
     if (!n_blocks) return;
-    hipLaunchKernelGGL(k_seq_decode, dim3((n_blocks + kSeqLanes - 1) / kSeqLanes), dim3(64), 0, stream, src, blocks, n_blocks, cells, seqs,
-                       blk_size, rep_final, status);
+    static const uint32_t forced = [] {                   // NAFGPU_K2_LANES: measurements only
+        const char *e = std::getenv("NAFGPU_K2_LANES");
+        return e ? static_cast<uint32_t>(std::atoi(e)) : 0u;
+    }();
+    uint32_t lanes = forced ? forced : (n_blocks + 359u) / 360u;     // about one wave per CU ...
+    lanes = forced ? lanes : (lanes < 16 ? 16 : lanes);              // ... of at least 16 lanes (measured: see above)
+    lanes = lanes < 1 ? 1 : (lanes > 64 ? 64 : lanes);
+    hipLaunchKernelGGL(k_seq_decode, dim3((n_blocks + lanes - 1) / lanes), dim3(64), 0, stream, src, blocks, n_blocks, cells, seqs,
+                       blk_size, rep_final, lanes, status);
 }
 
 size_t scan_tmp_bytes(uint64_t n) { return static_cast<size_t>((n + kScanTile - 1) / kScanTile + 1) * sizeof(TileAgg); }

@@ -245,7 +245,7 @@ def main():
     from nafcodec_amd import _ffi
     # raises if libnafgpu.so is missing: no CPU fallback.  Nothing in the environment may redirect the
     # measured path: the product library is the in-tree nafcodec_amd/libnafgpu.so, without debug switches.
-    for var in ("NAFGPU_LIB", "NAFGPU_PJ_MAX_DIST", "NAFGPU_LZ_MODE", "NAFGPU_TILE_KIB", "NAFGPU_PROBE_LIBS"):
+    for var in ("NAFGPU_LIB", "NAFGPU_PJ_MAX_DIST", "NAFGPU_LZ_MODE", "NAFGPU_TILE_KIB", "NAFGPU_K2_LANES", "NAFGPU_PROBE_LIBS"):
         if os.environ.get(var):
             raise SystemExit("bench.py: %s is set; refusing to print a headline from a redirected or ablated build" % var)
     lib = _ffi.Library(args.rehearsal_lib) if args.rehearsal_lib else _ffi.default()

@@ -267,7 +267,8 @@ void nafgpu_synth_free(nafgpu_synth_archive *a);
 /* ---- Encoder (EncoderBuilder / Encoder, encoder/mod.rs:46-384, writer.rs) ----------------
  * Host code: the reference's encoder is CPU code too, and the decode path above is what runs on the GPU.  Same
  * surface and checks as the reference; every section is written as one magicless Zstandard frame of 128 KiB
- * Huffman-literal blocks (no LZ matching: `compression_level` is accepted and ignored), which the reference's
+ * blocks -- Huffman / RLE / raw literals, and at `compression_level` 0 (the default level) or >= 3 greedy hash
+ * matches coded as sequences with the predefined FSE tables (levels 1-2: literals only) -- which the reference's
  * decoder, libzstd and this library all read.  Sections are kept in memory until the archive is written (the
  * reference's `Memory` storage, storage.rs).  Like the reference's encoder it never writes a Mask section and
  * accepts upper-case IUPAC letters only. */
@@ -275,7 +276,7 @@ typedef struct {
     uint8_t sequence_type;       /* 0 dna, 1 rna, 2 protein, 3 text (EncoderBuilder::new, mod.rs:81-90) */
     uint8_t id, comment, sequence, quality;   /* opt-in fields (mod.rs:112-145); all 0 by default */
     uint8_t reserved[3];
-    int32_t compression_level;   /* mod.rs:147-157; ignored (see above) */
+    int32_t compression_level;   /* mod.rs:147-157; 0 or >= 3: with LZ matches, 1-2: literals only (see above) */
     uint32_t threads;            /* blocks are encoded in parallel when the archive is written; 0 = hardware concurrency */
 } nafgpu_encoder_opts;
 typedef struct nafgpu_encoder nafgpu_encoder;

@@ -678,12 +678,285 @@ extern "C" void nafgpu_synth_free(nafgpu_synth_archive *a) {
 }
 
 // ======================================================================================
+// Blocks with LZ sequences (the Encoder at compression levels >= 3)
+// ======================================================================================
+namespace {
+
+// Literals_Section (RFC 8878 3.1.1.3.1) of `n` bytes: Huffman with four streams (new tree, or the previous block's), RLE, or raw.
+// *used_new: the section carries a new tree (the caller makes it the previous one if the block is emitted).
+void literals_section(const uint8_t *data, size_t n, const HufCode *prev, HufCode *cur, bool *used_new, std::vector<uint8_t> &out) {
+    *used_new = false;
+    auto raw = [&]() {
+        if (n < 32) {
+            out.push_back(static_cast<uint8_t>(n << 3));
+        } else if (n < 4096) {
+            const uint32_t v = (static_cast<uint32_t>(n) << 4) | (1u << 2);
+            out.push_back(v & 0xFF);
+            out.push_back(v >> 8);
+        } else {
+            const uint32_t v = (static_cast<uint32_t>(n) << 4) | (3u << 2);
+            out.push_back(v & 0xFF);
+            out.push_back((v >> 8) & 0xFF);
+            out.push_back(v >> 16);
+        }
+        out.insert(out.end(), data, data + n);
+    };
+    if (n < 256) return raw();
+    uint32_t count[256] = {0};
+    for (size_t i = 0; i < n; i++) count[data[i]]++;
+    if (count[data[0]] == n) {                                   // RLE literals
+        const uint32_t v = (static_cast<uint32_t>(n) << 4) | (3u << 2) | 1u;
+        out.push_back(v & 0xFF);
+        out.push_back((v >> 8) & 0xFF);
+        out.push_back(v >> 16);
+        out.push_back(data[0]);
+        return;
+    }
+    std::vector<uint8_t> tree;
+    bool have_new = build_lengths(count, cur->len);
+    if (have_new) {
+        assign_codes(cur);
+        have_new = cur->valid && write_weights(cur->weight, cur->max_sym, tree);
+    }
+    uint64_t cost_new = UINT64_MAX, cost_old = UINT64_MAX;
+    if (have_new) {
+        cost_new = tree.size() * 8;
+        for (int k = 0; k < 256; k++) cost_new += static_cast<uint64_t>(count[k]) * cur->len[k];
+    }
+    if (prev->valid) {
+        cost_old = 0;
+        for (int k = 0; k < 256; k++) {
+            if (!count[k]) continue;
+            if (!prev->len[k]) {
+                cost_old = UINT64_MAX;
+                break;
+            }
+            cost_old += static_cast<uint64_t>(count[k]) * prev->len[k];
+        }
+    }
+    if (cost_new == UINT64_MAX && cost_old == UINT64_MAX) return raw();
+    const bool treeless = cost_old <= cost_new;
+    const HufCode &h = treeless ? *prev : *cur;
+    std::vector<uint8_t> body;
+    if (!treeless) body = tree;
+    const size_t q = (n + 3) / 4;
+    std::vector<uint8_t> st[4];
+    encode_stream(h, data, q, st[0]);
+    encode_stream(h, data + q, q, st[1]);
+    encode_stream(h, data + 2 * q, q, st[2]);
+    encode_stream(h, data + 3 * q, n - 3 * q, st[3]);
+    for (int k = 0; k < 3; k++) {
+        if (st[k].size() > 0xFFFF) return raw();
+        body.push_back(st[k].size() & 0xFF);
+        body.push_back(static_cast<uint8_t>(st[k].size() >> 8));
+    }
+    for (int k = 0; k < 4; k++) body.insert(body.end(), st[k].begin(), st[k].end());
+    const size_t comp = body.size();
+    if (comp >= n) return raw();
+    const uint32_t type = treeless ? 3u : 2u;
+    if (n <= 1023 && comp <= 1023) {
+        const uint32_t v = type | (1u << 2) | (static_cast<uint32_t>(n) << 4) | (static_cast<uint32_t>(comp) << 14);
+        for (int k = 0; k < 3; k++) out.push_back((v >> (8 * k)) & 0xFF);
+    } else if (n <= 16383 && comp <= 16383) {
+        const uint32_t v = type | (2u << 2) | (static_cast<uint32_t>(n) << 4) | (static_cast<uint32_t>(comp) << 18);
+        for (int k = 0; k < 4; k++) out.push_back((v >> (8 * k)) & 0xFF);
+    } else {
+        const uint64_t v = type | (3u << 2) | (static_cast<uint64_t>(n) << 4) | (static_cast<uint64_t>(comp) << 22);
+        for (int k = 0; k < 5; k++) out.push_back((v >> (8 * k)) & 0xFF);
+    }
+    out.insert(out.end(), body.begin(), body.end());
+    *used_new = !treeless;
+}
+
+// The predefined FSE tables of the sequence codes (RFC 8878 3.1.1.3.2.2), as the DECODER builds them; encoding walks them
+// backwards: to encode symbol s in front of decoder state `next`, take the state of s whose range [base, base + 2^nb) holds `next`.
+struct SeqTable {
+    int al = 0, n_states = 0;
+    uint8_t sym[64], nb[64];
+    uint16_t base[64];
+};
+const int16_t kEncLL[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+const int16_t kEncML[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                            1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+const int16_t kEncOF[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+const uint32_t kEncLLBase[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512,
+                                 1024, 2048, 4096, 8192, 16384, 32768, 65536};
+const uint8_t kEncLLBits[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+const uint32_t kEncMLBase[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32,
+                                 33, 34, 35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539};
+const uint8_t kEncMLBits[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+
+void seq_table_build(const int16_t *norm, int nsym, int al, SeqTable *t) {
+    const int S = 1 << al;
+    uint16_t next[64];
+    int high = S - 1;
+    t->al = al;
+    t->n_states = S;
+    for (int k = 0; k < nsym; k++) {
+        if (norm[k] == -1) {
+            t->sym[high--] = static_cast<uint8_t>(k);
+            next[k] = 1;
+        } else {
+            next[k] = static_cast<uint16_t>(norm[k]);
+        }
+    }
+    const int step = (S >> 1) + (S >> 3) + 3, mask = S - 1;
+    int pos = 0;
+    for (int k = 0; k < nsym; k++)
+        for (int c = 0; c < norm[k]; c++) {
+            t->sym[pos] = static_cast<uint8_t>(k);
+            do pos = (pos + step) & mask;
+            while (pos > high);
+        }
+    for (int i = 0; i < S; i++) {
+        const uint16_t d = next[t->sym[i]]++;
+        const int nb = al - highbit(d);
+        t->nb[i] = static_cast<uint8_t>(nb);
+        t->base[i] = static_cast<uint16_t>((d << nb) - S);
+    }
+}
+// the state of symbol `s` that leads to decoder state `next` (next < 0: any state of s)
+int seq_state_for(const SeqTable &t, int s, int next) {
+    for (int i = 0; i < t.n_states; i++)
+        if (t.sym[i] == s && (next < 0 || (next >= t.base[i] && next < t.base[i] + (1 << t.nb[i])))) return i;
+    return -1;
+}
+
+struct LzSeq {
+    uint32_t ll, ml, off;                                        // literal run, match length (>= 3), distance (>= 1)
+};
+
+int ll_code(uint32_t ll) {
+    for (int c = 35; c >= 0; c--)
+        if (ll >= kEncLLBase[c]) return c;
+    return 0;
+}
+int ml_code(uint32_t ml) {
+    for (int c = 52; c >= 0; c--)
+        if (ml >= kEncMLBase[c]) return c;
+    return 0;
+}
+
+// Sequences_Section with the three predefined tables: header, then the backward bitstream
+void sequences_section(const std::vector<LzSeq> &seqs, std::vector<uint8_t> &out) {
+    static const SeqTable *tabs = [] {
+        static SeqTable t[3];
+        seq_table_build(kEncLL, 36, 6, &t[0]);
+        seq_table_build(kEncOF, 29, 5, &t[1]);
+        seq_table_build(kEncML, 53, 6, &t[2]);
+        return t;
+    }();
+    const SeqTable &TL = tabs[0], &TO = tabs[1], &TM = tabs[2];
+    const size_t n = seqs.size();
+    if (n < 128) {
+        out.push_back(static_cast<uint8_t>(n));
+    } else if (n < 0x7F00) {
+        out.push_back(static_cast<uint8_t>((n >> 8) + 128));
+        out.push_back(static_cast<uint8_t>(n & 0xFF));
+    } else {
+        out.push_back(255);
+        out.push_back(static_cast<uint8_t>((n - 0x7F00) & 0xFF));
+        out.push_back(static_cast<uint8_t>((n - 0x7F00) >> 8));
+    }
+    if (n == 0) return;
+    out.push_back(0x00);                                         // Symbol_Compression_Modes: predefined x 3
+    // What the decoder reads, first to last: initial states LL, OF, ML; then per sequence the extra bits OF, ML, LL and -- except
+    // after the last one -- the state updates LL, ML, OF.  It reads from the end of the stream, so the fields are written last to first.
+    BitSink bits;
+    int s_ll = -1, s_of = -1, s_ml = -1;                         // decoder states of sequence i + 1
+    for (size_t i = n; i-- > 0;) {
+        const LzSeq &q = seqs[i];
+        const uint32_t ofv = q.off + 3;                          // Offset_Value: always a new offset (no repeat codes)
+        const int cl = ll_code(q.ll), cm = ml_code(q.ml), co = highbit(ofv);
+        const int t_ll = seq_state_for(TL, cl, s_ll), t_of = seq_state_for(TO, co, s_of), t_ml = seq_state_for(TM, cm, s_ml);
+        if (i + 1 < n) {                                         // the updates that lead from this sequence's states to the next one's
+            bits.put(static_cast<uint32_t>(s_of - TO.base[t_of]), TO.nb[t_of]);
+            bits.put(static_cast<uint32_t>(s_ml - TM.base[t_ml]), TM.nb[t_ml]);
+            bits.put(static_cast<uint32_t>(s_ll - TL.base[t_ll]), TL.nb[t_ll]);
+        }
+        bits.put(q.ll - kEncLLBase[cl], kEncLLBits[cl]);
+        bits.put(q.ml - kEncMLBase[cm], kEncMLBits[cm]);
+        if (co > 24) {                                           // (BitSink takes at most 32 bits at a time safely)
+            bits.put((ofv - (1u << co)) & 0xFFFFu, 16);
+            bits.put((ofv - (1u << co)) >> 16, co - 16);
+        } else {
+            bits.put(ofv - (1u << co), co);
+        }
+        s_ll = t_ll;
+        s_of = t_of;
+        s_ml = t_ml;
+    }
+    bits.put(static_cast<uint32_t>(s_ml), TM.al);
+    bits.put(static_cast<uint32_t>(s_of), TO.al);
+    bits.put(static_cast<uint32_t>(s_ll), TL.al);
+    bits.put(1, 1);                                              // end mark
+    bits.flush();
+    out.insert(out.end(), bits.bytes.begin(), bits.bytes.end());
+}
+
+constexpr uint32_t kLzHashBits = 17, kLzMinMatch = 6, kLzWindow = 1u << 20;
+// One block of [data + b0, data + b0 + n) with greedy hash matching against everything since `chunk0` (and at most the window).
+void encode_block_lz(const uint8_t *data, size_t chunk0, size_t b0, size_t n, bool last, HufCode *prev, std::vector<uint32_t> &head,
+                     std::vector<uint8_t> &out) {
+    std::vector<LzSeq> seqs;
+    std::vector<uint8_t> lits;
+    lits.reserve(n);
+    auto hash = [&](size_t p) {
+        uint32_t v;
+        std::memcpy(&v, data + p, 4);
+        return (v * 2654435761u) >> (32 - kLzHashBits);
+    };
+    const size_t end = b0 + n;
+    size_t p = b0, lit0 = b0;
+    while (p + kLzMinMatch <= end) {
+        const uint32_t hsh = hash(p);
+        const uint32_t cand = head[hsh];                         // position + 1 of an earlier occurrence in this chunk (0: none)
+        head[hsh] = static_cast<uint32_t>(p - chunk0 + 1);
+        size_t len = 0, from = 0;
+        if (cand) {
+            from = chunk0 + cand - 1;
+            if (p - from <= kLzWindow - kBlockMax) {
+                while (p + len < end && data[from + len] == data[p + len]) len++;
+            }
+        }
+        if (len >= kLzMinMatch) {
+            seqs.push_back(LzSeq{static_cast<uint32_t>(p - lit0), static_cast<uint32_t>(len), static_cast<uint32_t>(p - from)});
+            lits.insert(lits.end(), data + lit0, data + p);
+            for (size_t k = 1; k < len && p + k + 4 <= end; k += 3) head[hash(p + k)] = static_cast<uint32_t>(p + k - chunk0 + 1);
+            p += len;
+            lit0 = p;
+        } else {
+            p++;
+        }
+    }
+    lits.insert(lits.end(), data + lit0, data + end);            // literals behind the last match
+    if (seqs.empty()) return encode_block(data + b0, n, last, prev, out);
+    std::vector<uint8_t> body;
+    HufCode cur{};
+    bool used_new = false;
+    literals_section(lits.data(), lits.size(), prev, &cur, &used_new, body);
+    sequences_section(seqs, body);
+    if (body.size() >= n || body.size() > kBlockMax) {           // not worth it: without sequences (which may still be Huffman or raw)
+        return encode_block(data + b0, n, last, prev, out);
+    }
+    const uint32_t bh = static_cast<uint32_t>(body.size() << 3) | (2u << 1) | (last ? 1u : 0u);
+    out.push_back(bh & 0xFF);
+    out.push_back((bh >> 8) & 0xFF);
+    out.push_back((bh >> 16) & 0xFF);
+    out.insert(out.end(), body.begin(), body.end());
+    if (used_new) *prev = cur;
+}
+
+}  // namespace
+
+// ======================================================================================
 // Encoder (EncoderBuilder / Encoder / SequenceWriter: encoder/mod.rs:46-384, writer.rs:6-100)
 // ======================================================================================
 namespace {
 
 // one section -> one magicless frame of 128 KiB Huffman-literal blocks; chunks of kChunkBlocks blocks in parallel
-void compress_section(const std::vector<uint8_t> &data, unsigned n_threads, std::vector<uint8_t> &out) {
+void compress_section(const std::vector<uint8_t> &data, unsigned n_threads, bool lz, std::vector<uint8_t> &out) {
     if (data.size() < 64) {                       // nothing to gain: raw blocks (an empty section is one empty last block)
         raw_frame(data, out);
         return;
@@ -697,9 +970,15 @@ void compress_section(const std::vector<uint8_t> &data, unsigned n_threads, std:
             const uint64_t c = next.fetch_add(1);
             if (c >= n_chunks) break;
             HufCode prev{};
+            std::vector<uint32_t> head;                       // (LZ) hash heads: matches are looked for inside the chunk
+            if (lz) head.assign(size_t(1) << kLzHashBits, 0);
+            const size_t chunk0 = static_cast<size_t>(c * kChunkBlocks * kBlockMax);
             for (uint64_t b = c * kChunkBlocks; b < std::min(n_blocks, (c + 1) * kChunkBlocks); b++) {
-                const size_t p0 = static_cast<size_t>(b * kBlockMax);
-                encode_block(data.data() + p0, std::min<size_t>(kBlockMax, data.size() - p0), b == n_blocks - 1, &prev, chunk_out[c]);
+                const size_t p0 = static_cast<size_t>(b * kBlockMax), bn = std::min<size_t>(kBlockMax, data.size() - p0);
+                if (lz)
+                    encode_block_lz(data.data(), chunk0, p0, bn, b == n_blocks - 1, &prev, head, chunk_out[c]);
+                else
+                    encode_block(data.data() + p0, bn, b == n_blocks - 1, &prev, chunk_out[c]);
             }
         }
     };
@@ -710,7 +989,7 @@ void compress_section(const std::vector<uint8_t> &data, unsigned n_threads, std:
     worker();
     for (auto &t : pool) t.join();
     out.push_back(0x00);   // FHD: no content size, no checksum, no dictionary
-    out.push_back(0x48);   // window 512 KiB (no block refers back)
+    out.push_back(lz ? 0x50 : 0x48);   // window 1 MiB when blocks refer back (kLzWindow), else 512 KiB
     for (auto &c : chunk_out) out.insert(out.end(), c.begin(), c.end());
 }
 
@@ -881,7 +1160,7 @@ extern "C" int nafgpu_encoder_finish(nafgpu_encoder *e, const uint8_t **bytes, u
         put_varint(o, e->n_records);
         auto block = [&](const std::vector<uint8_t> &data, uint64_t original) {      // write_block!, mod.rs:349-367
             std::vector<uint8_t> frame;
-            compress_section(data, e->opt.threads, frame);
+            compress_section(data, e->opt.threads, e->opt.compression_level == 0 || e->opt.compression_level >= 3, frame);
             put_varint(o, original);
             put_varint(o, frame.size());
             o.insert(o.end(), frame.begin(), frame.end());

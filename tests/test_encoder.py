@@ -21,7 +21,7 @@ R2 = dict(id="r2", comment="record 2", sequence="NTAATAAGCAATGACGGCAGC", quality
 
 def encode(records, sequence_type="dna", **fields):
     buf = io.BytesIO()
-    with Encoder(buf, sequence_type, **fields) as enc:
+    with Encoder(buf, sequence_type, **fields) as enc:      # (compression_level 0 = the default level: blocks with LZ sequences)
         for r in records:
             enc.write(Record(**r))
     return buf.getvalue()
@@ -87,6 +87,33 @@ def test_checks_of_push():
     enc.write(Record(id="c", sequence="TTA", quality="#II", length=3))
     enc.close()
     assert decoded(buf.getvalue()) == [("a", None, "ACGT", "IIII", 4), ("c", None, "TTA", "#II", 3)]
+
+
+@pytest.mark.skipif(not zstd_ref.available(), reason="libzstd not loadable")
+def test_levels_with_and_without_lz_sequences():
+    """compression_level 1-2: entropy-coded literals only; 0 (default) and >= 3: greedy matches, sequences coded with the
+    predefined FSE tables.  Repetitive records must come out much smaller with matches -- and identical either way."""
+    rng = np.random.default_rng(3)
+    motif = cases.rand_dna(rng, 5000)
+    recs = []
+    for i in range(12):
+        seq = motif * (3 + i % 5) + cases.rand_dna(rng, 1000 * i) + "N" * (700 * (i % 3))
+        recs.append(dict(id="read%d" % i, comment="the same comment over and over %d" % (i % 7), sequence=seq,
+                         quality=("IIIIIHHHGG#" * (len(seq) // 11 + 1))[:len(seq)]))
+    want = [(r["id"], r["comment"], r["sequence"], r["quality"], len(r["sequence"])) for r in recs]
+    sizes = {}
+    for level in (1, 3, 19, 0):
+        blob = encode(recs, id=True, comment=True, sequence=True, quality=True, compression_level=level)
+        assert decoded(blob) == want, level
+        d = oracle.Decoder(blob)
+        for sec in range(6):
+            try:
+                data, orig, comp, off = d.section(sec)
+            except Exception:
+                continue
+            assert zstd_ref.decompress_magicless(blob[off:off + comp], len(data) + 8) == data, (level, sec)
+        sizes[level] = len(blob)
+    assert sizes[3] == sizes[19] == sizes[0] and sizes[3] * 4 < sizes[1], sizes
 
 
 @pytest.mark.skipif(not zstd_ref.available(), reason="libzstd not loadable")

@@ -313,11 +313,12 @@ def test_encoder_output_decodes_on_the_gpu(lib):
             recs.append(nafcodec_amd.Record(id="rec%d" % i, comment="comment %d é" % i if i % 3 else "",
                                             sequence=cases.rand_dna(rng, n, alphabet, iupac), quality="I" * n if i % 2 else
                                             "".join(rng.choice(list("#8CGGGGGG<AFFJJ"), n))))
-        buf = io.BytesIO()
-        with nafcodec_amd.Encoder(buf, st, id=True, comment=True, sequence=True, quality=True) as enc:
-            for r in recs:
-                enc.write(r)
-        got = list(nafcodec_amd.Decoder(io.BytesIO(buf.getvalue())))
-        assert len(got) == len(recs)
-        for a, b in zip(got, recs):
-            assert (a.id, a.comment, a.sequence, a.quality, a.length) == (b.id, b.comment, b.sequence, b.quality, len(b.sequence)), (st, b.id)
+        for level in ((1, 3) if st == "dna" else (0,)):       # 1: literals only; 0 / 3: blocks with LZ sequences (predefined FSE tables)
+            buf = io.BytesIO()
+            with nafcodec_amd.Encoder(buf, st, id=True, comment=True, sequence=True, quality=True, compression_level=level) as enc:
+                for r in recs:
+                    enc.write(r)
+            got = list(nafcodec_amd.Decoder(io.BytesIO(buf.getvalue())))
+            assert len(got) == len(recs)
+            for a, b in zip(got, recs):
+                assert (a.id, a.comment, a.sequence, a.quality, a.length) == (b.id, b.comment, b.sequence, b.quality, len(b.sequence)), (st, level, b.id)

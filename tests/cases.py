@@ -252,6 +252,16 @@ def fuzz_cases(seed=1, n=120):
     seeds.append(nw.write_naf([{"id": "q", "sequence": dense}], sequence_type="text", level=3))
     # three 128 KiB blocks with their own deep Huffman trees: compact decode tables with escape sub-tables
     seeds.append(nw.write_naf(make_records(rng, [700000, 151], iupac=0.05), level=1))
+    # an archive of this repository's own Encoder: sequences coded with the PREDEFINED FSE tables, fresh offsets only
+    import io as _io
+    from nafcodec_amd import Encoder, Record
+    buf = _io.BytesIO()
+    motif = rand_dna(rng, 700)
+    with Encoder(buf, "dna", id=True, comment=True, sequence=True, quality=True) as enc:
+        for i in range(9):
+            seq = motif * (2 + i % 3) + rand_dna(rng, 300 * i)
+            enc.write(Record(id="e%d" % i, comment="c", sequence=seq, quality=("IIHHG#" * len(seq))[:len(seq)]))
+    seeds.append(buf.getvalue())
     out = []
     for it in range(n):
         blob = bytearray(seeds[it % len(seeds)])

@@ -46,6 +46,9 @@ def parse_args():
                     help="N=1 only: also time an archive shaped like a real genome (the reference's NZ_AAEN01000029 fixture tiled "
                          "this many times, libzstd level 1) and report it as path.real_genome; 0 skips it")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--rehearsal-one-gpu", action="store_true",
+                    help="tests only: several ranks (gloo) share GPU 0 -- the sharded flow with the real library on a one-GPU box; "
+                         "the line printed carries no metric and no value")
     ap.add_argument("--rehearsal-lib", default="",
                     help="tests only: run the control flow against another build of the library (the CPU harness); "
                          "the line printed then carries no metric and no value")
@@ -254,7 +257,7 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        if torch.cuda.is_available():
+        if torch.cuda.is_available() and not args.rehearsal_one_gpu:
             torch.cuda.set_device(local_rank)
             tdev = "cuda"
             dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
@@ -442,6 +445,8 @@ def main():
             line["cpu_baseline"], checked = cpu_baseline(lib, args.cpu_sample_bases, args.mask, device)
             line["config"]["oracle_checked_bases"] = checked
             line["config"]["workload"] += "; GPU decode of a %d-base archive of the same generator equals the CPU oracle's output" % checked
+        if args.rehearsal_one_gpu:
+            line.update({"metric": "REHEARSAL: %d ranks on one GPU -- not a measurement" % world, "value": None, "roofline": None})
         if args.rehearsal_lib:                   # control-flow rehearsal on the CPU harness: never a measurement
             line.update({"metric": "REHEARSAL on %s -- not a measurement" % os.path.basename(args.rehearsal_lib),
                          "value": None, "roofline": None})

@@ -68,3 +68,22 @@ def test_real_genome_leg_runs_and_checks_itself():
     leg = bench.real_genome_leg(_ffi.Library(os.path.join(ROOT, "tests", "emu", "_build", "libnafgpu_emu.so")), 0, 1)
     assert leg["bases"] == 5488676 and "bit-exact check passed" in leg["workload"]
     assert set(leg["roofline"]) >= {"bound", "achieved", "peak", "frac", "algorithmic_bytes_per_step"}
+
+
+@pytest.mark.gpu
+def test_three_ranks_share_the_one_gpu():
+    """The sharded bench flow with the REAL library: three processes (gloo for the exchange) write one 6-Gbase archive in parts,
+    each opens it with its shard_rank, decodes its block range on GPU 0, and the summed shard checksums must equal the
+    writers'.  (RCCL itself needs one GPU per rank: the driver's multi-GPU run is where that is exercised.)"""
+    world = 3
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+           "--bases", "2e9", "--no-cpu", "--rehearsal-one-gpu"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["metric"].startswith("REHEARSAL") and j["value"] is None and j["n_gpus"] == world
+    assert "ONE archive" in j["config"]["sharding"] and "passed" in j["config"]["workload"]

@@ -42,6 +42,15 @@ if stats:
         if "k_huf_decode" in r["Name"]:
             avg_ms = float(r["AverageNs"]) / 1e6
             break
+# the timed launches alone (the stats file's average also counts the warm-up launches): last `steps` launches of the kernel trace
+timed_avg = None
+trace = first(os.path.join(G, "%s_headline" % tag, "**", "*kernel_trace.csv"))
+if trace:
+    rows = [r for r in csv.DictReader(open(trace)) if "k_huf_decode" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows][-5:]
+    if d:
+        timed_avg = sum(d) / len(d)
 bench_line = None
 log = os.path.join(G, "%s_headline.log" % tag)
 if os.path.exists(log):
@@ -57,6 +66,7 @@ if fetch and write:
         "FETCH_SIZE_bytes": fetch["FETCH_SIZE"] * 1024 * 2, "WRITE_SIZE_bytes": write["WRITE_SIZE"] * 1024,
         "note": "FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB. K1 requests every input line whole (8 x dwordx4 per lane on one 128-byte line), so the guide's gfx950 correction applies: FETCH_SIZE x 2 (128-byte requests tallied at 64 B). WRITE_SIZE is exact for 16-byte-per-lane stores.",
         "rocprof_kernel_trace_avg_ms": avg_ms,
+        "rocprof_kernel_trace_avg_ms_timed_launches": timed_avg,
         "hip_events_ms_per_launch_same_run": bench_line and bench_line["roofline"]["ms_per_launch"],
         "sq": sq, "lds": lds,
     }

@@ -245,6 +245,14 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
 
+    dist = torch = None
+    if world > 1:
+        # PyTorch first: it brings its own copy of the HIP runtime, and a process that loads libnafgpu.so (linked against
+        # the system's) before it ends up with two runtimes, the second of which finds no device ("no ROCm-capable device is
+        # detected" -- seen with three ranks sharing one GPU, tests/test_bench_multirank.py).  Loaded first, torch's copy
+        # serves both.
+        import torch
+        import torch.distributed as dist
     from nafcodec_amd import _ffi
     # raises if libnafgpu.so is missing: no CPU fallback.  Nothing in the environment may redirect the
     # measured path: the product library is the in-tree nafcodec_amd/libnafgpu.so, without debug switches.
@@ -252,11 +260,8 @@ def main():
         if os.environ.get(var):
             raise SystemExit("bench.py: %s is set; refusing to print a headline from a redirected or ablated build" % var)
     lib = _ffi.Library(args.rehearsal_lib) if args.rehearsal_lib else _ffi.default()
-    dist = torch = None
     tdev = "cpu"
     if world > 1:
-        import torch
-        import torch.distributed as dist
         if torch.cuda.is_available() and not args.rehearsal_one_gpu:
             torch.cuda.set_device(local_rank)
             tdev = "cuda"

@@ -530,7 +530,8 @@ Failure ArchiveJob::init(int device) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (!hip_ok(e) || count <= 0)
-        return Failure::make(NAFGPU_E_DEVICE, "no HIP device available: libnafgpu decodes on the GPU only");
+        return Failure::make(NAFGPU_E_DEVICE, std::string("no HIP device available: libnafgpu decodes on the GPU only (hipGetDeviceCount: ") +
+                                                  hipGetErrorString(e) + ", " + std::to_string(count) + " devices)");
     if (device < 0) {
         if (!hip_ok(hipGetDevice(&device))) device = 0;
     }

@@ -87,3 +87,40 @@ def test_three_ranks_share_the_one_gpu():
     j = json.loads(lines[0])
     assert j["metric"].startswith("REHEARSAL") and j["value"] is None and j["n_gpus"] == world
     assert "ONE archive" in j["config"]["sharding"] and "passed" in j["config"]["workload"]
+
+
+RCCL_PROBE = r"""
+import os, sys, ctypes
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist                      # (before libnafgpu.so: see bench.py)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)        # "nccl" is RCCL on ROCm
+from nafcodec_amd import _ffi
+from nafcodec_amd.sharding import gather_placement
+lib = _ffi.default()
+arc = lib.synth(50_000_000, seed=3)
+opts = _ffi.Opts(); lib.c.nafgpu_opts_default(ctypes.byref(opts)); opts.device = 0
+h, err = ctypes.c_void_p(), _ffi.Error()
+assert lib.c.nafgpu_open_bytes(ctypes.cast(arc.bytes, ctypes.c_char_p), arc.n, ctypes.byref(opts), ctypes.byref(h), ctypes.byref(err)) == 0
+assert lib.c.nafgpu_upload(h) == 0
+res = _ffi.DeviceResult()
+scratch = (torch.zeros(4, dtype=torch.int64, device="cuda"), torch.zeros(4, dtype=torch.int64, device="cuda"))
+for _ in range(3):
+    assert lib.c.nafgpu_decode_all_device(h, ctypes.byref(res)) == 0
+    pl = gather_placement(dist, torch, res.n_bases, res.packed_bytes, res.first_record, res.carry, res.n_records, "cuda", scratch)
+dist.barrier(); torch.cuda.synchronize()
+t = torch.tensor([1.5], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+out = ctypes.c_uint64(); lib.c.nafgpu_hash64_device(h, res.d_sequence, res.n_bases, ctypes.byref(out))
+assert pl.total_bases == 50_000_000 and out.value == arc.seq_hash and float(t.item()) == 1.5
+print("rccl probe ok", flush=True)
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_and_the_library_share_a_process():
+    """What a rank of `bench.py --gpus N` does, with a world of one: RCCL's all-gather / all-reduce / barrier on device tensors
+    around decodes of the HIP library in the same process (PyTorch's HIP runtime and the library's must be one)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    p = subprocess.run([sys.executable, "-c", RCCL_PROBE % ROOT], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and "rccl probe ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]

@@ -366,9 +366,10 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
     (void)hipMemsetAsync(status, 0, 64, stream);
     if (n_seq_blocks_) {
         if (timer) timer->begin(stream, StageTimer::kSeqLz);
-        // blk_size of blocks with sequences is rewritten in full by k_seq_decode: re-runs are idempotent
+        // blk_size of blocks with sequences is rewritten in full by k_seq_values: re-runs are idempotent
         launch_seq_decode(stream, d_src_, d_seq_blocks_.as<SeqBlock>(), static_cast<uint32_t>(n_seq_blocks_),
-                          d_cells_.as<SeqCell>(), d_seqs_.as<Seq>(), d_blk_size_.as<uint32_t>(), d_rep_final_.as<uint32_t>(),
+                          d_cells_.as<SeqCell>(), d_seqs_.as<Seq>(), d_meta_.as<SeqMeta>(), d_blk_size_.as<uint32_t>(),
+                          d_rep_final_.as<uint32_t>(),
                           status);
         if (timer) timer->end(stream);
     }

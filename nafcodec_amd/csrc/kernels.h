@@ -17,7 +17,7 @@ struct ScanTotals {          // written by the scan kernels
 // K2: FSE sequence decode, one lane per block with sequences.  Adds match bytes to blk_size[].
 // rep_final: 3 u32 per block -- the repeat offsets the block ends with (concrete or kRepToken tokens)
 void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *blocks, uint32_t n_blocks,
-                       const SeqCell *cells, Seq *seqs, uint32_t *blk_size, uint32_t *rep_final, uint32_t *status);
+                       const SeqCell *cells, Seq *seqs, SeqMeta *meta, uint32_t *blk_size, uint32_t *rep_final, uint32_t *status);
 
 // K3: exclusive scan of u32 block sizes -> u64 bases (n+1 entries; the last is the total).
 // `tile_tmp` needs scan_tmp_bytes(n) bytes.  Flags status if the total differs from `expect_total`.
@@ -69,7 +69,7 @@ void launch_copy_fill(hipStream_t stream, const uint8_t *src, const CopyTask *ta
 // K1: Huffman literal streams, one lane per stream, one wave per task.  One launch per class (plan.h:
 // HufClass): `tasks` is the section's whole task list, cls names the run to launch, its table format,
 // destination and whether the segment-aware variant is needed (streams of blocks with a few sequences:
-// seq_blocks / seqs are then read, so k_seq_decode must have run).
+// seq_blocks / seqs are then read, so k_seq_values must have run).
 void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *tasks, const HufClass &cls,
                        const HufTblCopy *copies, const HufStream *streams, const uint16_t *pool,
                        const uint64_t *blk_base, uint8_t *out, uint8_t *lit, const SeqBlock *seq_blocks, const Seq *seqs,
@@ -89,7 +89,7 @@ struct LzArgs {
     const Seq *seqs;
     const uint8_t *lit;
     const uint64_t *blk_base;
-    const uint32_t *rep_final;   // 3 per block, from k_seq_decode
+    const uint32_t *rep_final;   // 3 per block, from k_seq_values
     uint32_t *rep_init;          // 3 per block
     uint32_t rep_carry[3];       // repeat offsets in front of the first block ({1, 4, 8} unless a tile in front left others)
     uint32_t rep_continues;      // 1: the first block continues a frame begun in front of this tile (no reset to {1, 4, 8})

@@ -2,7 +2,7 @@
 //
 // Everything here is integer / bit manipulation bound by HBM and LDS, not by MFMA:
 //   k_huf_decode   K1  Huffman literal streams (zstd literals section)        lane = stream
-//   k_seq_decode   K2  FSE sequence decode (LL / OF / ML)                     lane = block
+//   k_seq_states / k_seq_values   K2  FSE sequence decode (LL / OF / ML)   lane = block, then wave = block
 //   k_scan_*       K3/K6  tile scans: block bases, record ends, mask run ends
 //   k_copy_fill        Raw / RLE blocks and literal sections
 //   k_rep_partial/scan/apply, k_lz_literals, k_lz_index, k_lz_match_pass, k_lz_matches_ordered   K4
@@ -73,7 +73,7 @@ __device__ inline void flag_error(uint32_t *status, uint32_t code, uint32_t deta
 //   * a round is [flush what earlier rounds completed] -> [16 look-ups] -> [land the next piece].
 //   * SEG: streams of a block that has a few LZ sequences (plan.h: kDirectSeqMax) write their literals
 //     straight to their final positions: the stream's symbols are cut into segments by the block's
-//     decoded sequences (k_seq_decode ran before); at the end of a segment the lane drains its row
+//     decoded sequences (k_seq_values ran before); at the end of a segment the lane drains its row
 //     byte-wise, like at the end of a stream, and re-bases it at the next literal run.  The literal
 //     buffer round trip (K1 -> lit -> k_lz_literals -> out) disappears for those blocks.
 // DESIGN.md section 4 has the measurements behind each of these choices.
@@ -809,18 +809,77 @@ __device__ inline uint32_t rep_minus_one(uint32_t r) {      // rep - 1 for a con
     return r + ((r & kRepToken) ? 1u : 0xFFFFFFFFu);
 }
 
-// (Measured and dropped, twice: the three FSE tables of a block staged in LDS, 15 blocks per workgroup -- level-3 DNA went
-//  from 16.2 to 18.2 ms, because the 16-byte window of the bitstream still came from memory; then the bitstream too, through a
-//  256-byte ring per block fed by loads issued a chunk ahead: 16.4 -> 19.0 ms.  With one wave per CU nothing hides the
-//  ~250 dependent instructions of a sequence; the version below runs every block of the section at once and waits on L2.)
+// `tok` (an offset, or "incoming rep[slot] - d") applied after the map `f` (three entries of the same kind): maps compose
+__device__ inline uint32_t rep_apply_entry(uint32_t tok, const uint32_t *f, bool *bad) {
+    if (!(tok & kRepToken)) return tok;
+    const uint32_t fv = f[(tok >> 24) & 3u], d = tok & 0xFFFFFFu;
+    if (!(fv & kRepToken)) {
+        if (fv <= d) {
+            *bad = true;
+            return 1;
+        }
+        return fv - d;
+    }
+    const uint32_t d2 = (fv & 0xFFFFFFu) + d;
+    if (d2 > 0xFFFFFFu) *bad = true;
+    return (fv & 0xFF000000u) | (d2 & 0xFFFFFFu);
+}
+
+// K2 is two kernels.  The sequences of a block are a chain -- where the bits of sequence i+1 lie depends on the three FSE
+// states after sequence i -- but only the STATES and the bit cursor are: with those known for every sequence, the values
+// (literal length, match length, offset), the output positions and the repeat offsets are work for as many threads as
+// there are sequences.  So
+//   k_seq_states   lane = block walks the chain and does nothing else: three 4-byte cell reads, the 16-byte window, the
+//                  state bits in ONE field (LL, ML, OF state updates are adjacent in the stream: <= 26 bits), one 8-byte
+//                  record {cursor, states} per sequence.  (The first version did all of K2 in this loop: ~250 instructions
+//                  per sequence, and with one wave per SIMD every one of them is exposed -- 7.5 ms for level-3 DNA,
+//                  18-21 ms for the qualities of 10 M reads, the largest item of every LZ-heavy archive.)
+//   k_seq_values   wave = block, four consecutive sequences per lane: values from the records, running sums for the
+//                  positions, and the repeat-offset history as a scan of composable maps (rep_apply_entry) over the lanes.
+// (Measured and dropped in the one-kernel version, twice: the three FSE tables of a block staged in LDS, 15 blocks per
+//  workgroup -- level-3 DNA 16.2 -> 18.2 ms; then the bitstream too, through a 256-byte ring per block: 16.4 -> 19.0 ms.)
 // `lanes` = blocks per wave.  Every sequence ends in four loads per lane and the wave goes on when the slowest of them is
-// back: with fewer lanes in a wave each block runs closer to the mean latency than to the maximum.  Measured (ms per decode,
-// lanes = 4 / 8 / 16 / 32 / 64): level-3 DNA, 3 906 blocks: 17.0 / 14.8 / 13.5 / 14.0 / 15.4; FASTQ-like level 1, 11.5 k
-// blocks in the quality section: - / 58.7 / 53.3 / 50.5 / 52.7 -- very thin waves lose again (more waves than the memory
-// system likes).  The launcher aims at about one wave per CU and never goes below 16 lanes.
-__global__ __launch_bounds__(64) void k_seq_decode(const uint8_t *__restrict__ src, const SeqBlock *__restrict__ blocks,
-                                                   uint32_t n_blocks, const SeqCell *__restrict__ cells, Seq *seqs,
-                                                   uint32_t *blk_size, uint32_t *rep_final, uint32_t lanes, uint32_t *status) {
+// back: with fewer lanes in a wave each block runs closer to the mean latency than to the maximum.  The launcher aims at
+// about one wave per CU and never goes below 16 lanes.
+struct SeqRec {          // what k_seq_states leaves for k_seq_values
+    int32_t pos;         // unread bits below the cursor before this sequence's extra bits
+    uint32_t states;     // LL state | ML state << 9 | OF state << 18
+};
+static_assert(sizeof(SeqRec) == 8 && sizeof(SeqRec) <= sizeof(SeqMeta), "SeqRec layout (the records live in the SeqMeta buffer until k_lz_literals fills that)");
+
+// One 16-byte window of a backward bitstream: a sequence reads at most 31 + 16 + 16 extra bits and 9 + 9 + 8 state
+// bits = 89, the window ending at the byte that holds the cursor has > 120 unread bits, and its address depends on the
+// cursor alone -- so the window load and the three table look-ups of a sequence are issued together and the dependent
+// chain per sequence is ONE memory latency.  Bits below the stream's first bit are whatever precedes it in the archive
+// (readable: kSrcFrontPad); a stream that reaches them has pos < 0 and is flagged.
+struct SeqWindow {
+    const uint8_t *p;     // first byte of the bitstream
+    int32_t pos;          // unread bits below the cursor (negative: overrun)
+    uint64_t lo, hi;      // bytes [off, off + 16) of the stream, off = ceil(pos / 8) - 16
+    int32_t base;         // 8 * off
+    __device__ void load() {
+        const int32_t off = ((pos + 7) >> 3) - 16;
+        base = off * 8;
+        uint64_t w[2];
+        __builtin_memcpy(w, p + off, 16);
+        lo = w[0];
+        hi = w[1];
+    }
+    __device__ uint32_t read(uint32_t nb) {          // nb <= 31; the window holds the bits [pos - nb, pos)
+        pos -= nb;
+        const uint32_t a = static_cast<uint32_t>(pos - base) & 127u;   // bit index of the field's lowest bit inside the window
+        // branch-free (the lanes of a wave stand at 64 different bit positions: every branch is taken both ways)
+        const bool up = a >= 64;
+        const uint64_t x = up ? hi : lo, y = up ? 0ull : hi;
+        const uint32_t t = a & 63u;
+        const uint64_t v = (x >> t) | ((y << 1) << (63u - t));
+        return static_cast<uint32_t>(v) & ((1u << nb) - 1u);
+    }
+};
+
+__global__ __launch_bounds__(64) void k_seq_states(const uint8_t *__restrict__ src, const SeqBlock *__restrict__ blocks,
+                                                   uint32_t n_blocks, const SeqCell *__restrict__ cells, SeqRec *recs,
+                                                   uint32_t lanes, uint32_t *status) {
     if (status[0] != 0) return;
     if (threadIdx.x >= lanes) return;
     const uint32_t b = blockIdx.x * lanes + threadIdx.x;
@@ -828,105 +887,194 @@ __global__ __launch_bounds__(64) void k_seq_decode(const uint8_t *__restrict__ s
     const SeqBlock sb = blocks[b];
     const uint8_t *bits = src + sb.bits_off;
     const uint32_t lastb = bits[sb.bits_len - 1];   // host checked: non-zero
-    // One 16-byte window per sequence: a sequence reads at most 31 + 16 + 16 extra bits and 9 + 9 + 8 state
-    // bits = 89, the window ending at the byte that holds the cursor has > 120 unread bits, and its
-    // address depends on the cursor alone -- so the window load and the three table look-ups of a
-    // sequence are issued together and the dependent chain per sequence is ONE memory latency
-    // (six dependent loads per sequence made this kernel the longest one on FASTQ archives).
-    // Bits below the stream's first bit are whatever precedes it in the archive (readable: kSrcFrontPad);
-    // a stream that reaches them has pos < 0 and is flagged.
-    struct Window {
-        const uint8_t *p;     // first byte of the bitstream
-        int64_t pos;          // unread bits below the cursor (negative: overrun)
-        uint64_t lo, hi;      // bytes [off, off + 16) of the stream, off = ceil(pos / 8) - 16
-        int64_t base;         // 8 * off
-        __device__ void load() {
-            const int64_t off = ((pos + 7) >> 3) - 16;
-            base = off * 8;
-            uint64_t w[2];
-            __builtin_memcpy(w, p + off, 16);
-            lo = w[0];
-            hi = w[1];
-        }
-        __device__ uint32_t read(uint32_t nb) {          // nb <= 31; the window holds the bits [pos - nb, pos)
-            pos -= nb;
-            const uint32_t a = static_cast<uint32_t>(pos - base) & 127u;   // bit index of the field's lowest bit inside the window
-            // branch-free (the lanes of a wave stand at 64 different bit positions: every branch is taken both ways, and
-            // with one wave per SIMD nothing hides the instructions of either side)
-            const bool up = a >= 64;
-            const uint64_t x = up ? hi : lo, y = up ? 0ull : hi;
-            const uint32_t t = a & 63u;
-            const uint64_t v = (x >> t) | ((y << 1) << (63u - t));
-            return static_cast<uint32_t>(v) & ((1u << nb) - 1u);
-        }
-    };
-    Window r{bits, static_cast<int64_t>(sb.bits_len - 1) * 8 + (31 - __clz(static_cast<int>(lastb | 1u))), 0, 0, 0};
-    const SeqCell *tll = cells + sb.ll_tbl, *tof = cells + sb.of_tbl, *tml = cells + sb.ml_tbl;
+    SeqWindow r{bits, static_cast<int32_t>(sb.bits_len - 1) * 8 + (31 - __clz(static_cast<int>(lastb | 1u))), 0, 0, 0};
     r.load();
-    uint32_t sll = r.read(sb.ll_al), sof = r.read(sb.of_al), sml = r.read(sb.ml_al);
+    const uint32_t s0 = r.read(sb.ll_al), s1 = r.read(sb.of_al), s2 = r.read(sb.ml_al);
+    // the first dword of a cell: next_base | nb << 16 | extra_bits << 24 (read at 32-bit byte offsets from the pool's base)
+    const char *cb = reinterpret_cast<const char *>(cells);
+    const uint32_t bl = 8u * sb.ll_tbl, bo = 8u * sb.of_tbl, bm = 8u * sb.ml_tbl;
+    uint32_t sl = s0, so = s1, sm = s2;
+    int32_t pos = r.pos;
+    SeqRec *dst = recs + sb.seq_first;
+    const uint32_t n = sb.n_seq;
+    // (everything loaded so far is used here, so that no load is pending when the loop is entered: otherwise the loop's first
+    //  wait has to be vmcnt(0) on every trip, which also waits for the record store of the trip before)
+#ifndef NAFGPU_EMU
+    asm volatile("" ::"v"(bl), "v"(bo), "v"(bm), "v"(sl), "v"(so), "v"(sm), "v"(pos), "v"(n));
+#endif
+    // every sequence but the last: its record, its extra bits skipped, the three state updates (LL, ML, OF: one field)
+    for (uint32_t i = 0; i + 1 < n; i++) {
+        if (pos < 0) break;
+        // the 12 bytes that end with the cursor's byte: at most 63 extra bits and 26 state bits lie between the
+        // field's lowest bit and the cursor, so that bit is 0..96 bits above the window's first
+        const int32_t off = ((pos + 7) >> 3) - 12;
+        uint32_t w[3];
+        __builtin_memcpy(w, bits + off, 12);
+        const uint32_t cl = *reinterpret_cast<const uint32_t *>(cb + (bl + 8u * sl)), co = *reinterpret_cast<const uint32_t *>(cb + (bo + 8u * so)),
+                       cm = *reinterpret_cast<const uint32_t *>(cb + (bm + 8u * sm));
+        dst[i] = SeqRec{pos, sl | sm << 9 | so << 18};
+        const uint32_t nbl = (cl >> 16) & 0xFFu, nbm = (cm >> 16) & 0xFFu, nbo = (co >> 16) & 0xFFu;
+        pos -= static_cast<int32_t>((cl >> 24) + (co >> 24) + (cm >> 24) + nbl + nbm + nbo);
+        const uint32_t a = static_cast<uint32_t>(pos - off * 8), k = a >> 5;
+        const uint32_t x = k == 0 ? w[0] : (k == 1 ? w[1] : (k == 2 ? w[2] : 0u));
+        const uint32_t y = k == 0 ? w[1] : (k == 1 ? w[2] : 0u);
+        const uint32_t f = __builtin_amdgcn_alignbit(y, x, a & 31u);
+        sl = (cl & 0xFFFFu) + __builtin_amdgcn_ubfe(f, nbm + nbo, nbl);
+        sm = (cm & 0xFFFFu) + __builtin_amdgcn_ubfe(f, nbo, nbm);
+        so = (co & 0xFFFFu) + __builtin_amdgcn_ubfe(f, 0, nbo);
+    }
+    if (pos >= 0) {                                      // the last: no state update after it
+        const uint32_t cl = *reinterpret_cast<const uint32_t *>(cb + (bl + 8u * sl)), co = *reinterpret_cast<const uint32_t *>(cb + (bo + 8u * so)),
+                       cm = *reinterpret_cast<const uint32_t *>(cb + (bm + 8u * sm));
+        dst[n - 1] = SeqRec{pos, sl | sm << 9 | so << 18};
+        pos -= static_cast<int32_t>((cl >> 24) + (co >> 24) + (cm >> 24));
+    }
+    if (pos != 0) flag_error(status, kStSeqBadEnd, sb.blk);
+}
+
+constexpr uint32_t kSeqPerLane = 4;
+
+__global__ __launch_bounds__(64) void k_seq_values(const uint8_t *__restrict__ src, const SeqBlock *__restrict__ blocks,
+                                                   uint32_t n_blocks, const SeqCell *__restrict__ cells,
+                                                   const SeqRec *__restrict__ recs, Seq *seqs, uint32_t *blk_size,
+                                                   uint32_t *rep_final, uint32_t *status) {
+    __shared__ uint32_t s_sum[2][2][64];        // [ping-pong][ll, ml][lane]
+    __shared__ uint32_t s_map[2][3][64];        // [ping-pong][slot][lane]
+    if (status[0] != 0) return;                 // (k_seq_states flagged a stream: its records are not all there)
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    if (b >= n_blocks) return;
+    const SeqBlock sb = blocks[b];
+    const uint8_t *bits = src + sb.bits_off;
+    const SeqCell *tll = cells + sb.ll_tbl, *tof = cells + sb.of_tbl, *tml = cells + sb.ml_tbl;
+    const SeqRec *rec = recs + sb.seq_first;
     Seq *dst = seqs + sb.seq_first;
-    uint64_t sum_ll = 0, sum_ml = 0;
-    uint32_t r0 = kRepToken | (0u << 24), r1 = kRepToken | (1u << 24), r2 = kRepToken | (2u << 24);
-    bool bad_off = false;
-    for (uint32_t i = 0; i < sb.n_seq; i++) {
-        if (r.pos < 0) break;
-        const SeqCell cl = tll[sll], co = tof[sof], cm = tml[sml];
-        r.load();
-        Seq s;
-        const uint32_t ofv = co.base_value + r.read(co.extra_bits);   // extra bits in the order OF, ML, LL
-        s.ml = cm.base_value + r.read(cm.extra_bits);
-        s.ll = cl.base_value + r.read(cl.extra_bits);
-        if (i + 1 < sb.n_seq) {                          // state updates LL, ML, OF; none after the last
-            sll = cl.next_base + r.read(cl.nb);
-            sml = cm.next_base + r.read(cm.nb);
-            sof = co.next_base + r.read(co.nb);
-        }
-        if (r.pos < 0) break;
-        // repeat-offset history (App. B "Repeat offsets"), on tokens where the value is inherited
-        if (ofv > 3) {
-            s.off = ofv - 3;
-            bad_off = bad_off || (s.off & kRepToken);    // >= 2^31: beyond any legal window
-            r2 = r1;
-            r1 = r0;
-            r0 = s.off;
-        } else {
-            const uint32_t idx = ofv - 1 + (s.ll == 0 ? 1u : 0u);
-            if (idx == 0) {
-                s.off = r0;
-            } else {
-                s.off = idx == 1 ? r1 : (idx == 2 ? r2 : rep_minus_one(r0));
-                bad_off = bad_off || s.off == 0;
-                if (idx > 1) r2 = r1;
+    const uint32_t id0 = kRepToken | (0u << 24), id1 = kRepToken | (1u << 24), id2 = kRepToken | (2u << 24);
+    uint32_t carry[3] = {id0, id1, id2};        // the history at the start of the tile, in terms of the block's
+    uint32_t run_ll = 0, run_ml = 0;            // sums over the tiles before (<= kBlockMax + one tile: checked per tile)
+    bool bad = false;
+    for (uint32_t base = 0; base < sb.n_seq; base += 64 * kSeqPerLane) {
+        const uint32_t i0 = base + kSeqPerLane * lane;
+        uint32_t ll[kSeqPerLane], ml[kSeqPerLane], offs[kSeqPerLane];
+        uint32_t r0 = id0, r1 = id1, r2 = id2, sum_ll = 0, sum_ml = 0;
+        for (uint32_t j = 0; j < kSeqPerLane; j++) {
+            ll[j] = ml[j] = 0;
+            offs[j] = 0;
+            if (i0 + j >= sb.n_seq) continue;
+            const SeqRec q = rec[i0 + j];
+            const SeqCell cl = tll[q.states & 511u], cm = tml[(q.states >> 9) & 511u], co = tof[q.states >> 18];
+            SeqWindow r{bits, q.pos, 0, 0, 0};
+            r.load();
+            const uint32_t ofv = co.base_value + r.read(co.extra_bits);   // extra bits in the order OF, ML, LL
+            ml[j] = cm.base_value + r.read(cm.extra_bits);
+            ll[j] = cl.base_value + r.read(cl.extra_bits);
+            sum_ll += ll[j];
+            sum_ml += ml[j];
+            // repeat-offset history (App. B "Repeat offsets"), on tokens: "what this lane's first sequence inherits"
+            uint32_t o;
+            if (ofv > 3) {
+                o = ofv - 3;
+                bad = bad || (o & kRepToken);                // >= 2^31: beyond any legal window
+                r2 = r1;
                 r1 = r0;
-                r0 = s.off;
+                r0 = o;
+            } else {
+                const uint32_t idx = ofv - 1 + (ll[j] == 0 ? 1u : 0u);
+                if (idx == 0) {
+                    o = r0;
+                } else {
+                    o = idx == 1 ? r1 : (idx == 2 ? r2 : rep_minus_one(r0));
+                    bad = bad || o == 0;
+                    if (idx > 1) r2 = r1;
+                    r1 = r0;
+                    r0 = o;
+                }
+            }
+            offs[j] = o;
+        }
+        // inclusive scans over the lanes: the sums, and the maps "history before my first sequence -> history after my last"
+        uint32_t m[3] = {r0, r1, r2}, in_ll = sum_ll, in_ml = sum_ml;
+        uint32_t pp = 0;
+        for (uint32_t d = 1; d < 64; d <<= 1, pp ^= 1u) {
+            s_sum[pp][0][lane] = in_ll;
+            s_sum[pp][1][lane] = in_ml;
+            s_map[pp][0][lane] = m[0];
+            s_map[pp][1][lane] = m[1];
+            s_map[pp][2][lane] = m[2];
+            wave_sync();
+            if (lane >= d) {
+                in_ll += s_sum[pp][0][lane - d];
+                in_ml += s_sum[pp][1][lane - d];
+                if ((m[0] | m[1] | m[2]) & kRepToken) {      // (a map without tokens no longer depends on what came before)
+                    const uint32_t f[3] = {s_map[pp][0][lane - d], s_map[pp][1][lane - d], s_map[pp][2][lane - d]};
+                    const uint32_t n0 = rep_apply_entry(m[0], f, &bad), n1 = rep_apply_entry(m[1], f, &bad),
+                                   n2 = rep_apply_entry(m[2], f, &bad);
+                    m[0] = n0;
+                    m[1] = n1;
+                    m[2] = n2;
+                }
             }
         }
-        s.opos = static_cast<uint32_t>(sum_ll + sum_ml);
-        s.lpos = static_cast<uint32_t>(sum_ll);
-        dst[i] = s;
-        sum_ll += s.ll;
-        sum_ml += s.ml;
+        s_sum[pp][0][lane] = in_ll;
+        s_sum[pp][1][lane] = in_ml;
+        s_map[pp][0][lane] = m[0];
+        s_map[pp][1][lane] = m[1];
+        s_map[pp][2][lane] = m[2];
+        wave_sync();
+        // what my first sequence inherits: the lanes before me applied to the tile's start
+        uint32_t init[3] = {carry[0], carry[1], carry[2]};
+        uint32_t pre_ll = run_ll, pre_ml = run_ml;
+        if (lane) {
+            const uint32_t e[3] = {s_map[pp][0][lane - 1], s_map[pp][1][lane - 1], s_map[pp][2][lane - 1]};
+            init[0] = rep_apply_entry(e[0], carry, &bad);
+            init[1] = rep_apply_entry(e[1], carry, &bad);
+            init[2] = rep_apply_entry(e[2], carry, &bad);
+            pre_ll += s_sum[pp][0][lane - 1];
+            pre_ml += s_sum[pp][1][lane - 1];
+        }
+        for (uint32_t j = 0; j < kSeqPerLane; j++) {
+            if (i0 + j >= sb.n_seq) break;
+            Seq s;
+            s.ll = ll[j];
+            s.ml = ml[j];
+            s.off = rep_apply_entry(offs[j], init, &bad);
+            s.opos = pre_ll + pre_ml;
+            s.lpos = pre_ll;
+            dst[i0 + j] = s;
+            pre_ll += ll[j];
+            pre_ml += ml[j];
+        }
+        // the tile's totals and its whole map, for the next tile
+        {
+            const uint32_t e[3] = {s_map[pp][0][63], s_map[pp][1][63], s_map[pp][2][63]};
+            const uint32_t n0 = rep_apply_entry(e[0], carry, &bad), n1 = rep_apply_entry(e[1], carry, &bad),
+                           n2 = rep_apply_entry(e[2], carry, &bad);
+            carry[0] = n0;
+            carry[1] = n1;
+            carry[2] = n2;
+            run_ll += s_sum[pp][0][63];
+            run_ml += s_sum[pp][1][63];
+        }
+        wave_sync();                                      // (the next tile writes the other half first, then this one)
+        if (run_ll > kBlockMax || run_ml > kBlockMax) break;   // invalid: flagged below; keeps the 32-bit sums exact
     }
-    if (r.pos != 0) {
-        flag_error(status, kStSeqBadEnd, sb.blk);
-        return;
-    }
-    if (sum_ll > sb.lit_size) {
+    const bool any_bad = __any(bad ? 1 : 0) != 0;
+    if (lane != 0) return;
+    if (run_ll > sb.lit_size) {
         flag_error(status, kStSeqLiterals, sb.blk);
         return;
     }
-    if (bad_off) {
+    if (any_bad) {
         flag_error(status, kStBadOffset, sb.blk);
         return;
     }
-    rep_final[3 * b + 0] = r0;
-    rep_final[3 * b + 1] = r1;
-    rep_final[3 * b + 2] = r2;
-    if (sb.lit_size + sum_ml > kBlockMax) {
+    rep_final[3 * b + 0] = carry[0];
+    rep_final[3 * b + 1] = carry[1];
+    rep_final[3 * b + 2] = carry[2];
+    if (sb.lit_size + run_ml > kBlockMax) {
         flag_error(status, kStSizeMismatch, sb.blk);
         return;
     }
-    blk_size[sb.blk] = sb.lit_size + static_cast<uint32_t>(sum_ml);
+    blk_size[sb.blk] = sb.lit_size + run_ml;
 }
 
 // ======================================================================================
@@ -1417,7 +1565,7 @@ __device__ inline uint32_t rep_resolve(uint32_t tok, const uint32_t *init, bool 
     return base - d;
 }
 
-// A block maps the three repeat offsets it inherits to the three it leaves behind; k_seq_decode
+// A block maps the three repeat offsets it inherits to the three it leaves behind; k_seq_values
 // recorded that map symbolically: each outgoing offset is a value, or "incoming rep[slot] - d".
 // Such maps compose (rep_resolve is "apply entry `tok` after the map `f`", whether f is concrete or
 // symbolic), so the chain over all blocks is done in three steps instead of one serial walk:
@@ -1426,21 +1574,6 @@ __device__ inline uint32_t rep_resolve(uint32_t tok, const uint32_t *init, bool 
 //   k_rep_apply    thread t walks its C blocks from that triple and writes every block's initial triple
 // Repeat offsets restart at {1, 4, 8} with each frame.
 constexpr uint32_t kRepChunk = 64;
-
-__device__ inline uint32_t rep_apply_entry(uint32_t tok, const uint32_t *f, bool *bad) {
-    if (!(tok & kRepToken)) return tok;
-    const uint32_t fv = f[(tok >> 24) & 3u], d = tok & 0xFFFFFFu;
-    if (!(fv & kRepToken)) {
-        if (fv <= d) {
-            *bad = true;
-            return 1;
-        }
-        return fv - d;
-    }
-    const uint32_t d2 = (fv & 0xFFFFFFu) + d;
-    if (d2 > 0xFFFFFFu) *bad = true;
-    return (fv & 0xFF000000u) | (d2 & 0xFFFFFFu);
-}
 
 // (continues: the first block goes on with a frame begun in front of this tile -- its repeat offsets are the
 //  ones carried over, not {1, 4, 8})
@@ -2770,7 +2903,7 @@ __global__ __launch_bounds__(256) void k_hash64(const uint8_t *__restrict__ p, u
 // launchers
 // ======================================================================================
 void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *blocks, uint32_t n_blocks,
-                       const SeqCell *cells, Seq *seqs, uint32_t *blk_size, uint32_t *rep_final, uint32_t *status) {
+                       const SeqCell *cells, Seq *seqs, SeqMeta *meta, uint32_t *blk_size, uint32_t *rep_final, uint32_t *status) {
     if (!n_blocks) return;
     static const uint32_t forced = [] {                   // NAFGPU_K2_LANES: measurements only
         const char *e = std::getenv("NAFGPU_K2_LANES");
@@ -2779,8 +2912,11 @@ void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *b
     uint32_t lanes = forced ? forced : (n_blocks + 359u) / 360u;     // about one wave per CU ...
     lanes = forced ? lanes : (lanes < 16 ? 16 : lanes);              // ... of at least 16 lanes (measured: see above)
     lanes = lanes < 1 ? 1 : (lanes > 64 ? 64 : lanes);
-    hipLaunchKernelGGL(k_seq_decode, dim3((n_blocks + lanes - 1) / lanes), dim3(64), 0, stream, src, blocks, n_blocks, cells, seqs,
-                       blk_size, rep_final, lanes, status);
+    SeqRec *recs = reinterpret_cast<SeqRec *>(meta);      // (the SeqMeta records are written after these two kernels)
+    hipLaunchKernelGGL(k_seq_states, dim3((n_blocks + lanes - 1) / lanes), dim3(64), 0, stream, src, blocks, n_blocks, cells, recs,
+                       lanes, status);
+    hipLaunchKernelGGL(k_seq_values, dim3(n_blocks), dim3(64), 0, stream, src, blocks, n_blocks, cells, recs, seqs, blk_size,
+                       rep_final, status);
 }
 
 size_t scan_tmp_bytes(uint64_t n) { return static_cast<size_t>((n + kScanTile - 1) / kScanTile + 1) * sizeof(TileAgg); }

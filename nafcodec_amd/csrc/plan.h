@@ -118,7 +118,7 @@ struct alignas(16) SeqMeta {   // what the match passes need to know about a seq
 static_assert(sizeof(SeqMeta) == 16, "SeqMeta layout");
 
 // Repeat offsets (App. B): a block starts from the three offsets its predecessor ends with, which
-// k_seq_decode does not know (blocks decode in parallel).  It tracks them symbolically instead:
+// k_seq_values does not know (blocks decode in parallel).  It tracks them symbolically instead:
 //   token = kRepToken | slot << 24 | d   means   (initial rep[slot]) - d
 // and k_rep_chain later walks the blocks in frame order to turn every block's final triple into
 // the next block's initial one.

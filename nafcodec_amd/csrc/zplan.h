@@ -26,7 +26,7 @@ struct HufTableRef {                     // one Huffman tree in the table pool
 struct ZPlan {
     // per zstd block
     std::vector<uint32_t> blk_size;      // decoded size; blocks with sequences: literal bytes only
-                                         // (k_seq_decode adds the match bytes on the device)
+                                         // (k_seq_values adds the match bytes on the device)
     // Huffman literals
     std::vector<HufStream> streams;
     std::vector<HufTask> tasks;          // grouped by launch class

@@ -991,40 +991,49 @@ __global__ __launch_bounds__(64) void k_seq_values(const uint8_t *__restrict__ s
             }
             offs[j] = o;
         }
-        // inclusive scans over the lanes: the sums, and the maps "history before my first sequence -> history after my last"
+        // inclusive scans over the lanes: the sums, and the maps "history before my first sequence -> history after my last".
+        // A map without tokens no longer depends on what came before, so the map rounds stop as soon as every lane's is
+        // either closed or complete (with mostly fresh offsets: after the first round or two).
         uint32_t m[3] = {r0, r1, r2}, in_ll = sum_ll, in_ml = sum_ml;
         uint32_t pp = 0;
         for (uint32_t d = 1; d < 64; d <<= 1, pp ^= 1u) {
             s_sum[pp][0][lane] = in_ll;
             s_sum[pp][1][lane] = in_ml;
-            s_map[pp][0][lane] = m[0];
-            s_map[pp][1][lane] = m[1];
-            s_map[pp][2][lane] = m[2];
             wave_sync();
             if (lane >= d) {
                 in_ll += s_sum[pp][0][lane - d];
                 in_ml += s_sum[pp][1][lane - d];
-                if ((m[0] | m[1] | m[2]) & kRepToken) {      // (a map without tokens no longer depends on what came before)
-                    const uint32_t f[3] = {s_map[pp][0][lane - d], s_map[pp][1][lane - d], s_map[pp][2][lane - d]};
-                    const uint32_t n0 = rep_apply_entry(m[0], f, &bad), n1 = rep_apply_entry(m[1], f, &bad),
-                                   n2 = rep_apply_entry(m[2], f, &bad);
-                    m[0] = n0;
-                    m[1] = n1;
-                    m[2] = n2;
-                }
             }
         }
         s_sum[pp][0][lane] = in_ll;
         s_sum[pp][1][lane] = in_ml;
-        s_map[pp][0][lane] = m[0];
-        s_map[pp][1][lane] = m[1];
-        s_map[pp][2][lane] = m[2];
+        uint32_t pm = 0;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const bool need = lane >= d && ((m[0] | m[1] | m[2]) & kRepToken) != 0;
+            if (!__any(need ? 1 : 0)) break;
+            s_map[pm][0][lane] = m[0];
+            s_map[pm][1][lane] = m[1];
+            s_map[pm][2][lane] = m[2];
+            wave_sync();
+            if (need) {
+                const uint32_t f[3] = {s_map[pm][0][lane - d], s_map[pm][1][lane - d], s_map[pm][2][lane - d]};
+                const uint32_t n0 = rep_apply_entry(m[0], f, &bad), n1 = rep_apply_entry(m[1], f, &bad),
+                               n2 = rep_apply_entry(m[2], f, &bad);
+                m[0] = n0;
+                m[1] = n1;
+                m[2] = n2;
+            }
+            pm ^= 1u;
+        }
+        s_map[pm][0][lane] = m[0];
+        s_map[pm][1][lane] = m[1];
+        s_map[pm][2][lane] = m[2];
         wave_sync();
         // what my first sequence inherits: the lanes before me applied to the tile's start
         uint32_t init[3] = {carry[0], carry[1], carry[2]};
         uint32_t pre_ll = run_ll, pre_ml = run_ml;
         if (lane) {
-            const uint32_t e[3] = {s_map[pp][0][lane - 1], s_map[pp][1][lane - 1], s_map[pp][2][lane - 1]};
+            const uint32_t e[3] = {s_map[pm][0][lane - 1], s_map[pm][1][lane - 1], s_map[pm][2][lane - 1]};
             init[0] = rep_apply_entry(e[0], carry, &bad);
             init[1] = rep_apply_entry(e[1], carry, &bad);
             init[2] = rep_apply_entry(e[2], carry, &bad);
@@ -1045,7 +1054,7 @@ __global__ __launch_bounds__(64) void k_seq_values(const uint8_t *__restrict__ s
         }
         // the tile's totals and its whole map, for the next tile
         {
-            const uint32_t e[3] = {s_map[pp][0][63], s_map[pp][1][63], s_map[pp][2][63]};
+            const uint32_t e[3] = {s_map[pm][0][63], s_map[pm][1][63], s_map[pm][2][63]};
             const uint32_t n0 = rep_apply_entry(e[0], carry, &bad), n1 = rep_apply_entry(e[1], carry, &bad),
                            n2 = rep_apply_entry(e[2], carry, &bad);
             carry[0] = n0;

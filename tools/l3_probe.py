@@ -14,12 +14,17 @@ for level in (1, 3):
     lens = nw.length_words([n_bases])
     lenp = zstd_ref.compress_magicless(lens, 1, True)
     blob = bytes([1, 0xF9, 0xEC, 1, 0x0A, 0x20]) + nw.varint(60) + nw.varint(1) + nw.varint(len(lens)) + nw.varint(len(lenp)) + lenp + nw.varint(n_bases) + nw.varint(len(payload)) + payload
-    dec = nafcodec_amd.Decoder(io.BytesIO(blob))
-    res = dec.decode_all_device(); res = dec.decode_all_device()
     lut = np.frombuffer(b"-TGKCYSBAWRDMHVN", dtype=np.uint8)
     a = np.frombuffer(packed, dtype=np.uint8)
     want = np.empty(n_bases, dtype=np.uint8); want[0::2] = lut[a & 15]; want[1::2] = lut[a >> 4]
-    ok = dec.hash_device(res.d_sequence, res.n_bases) == _ffi.default().c.nafgpu_hash64_host(want.tobytes(), n_bases)
-    print("level", level, "bases", n_bases, "compress s %.1f" % tc, "B/base %.4f" % (len(payload) / n_bases), "ok", ok,
-          "ms total %.2f huf %.2f seq_lz %.2f other %.2f" % (res.ms_total, res.ms_huf, res.ms_seq_lz, res.ms_other),
-          "Gbases/s %.1f" % (n_bases / res.ms_total / 1e6), flush=True)
+    want_hash = _ffi.default().c.nafgpu_hash64_host(want.tobytes(), n_bases)
+    # NAFGPU_PROBE_LIBS: comma-separated experiment builds timed on the same archive after the product
+    for path in [None] + [x for x in os.environ.get("NAFGPU_PROBE_LIBS", "").split(",") if x]:
+        lib = _ffi.default() if path is None else _ffi.Library(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), path))
+        dec = nafcodec_amd.Decoder(io.BytesIO(blob), _lib=lib)
+        res = dec.decode_all_device(); res = dec.decode_all_device()
+        ok = dec.hash_device(res.d_sequence, res.n_bases) == want_hash
+        print("level", level, "product" if path is None else path, "bases", n_bases, "compress s %.1f" % tc, "B/base %.4f" % (len(payload) / n_bases), "ok", ok,
+              "ms total %.2f huf %.2f seq_lz %.2f other %.2f" % (res.ms_total, res.ms_huf, res.ms_seq_lz, res.ms_other),
+              "Gbases/s %.1f" % (n_bases / res.ms_total / 1e6), flush=True)
+        dec.close()

@@ -57,6 +57,18 @@ def build_cases(scale=1):
     dense = "".join(rng.choice(list("GGGGGGGJJJJF#"), 60000 * scale))
     add("text_dense_chains", nw.write_naf([{"id": "q", "sequence": dense}], sequence_type="text", level=3))
     add("dna_dense_chains", nw.write_naf([{"id": "d", "sequence": "".join(rng.choice(list("AAAAAAAT"), 150001 * scale))}], level=3))
+    # repeat offsets, densely: a 211-character motif copied over and over with a substitution every ~17 characters and a
+    # deletion now and then -- almost every sequence of the blocks is "same offset as before" (or the one before that, or
+    # that minus one after a literal-free match), thousands in a row, so k_seq_values' maps stay open across its lanes
+    # and tiles and the history has to be carried through both
+    motif = rng.choice(list("ACGTRYKMSWBDHVN"), 211)
+    rep = np.tile(motif, 1400 * scale)
+    hits = np.flatnonzero(rng.random(rep.size) < 1 / 17)
+    rep[hits] = rng.choice(list("ACGT"), hits.size)
+    rep = np.delete(rep, np.flatnonzero(rng.random(rep.size) < 1 / 900))
+    for lvl in (1, 3, 9):
+        add("text_repeat_offsets_l%d" % lvl, nw.write_naf([{"id": "r", "sequence": "".join(rep)}], sequence_type="text", level=lvl))
+    add("dna_repeat_offsets", nw.write_naf([{"id": "r", "sequence": "".join(rep)}], level=3))
     add("title_and_extended", nw.write_naf(make_records(rng, [10, 20, 30]), title="a title ✓", extended=True))
     add("v2_dna", nw.write_naf(make_records(rng, [100, 101]), version=2))
     add("no_ids_no_comments", nw.write_naf(make_records(rng, [5, 6, 7]), ids=False, comments=False))

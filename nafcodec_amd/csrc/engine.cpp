@@ -358,12 +358,37 @@ const uint8_t *SectionJob::tile_data() const {
 SectionJob::~SectionJob() {
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
+    if (ev_early_fork_) (void)hipEventDestroy(ev_early_fork_);
+    if (ev_early_join_) (void)hipEventDestroy(ev_early_join_);
 }
 
 void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
     if (!ready_) return;
     uint32_t *status = d_status_.as<uint32_t>();
     (void)hipMemsetAsync(status, 0, 64, stream);
+    auto launch_class = [&](const HufClass &c, hipStream_t st, uint8_t *out_base) {
+        launch_huf_decode(st, d_src_, d_tasks_.as<HufTask>(), c, d_tbl_copies_.as<HufTblCopy>(), d_streams_.as<HufStream>(),
+                          d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(), d_seq_blocks_.as<SeqBlock>(),
+                          d_seqs_.as<Seq>(), d_dicts_.bytes(), t_char_ != 0, t_char_, status);
+    };
+    // Streams bound for the literal buffer need nothing from K2 (their destinations are the plan's): they start on `aux`
+    // now, beside k_seq_states -- a chain per block that keeps one wave per CU busy and leaves the rest of the chip idle.
+    bool early = false;
+    if (n_seq_blocks_ && aux) {
+        bool any = false;
+        for (const HufClass &c : classes_) any = any || c.to_lit;
+        if (any) {
+            if (!ev_early_fork_) (void)hipEventCreateWithFlags(&ev_early_fork_, hipEventDisableTiming);
+            if (!ev_early_join_) (void)hipEventCreateWithFlags(&ev_early_join_, hipEventDisableTiming);
+            early = ev_early_fork_ && ev_early_join_ && hip_ok(hipEventRecord(ev_early_fork_, stream)) &&
+                    hip_ok(hipStreamWaitEvent(aux, ev_early_fork_, 0));
+            if (early) {
+                for (const HufClass &c : classes_)
+                    if (c.to_lit) launch_class(c, aux, nullptr);
+                (void)hipEventRecord(ev_early_join_, aux);
+            }
+        }
+    }
     if (n_seq_blocks_) {
         if (timer) timer->begin(stream, StageTimer::kSeqLz);
         // blk_size of blocks with sequences is rewritten in full by k_seq_values: re-runs are idempotent
@@ -390,37 +415,36 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
     // segment -- blocks with a few) and streams that feed the literal buffer (blocks with many sequences).  When
     // both kinds exist the literal-buffer classes run on `aux` beside the others, so the launches share the chip
     // instead of each ending in a half-empty tail; K4 then waits for both.  One timed span covers the phase.
-    auto launch_class = [&](const HufClass &c, hipStream_t st) {
-        launch_huf_decode(st, d_src_, d_tasks_.as<HufTask>(), c, d_tbl_copies_.as<HufTblCopy>(), d_streams_.as<HufStream>(),
-                          d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(), d_seq_blocks_.as<SeqBlock>(),
-                          d_seqs_.as<Seq>(), d_dicts_.bytes(), ascii, t_char_, status);
-    };
     // The classes are independent of each other.  The one with the most tasks goes to `stream`, the others to `aux`
     // beside it: a class of a few tasks (the tail of a section; streams bound for the literal buffer) takes a whole
     // task's time -- 2.5 ms on one CU for 64 streams -- which back to back was a fifth of a real-genome decode, and
     // two large classes share the chip instead of each ending in a half-empty tail.  K4 waits for both.
-    if (!classes_.empty()) {
+    std::vector<const HufClass *> rest;                     // (what did not start early)
+    for (const HufClass &c : classes_)
+        if (!(early && c.to_lit)) rest.push_back(&c);
+    if (!rest.empty()) {
         if (timer) timer->begin(stream, StageTimer::kHuf);
         size_t big = 0;
-        for (size_t c = 1; c < classes_.size(); c++)
-            if (classes_[c].n_tasks > classes_[big].n_tasks) big = c;
+        for (size_t c = 1; c < rest.size(); c++)
+            if (rest[c]->n_tasks > rest[big]->n_tasks) big = c;
         bool forked = false;
-        if (classes_.size() > 1 && aux) {
+        if (rest.size() > 1 && aux) {
             if (!ev_fork_) (void)hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming);
             if (!ev_join_) (void)hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming);
             forked = ev_fork_ && ev_join_ && hip_ok(hipEventRecord(ev_fork_, stream)) && hip_ok(hipStreamWaitEvent(aux, ev_fork_, 0));
         }
         if (forked) {
-            for (size_t c = 0; c < classes_.size(); c++)
-                if (c != big) launch_class(classes_[c], aux);
+            for (size_t c = 0; c < rest.size(); c++)
+                if (c != big) launch_class(*rest[c], aux, out_base);
             (void)hipEventRecord(ev_join_, aux);
-            launch_class(classes_[big], stream);
+            launch_class(*rest[big], stream, out_base);
             (void)hipStreamWaitEvent(stream, ev_join_, 0);
         } else {
-            for (const HufClass &c : classes_) launch_class(c, stream);
+            for (const HufClass *c : rest) launch_class(*c, stream, out_base);
         }
         if (timer) timer->end(stream);
     }
+    if (early) (void)hipStreamWaitEvent(stream, ev_early_join_, 0);   // the literal buffer is complete from here on
     if (n_seq_blocks_) {
         if (timer) timer->begin(stream, StageTimer::kSeqLz);
         LzArgs la{};

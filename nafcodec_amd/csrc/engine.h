@@ -154,6 +154,7 @@ private:
     uint32_t t_char_ = 0;
     bool sharded_ = false;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;   // K1 on two streams (created on first use, destroyed with the job)
+    hipEvent_t ev_early_fork_ = nullptr, ev_early_join_ = nullptr;   // literal-buffer classes of K1 beside K2
     const uint8_t *d_src_ = nullptr;                     // device address of payload offset 0 (only [src_lo, src_hi) of the tile is behind it)
     float plan_ms_ = 0;
     bool ready_ = false;

@@ -901,6 +901,8 @@ __global__ __launch_bounds__(64) void k_seq_states(const uint8_t *__restrict__ s
     //  wait has to be vmcnt(0) on every trip, which also waits for the record store of the trip before)
 #ifndef NAFGPU_EMU
     asm volatile("" ::"v"(bl), "v"(bo), "v"(bm), "v"(sl), "v"(so), "v"(sm), "v"(pos), "v"(n));
+    // (the literal-buffer classes of K1 run beside this kernel: the chain goes first whenever it can issue)
+    __builtin_amdgcn_s_setprio(3);
 #endif
     // every sequence but the last: its record, its extra bits skipped, the three state updates (LL, ML, OF: one field)
     for (uint32_t i = 0; i + 1 < n; i++) {

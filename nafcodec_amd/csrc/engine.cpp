@@ -360,12 +360,26 @@ SectionJob::~SectionJob() {
     if (ev_join_) (void)hipEventDestroy(ev_join_);
     if (ev_early_fork_) (void)hipEventDestroy(ev_early_fork_);
     if (ev_early_join_) (void)hipEventDestroy(ev_early_join_);
+    if (ev_k2_) (void)hipEventDestroy(ev_k2_);
+}
+
+void SectionJob::run_k2_ahead(hipStream_t st) {
+    if (!ready_ || !n_seq_blocks_) return;
+    if (!ev_k2_ && !hip_ok(hipEventCreateWithFlags(&ev_k2_, hipEventDisableTiming))) return;
+    uint32_t *status = d_status_.as<uint32_t>();
+    (void)hipMemsetAsync(status, 0, 64, st);
+    launch_seq_decode(st, d_src_, d_seq_blocks_.as<SeqBlock>(), static_cast<uint32_t>(n_seq_blocks_), d_cells_.as<SeqCell>(),
+                      d_seqs_.as<Seq>(), d_meta_.as<SeqMeta>(), d_blk_size_.as<uint32_t>(), d_rep_final_.as<uint32_t>(), status);
+    k2_ahead_ = hip_ok(hipEventRecord(ev_k2_, st));
+    if (!k2_ahead_) (void)hipStreamSynchronize(st);         // (cannot happen; run() then simply does it again)
 }
 
 void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
     if (!ready_) return;
     uint32_t *status = d_status_.as<uint32_t>();
-    (void)hipMemsetAsync(status, 0, 64, stream);
+    const bool k2_done = k2_ahead_ && hip_ok(hipStreamWaitEvent(stream, ev_k2_, 0));
+    k2_ahead_ = false;
+    if (!k2_done) (void)hipMemsetAsync(status, 0, 64, stream);
     auto launch_class = [&](const HufClass &c, hipStream_t st, uint8_t *out_base) {
         launch_huf_decode(st, d_src_, d_tasks_.as<HufTask>(), c, d_tbl_copies_.as<HufTblCopy>(), d_streams_.as<HufStream>(),
                           d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(), d_seq_blocks_.as<SeqBlock>(),
@@ -389,7 +403,7 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
             }
         }
     }
-    if (n_seq_blocks_) {
+    if (n_seq_blocks_ && !k2_done) {
         if (timer) timer->begin(stream, StageTimer::kSeqLz);
         // blk_size of blocks with sequences is rewritten in full by k_seq_values: re-runs are idempotent
         launch_seq_decode(stream, d_src_, d_seq_blocks_.as<SeqBlock>(), static_cast<uint32_t>(n_seq_blocks_),
@@ -548,6 +562,7 @@ ArchiveJob::~ArchiveJob() {
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
     if (aux_stream_) (void)hipStreamDestroy(aux_stream_);
+    if (k2_stream_) (void)hipStreamDestroy(k2_stream_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -568,6 +583,7 @@ Failure ArchiveJob::init(int device) {
         e = hipStreamCreate(&stream_);
         if (!hip_ok(e)) return dev_fail("hipStreamCreate", e);
         if (!hip_ok(hipStreamCreate(&aux_stream_))) aux_stream_ = nullptr;   // optional: K1 then stays on one stream
+        if (!hip_ok(hipStreamCreate(&k2_stream_))) k2_stream_ = nullptr;     // optional: K2 of a section beside the section before
     }
     return Failure();
 }
@@ -670,6 +686,16 @@ Failure ArchiveJob::decode() {
     // The sequence and quality sections: one resident tile each (kernels only), or tile after tile -- all of them
     // now when the whole output is resident, the first one when the output is held a tile at a time (the
     // iterator asks for the next ones, advance_tile).
+    // K2 of every later single-tile section starts now, on its own stream: the sequence chains of a Quality section take
+    // as long as the whole Sequence section in front of it, on one wave per CU.
+    if (k2_stream_) {
+        bool first = true;
+        for (int s = kMask + 1; s < kNumSections; s++) {
+            if (!job_[s].ready() || job_[s].n_tiles() != 1) continue;
+            if (!first) job_[s].run_k2_ahead(k2_stream_);
+            first = false;
+        }
+    }
     for (int s = kMask + 1; s < kNumSections; s++) {
         if (!job_[s].ready()) continue;
         if (job_[s].n_tiles() == 1) {

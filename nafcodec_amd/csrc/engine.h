@@ -100,6 +100,9 @@ public:
     // Enqueues the decode kernels of the resident tile.  Results: out() holds size() bytes once the stream is done.
     // aux: a second stream (or null) on which the literal-buffer Huffman tasks run beside the direct ones
     void run(hipStream_t stream, StageTimer *timer, hipStream_t aux = nullptr);
+    // K2 of this section enqueued on `st` ahead of run(): a chain per block that leaves most of the chip idle, so it
+    // goes beside the section decoded before this one; run() then waits for it instead of launching it.
+    void run_k2_ahead(hipStream_t st);
     // After synchronisation: device status -> Failure
     Failure check(hipStream_t stream);
     // Tiles: uploads tile t (they are decoded in order), decodes it, synchronises, keeps what the next one needs
@@ -155,6 +158,8 @@ private:
     bool sharded_ = false;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;   // K1 on two streams (created on first use, destroyed with the job)
     hipEvent_t ev_early_fork_ = nullptr, ev_early_join_ = nullptr;   // literal-buffer classes of K1 beside K2
+    hipEvent_t ev_k2_ = nullptr;                                      // run_k2_ahead -> run
+    bool k2_ahead_ = false;
     const uint8_t *d_src_ = nullptr;                     // device address of payload offset 0 (only [src_lo, src_hi) of the tile is behind it)
     float plan_ms_ = 0;
     bool ready_ = false;
@@ -228,7 +233,7 @@ public:
 
 private:
     int device_ = -1;
-    hipStream_t stream_ = nullptr, aux_stream_ = nullptr;
+    hipStream_t stream_ = nullptr, aux_stream_ = nullptr, k2_stream_ = nullptr;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;   // record / mask table scans beside the sequence decode
     StageTimer timer_;
     StageTimes times_;

@@ -3061,15 +3061,30 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
                        a.rep_carry[2], a.status);
     hipLaunchKernelGGL(k_rep_apply, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, a.blocks, a.n_blocks, a.rep_final,
                        chunk_init, a.rep_init, a.rep_continues, a.rep_out, a.status);
+    const uint32_t grid = a.n_blocks < 256u * 8u ? a.n_blocks : 256u * 8u;
+    // Swept sections: k_pj_fill (distances into D) and k_lz_literals (literals into the output) touch different buffers and
+    // both walk the sequences block by block between barriers, at a fraction of the memory's rate: side by side.
+    const bool side = a.pj_dist && a.side && a.ev_side_fork && a.ev_side_join && hipEventRecord(a.ev_side_fork, stream) == hipSuccess &&
+                      hipStreamWaitEvent(a.side, a.ev_side_fork, 0) == hipSuccess;
+    const hipStream_t fill_stream = side ? a.side : stream;
+    if (side) {
+        (void)hipMemsetAsync(a.pj_dist, 0, static_cast<size_t>(a.n_elems) * sizeof(uint32_t), fill_stream);
+        hipLaunchKernelGGL(k_pj_fill<ASCII>, dim3(grid), dim3(256), 0, fill_stream, a.blocks, a.n_blocks, a.seqs, a.rep_init, a.blk_base,
+                           a.pj_dist, a.status);
+        (void)hipEventRecord(a.ev_side_join, fill_stream);
+    }
     hipLaunchKernelGGL(k_lz_literals<ASCII>, dim3(a.n_blocks), dim3(256), 0, stream, a.blocks, a.seqs, a.lit, a.blk_base,
                        a.meta, a.blk_pending, a.out, a.t_char, a.status);
-    const uint32_t grid = a.n_blocks < 256u * 8u ? a.n_blocks : 256u * 8u;
     if (a.pj_dist) {
         // ---- dense: every element learns its source distance, then the frame is swept (see k_pj_sweep)
         const uint32_t max_dist = pj_max_dist();
-        (void)hipMemsetAsync(a.pj_dist, 0, static_cast<size_t>(a.n_elems) * sizeof(uint32_t), stream);
-        hipLaunchKernelGGL(k_pj_fill<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.rep_init, a.blk_base,
-                           a.pj_dist, a.status);
+        if (side) {
+            (void)hipStreamWaitEvent(stream, a.ev_side_join, 0);
+        } else {
+            (void)hipMemsetAsync(a.pj_dist, 0, static_cast<size_t>(a.n_elems) * sizeof(uint32_t), stream);
+            hipLaunchKernelGGL(k_pj_fill<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.rep_init, a.blk_base,
+                               a.pj_dist, a.status);
+        }
         uint64_t tiles = (a.n_elems + kPjTile - 1) / kPjTile;
         if (tiles > 256u * 16u) tiles = 256u * 16u;
         unsigned long long *pcount = a.counters + 4;       // [4..6]: pending elements, rotating (k_pj_sweep)

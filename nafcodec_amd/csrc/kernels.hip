@@ -2107,7 +2107,9 @@ constexpr uint32_t kPjTile = 2048;           // elements per tile (256 threads x
 constexpr uint32_t kPjFinal = 0xFFFF0000u;   // D >= kPjFinal: final, and the low 16 bits ARE the element (byte / two characters)
 constexpr uint32_t kPjShort = 16;            // k_pj_fill: matches up to this long are filled by the thread that looked at them
 constexpr uint32_t kPjLocal = 4;             // jumps inside the tile (LDS) before a sweep looks into memory
-constexpr uint32_t kPjSweeps = 40;           // 2^40 > any chain; what is left after them goes to the frame-order walk
+constexpr uint32_t kPjSweeps = 24;           // a sweep at least halves every chain: 2^24 matches deep; what is left after them goes to the
+                                             // frame-order walk (every launch that finds nothing left still costs its 4-5 us: 40 of them
+                                             // plus as many k_pj_list were 0.4 ms per section)
 
 template <bool ASCII>
 __global__ __launch_bounds__(256) void k_pj_fill(const SeqBlock *__restrict__ blocks, uint32_t n_blocks, const Seq *__restrict__ seqs,

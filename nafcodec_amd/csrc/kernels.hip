@@ -1725,9 +1725,10 @@ __global__ __launch_bounds__(256) void k_lz_literals(const SeqBlock *__restrict_
     if (tid == 0) blk_pending[blockIdx.x] = sb.n_seq;
     auto put = [&](Elem *d, uint8_t b) { *d = ASCII ? static_cast<Elem>(byte_chars(b, t_char)) : static_cast<Elem>(b); };
     if (sb.direct) {                                       // k_huf_decode put the literals in place: only the match table is left to do
+        if (!meta) return;
         for (uint32_t s = tid; s < sb.n_seq; s += 256) {
             const Seq q = sq[s];
-            meta[sb.seq_first + s] = SeqMeta{obase + q.opos + q.ll, q.ml, 0u};
+            if (meta) meta[sb.seq_first + s] = SeqMeta{obase + q.opos + q.ll, q.ml, 0u};
         }
         return;
     }
@@ -1736,7 +1737,7 @@ __global__ __launch_bounds__(256) void k_lz_literals(const SeqBlock *__restrict_
         __syncthreads();
         if (s0 + tid < sb.n_seq) {
             const Seq q = sq[s0 + tid];
-            meta[sb.seq_first + s0 + tid] = SeqMeta{obase + q.opos + q.ll, q.ml, 0u};   // where the match of this sequence starts; pending
+            if (meta) meta[sb.seq_first + s0 + tid] = SeqMeta{obase + q.opos + q.ll, q.ml, 0u};   // where the match of this sequence starts; pending (swept sections keep no such records)
             if (q.ll <= kLzShort) {
                 for (uint32_t k = 0; k < q.ll; k++) put(out + q.opos + k, blit[q.lpos + k]);
             } else {
@@ -2502,7 +2503,8 @@ __global__ __launch_bounds__(256) void k_lz_matches_ordered(const SeqBlock *__re
             // collect the batch's pending matches (flags are read 256 at a time), restore their order
             if (tid == 0) s_n = 0;
             __syncthreads();
-            if (s0 + tid < sb.n_seq && meta[sb.seq_first + s0 + tid].flag == 0) s_idx[atomicAdd(&s_n, 1u)] = s0 + tid;
+            // (meta == nullptr: a swept section -- no per-match records, every match is redone in order)
+            if (s0 + tid < sb.n_seq && (!meta || meta[sb.seq_first + s0 + tid].flag == 0)) s_idx[atomicAdd(&s_n, 1u)] = s0 + tid;
             __syncthreads();
             const uint32_t n = s_n;
             if (n > 1) {
@@ -2521,7 +2523,7 @@ __global__ __launch_bounds__(256) void k_lz_matches_ordered(const SeqBlock *__re
                 const Seq q = seqs[g];
                 bool bad = false;
                 const uint32_t off = rep_resolve(q.off, init, &bad);
-                const uint64_t mpos = meta[g].pos;
+                const uint64_t mpos = meta ? meta[g].pos : blk_base[sb.blk] + q.opos + q.ll;
                 s_mpos[tid] = mpos;
                 s_ml[tid] = q.ml;
                 s_off[tid] = (bad || off > mpos - fstart) ? 0u : off;
@@ -3076,7 +3078,7 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
         (void)hipEventRecord(a.ev_side_join, fill_stream);
     }
     hipLaunchKernelGGL(k_lz_literals<ASCII>, dim3(a.n_blocks), dim3(256), 0, stream, a.blocks, a.seqs, a.lit, a.blk_base,
-                       a.meta, a.blk_pending, a.out, a.t_char, a.status);
+                       a.pj_dist ? nullptr : a.meta, a.blk_pending, a.out, a.t_char, a.status);
     if (a.pj_dist) {
         // ---- dense: every element learns its source distance, then the frame is swept (see k_pj_sweep)
         const uint32_t max_dist = pj_max_dist();
@@ -3110,8 +3112,8 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
             hipLaunchKernelGGL(k_pj_emit<ASCII>, dim3(static_cast<uint32_t>(eg ? eg : 1)), dim3(256), 0, stream, a.pj_dist, a.out, a.n_elems, a.status);
         }
         // anything still pending (a distance that would not fit 32 bits): frame order
-        hipLaunchKernelGGL(k_lz_matches_ordered<ASCII>, dim3(1), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.meta,
-                           a.blk_pending, a.rep_init, a.blk_base, a.out, pcount + kPjSweeps % 3u, a.status);
+        hipLaunchKernelGGL(k_lz_matches_ordered<ASCII>, dim3(1), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs,
+                           static_cast<SeqMeta *>(nullptr), a.blk_pending, a.rep_init, a.blk_base, a.out, pcount + kPjSweeps % 3u, a.status);
         return;
     }
     // ---- sparse: matches one by one; pass 1 walks the blocks, the later ones the list of what is still pending

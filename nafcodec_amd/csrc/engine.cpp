@@ -508,13 +508,6 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
                 la.pj_list[1] = d_pj_list_[1].as<uint32_t>();
             }
             lz_dense_ = true;
-            if (aux) {
-                if (!ev_fork_) (void)hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming);
-                if (!ev_join_) (void)hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming);
-                la.side = aux;                                 // (the K1 launches that used these events are joined by now)
-                la.ev_side_fork = ev_fork_;
-                la.ev_side_join = ev_join_;
-            }
         } else {
             // the pending lists are an accelerator: without memory for them every pass walks the blocks
             const bool lists = plan_.n_sequences < (1ull << 40) && n_seq_blocks_ < (1ull << 24) &&

@@ -105,8 +105,6 @@ struct LzArgs {
     uint32_t *pj_tiles;          // dense: pending elements per tile of 2048 (lz_pj_tiles(n_elems) words)
     uint32_t *pj_list[2];        // dense, optional: two lists of pending element indices, pj_list_cap entries each (k_pj_list)
     uint64_t pj_list_cap;
-    hipStream_t side;            // swept sections: k_pj_fill runs here beside k_lz_literals (nullptr: after it), between these two events
-    hipEvent_t ev_side_fork, ev_side_join;
     unsigned long long *counters;// 8 words: [0] matches still pending (sparse), [1] matches left to the one-workgroup stage, [4..6] stage counters
     uint8_t *out;
     uint32_t t_char;

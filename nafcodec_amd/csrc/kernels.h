@@ -14,7 +14,9 @@ struct ScanTotals {          // written by the scan kernels
     uint64_t count;          // number of run terminators (runs modes) or elements (exclusive mode)
 };
 
-// K2: FSE sequence decode, one lane per block with sequences.  Adds match bytes to blk_size[].
+// K2: FSE sequence decode in two kernels -- k_seq_states (one lane per block with sequences: the FSE states and the bit
+// cursor of every sequence) and k_seq_values (one wave per block: values, positions, repeat offsets).  Adds match bytes to
+// blk_size[].  `meta` is scratch here (the 8-byte state records): nothing else uses it before k_lz_literals.
 // rep_final: 3 u32 per block -- the repeat offsets the block ends with (concrete or kRepToken tokens)
 void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *blocks, uint32_t n_blocks,
                        const SeqCell *cells, Seq *seqs, SeqMeta *meta, uint32_t *blk_size, uint32_t *rep_final, uint32_t *status);

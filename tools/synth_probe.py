@@ -27,5 +27,5 @@ for path in [None] + [x for x in os.environ.get("NAFGPU_PROBE_LIBS", "").split("
     ok = dec.hash_device(best.d_sequence, best.n_bases) == arc.seq_hash
     print("synthetic", n, "bases iupac", ip, "mask", int(mask), "product" if path is None else path, "ok", ok,
           "ms total %.2f huf %.2f seq_lz %.2f other %.2f" % (best.ms_total, best.ms_huf, best.ms_seq_lz, best.ms_other),
-          "Gbases/s %.1f" % (n / best.ms_total / 1e6), flush=True)
+          "Gbases/s %.1f" % (n / best.ms_total / 1e6), "out at 0x%x" % best.d_sequence, flush=True)
     dec.close()

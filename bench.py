@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--real-copies", type=int, default=3000,
                     help="N=1 only: also time an archive shaped like a real genome (the reference's NZ_AAEN01000029 fixture tiled "
                          "this many times, libzstd level 1) and report it as path.real_genome; 0 skips it")
+    ap.add_argument("--real-copies-per-gpu", type=int, default=1000,
+                    help="N>1: the real-genome archive (WITH LZ sequences) holds this many tiles per GPU, ONE archive decoded through the "
+                         "shard protocol and reported as path.real_genome; 0 skips it")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--rehearsal-one-gpu", action="store_true",
                     help="tests only: several ranks (gloo) share GPU 0 -- the sharded flow with the real library on a one-GPU box; "
@@ -131,34 +134,27 @@ def cpu_baseline(lib, n_bases_target, mask, device):
     return out, want.n_bases
 
 
-def real_genome_leg(lib, device, copies):
-    """Second measured workload (reported beside the headline, never as `value`): an archive with the block structure
-    `ennaf` gives real genomes -- the sequence of tests/golden/NZ_AAEN01000029.naf (the reference's own fixture: 5.5 Mbases,
-    IUPAC codes besides ACGT) tiled `copies` times and compressed by the system libzstd at level 1 in streaming mode: one
-    Huffman tree per 128 KiB block, a few LZ sequences per block.  The fixture is decoded by the HIP path itself; the
-    expected output of the tiled archive is the tiled output of the fixture (checksum compared)."""
+def _decode_bulk(lib, device, blob):
+    ffi = _ffi_mod()
+    opts = ffi.Opts()
+    lib.c.nafgpu_opts_default(ctypes.byref(opts))
+    opts.device = device
+    h, err, res = ctypes.c_void_p(), ffi.Error(), ffi.DeviceResult()
+    if lib.c.nafgpu_open_bytes(blob, len(blob), ctypes.byref(opts), ctypes.byref(h), ctypes.byref(err)) != 0:
+        raise RuntimeError("open failed: %s" % err.message.decode())
+    if lib.c.nafgpu_decode_all_device(h, ctypes.byref(res)) != 0:
+        lib.c.nafgpu_last_error(h, ctypes.byref(err))
+        raise RuntimeError("decode failed: %s" % err.message.decode())
+    return h, res
+
+
+def real_genome_period(lib, device):
+    """The packed bytes (numpy uint8) of the reference's NZ_AAEN01000029 fixture, decoded by the HIP path itself and
+    packed again -- one period of the real-genome workload -- and its IUPAC characters."""
     import numpy as np
     here = os.path.dirname(os.path.abspath(__file__))
-    sys.path.insert(0, os.path.join(here, "tests"))
-    import zstd_ref                                                   # ctypes binding of libzstd.so.1 (test helper, no oracle)
-    if not zstd_ref.available():
-        return None
-    ffi = _ffi_mod()
-
-    def decode(blob):
-        opts = ffi.Opts()
-        lib.c.nafgpu_opts_default(ctypes.byref(opts))
-        opts.device = device
-        h, err, res = ctypes.c_void_p(), ffi.Error(), ffi.DeviceResult()
-        if lib.c.nafgpu_open_bytes(blob, len(blob), ctypes.byref(opts), ctypes.byref(h), ctypes.byref(err)) != 0:
-            raise RuntimeError("open failed: %s" % err.message.decode())
-        if lib.c.nafgpu_decode_all_device(h, ctypes.byref(res)) != 0:
-            lib.c.nafgpu_last_error(h, ctypes.byref(err))
-            raise RuntimeError("decode failed: %s" % err.message.decode())
-        return h, res
-
     blob = open(os.path.join(here, "tests", "golden", "NZ_AAEN01000029.naf"), "rb").read()
-    h, res = decode(blob)
+    h, res = _decode_bulk(lib, device, blob)
     seq = ctypes.create_string_buffer(int(res.n_bases))
     lib.c.nafgpu_copy_to_host(h, res.d_sequence, int(res.n_bases), ctypes.cast(seq, ctypes.c_void_p))
     lib.c.nafgpu_close(h)
@@ -169,6 +165,17 @@ def real_genome_leg(lib, device, copies):
         code[c] = i
     nib = code[chars]
     one = (nib[0::2] | (nib[1::2] << 4)).astype(np.uint8)
+    period = np.frombuffer(b"-TGKCYSBAWRDMHVN", dtype=np.uint8)[np.stack([one & 15, one >> 4], axis=1).reshape(-1)]
+    return one, period
+
+
+def real_genome_archive(one, copies):
+    """-> (archive bytes, compressed sequence payload length, bases): `one` tiled `copies` times, written by the system
+    libzstd at level 1 in streaming mode (what `ennaf` does): one Huffman tree per 128 KiB block, a few LZ sequences."""
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "tests"))
+    import zstd_ref                                                   # ctypes binding of libzstd.so.1 (test helper, no oracle)
     packed = np.tile(one, copies).tobytes()
     n_bases = 2 * len(packed)
 
@@ -181,14 +188,32 @@ def real_genome_leg(lib, device, copies):
         return bytes(reversed(out))
 
     payload = zstd_ref.compress_magicless(packed, 1, True)
+    del packed
     lens = b"".join((0xFFFFFFFF).to_bytes(4, "little") for _ in range(n_bases // 0xFFFFFFFF)) + (n_bases % 0xFFFFFFFF).to_bytes(4, "little")
     lenp = zstd_ref.compress_magicless(lens, 1, True)
     arc = (bytes([1, 0xF9, 0xEC, 1, 0x0A, 0x20]) + varint(60) + varint(1) + varint(len(lens)) + varint(len(lenp)) + lenp +
            varint(n_bases) + varint(len(payload)) + payload)
-    want = np.tile(np.frombuffer(b"-TGKCYSBAWRDMHVN", dtype=np.uint8)[np.stack([one & 15, one >> 4], axis=1).reshape(-1)], copies).tobytes()
+    return arc, len(payload), n_bases
+
+
+def real_genome_leg(lib, device, copies):
+    """Second measured workload (reported beside the headline, never as `value`): an archive with the block structure
+    `ennaf` gives real genomes -- the sequence of tests/golden/NZ_AAEN01000029.naf (the reference's own fixture: 5.5 Mbases,
+    IUPAC codes besides ACGT) tiled `copies` times and compressed by the system libzstd at level 1 in streaming mode: one
+    Huffman tree per 128 KiB block, a few LZ sequences per block.  The fixture is decoded by the HIP path itself; the
+    expected output of the tiled archive is the tiled output of the fixture (checksum compared)."""
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "tests"))
+    import zstd_ref
+    if not zstd_ref.available():
+        return None
+    one, period = real_genome_period(lib, device)
+    arc, payload_len, n_bases = real_genome_archive(one, copies)
+    want = np.tile(period, copies).tobytes()
     want_hash = lib.c.nafgpu_hash64_host(want, len(want))
-    del want, packed
-    h, res = decode(arc)
+    del want
+    h, res = _decode_bulk(lib, device, arc)
     try:
         best = None
         for _ in range(4):
@@ -200,16 +225,87 @@ def real_genome_leg(lib, device, copies):
         lib.c.nafgpu_hash64_device(h, res.d_sequence, res.n_bases, ctypes.byref(hs))
         if int(res.n_bases) != n_bases or hs.value != want_hash:
             raise RuntimeError("real-genome leg: GPU output differs from the tiled fixture")
-        alg = len(payload) + n_bases                                   # compressed bytes in, characters out
+        alg = payload_len + n_bases                                    # compressed bytes in, characters out
         gbs = alg / (best[0] * 1e-3) / 1e9
         return {"workload": "sequence of the reference fixture NZ_AAEN01000029 x %d, libzstd level 1 streaming (%d zstd blocks, one Huffman "
-                            "tree each, %d Huffman streams), bit-exact check passed" % (copies, res.n_zstd_blocks, res.n_huf_streams),
+                            "tree each, %d Huffman streams); output checksum equals the tiled fixture's" % (copies, res.n_zstd_blocks, res.n_huf_streams),
                 "bases": n_bases, "ms_per_step": round(best[0], 3), "value": round(n_bases / best[0] / 1e6, 1), "unit": "Gbases/s",
                 "ms_huf": round(best[1], 3), "ms_seq_lz": round(best[2], 3), "ms_other": round(best[3], 3),
                 "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": int(alg)}}
     finally:
         lib.c.nafgpu_close(h)
+
+
+def real_genome_sharded_leg(lib, dist, torch, tdev, device, rank, world, copies_per_gpu, steps=3, warmup=1):
+    """The real-genome workload over `world` ranks (SURVEY 8e for sections WITH LZ sequences): rank 0 writes ONE archive of
+    copies_per_gpu x world tiles into shared memory, every rank maps it and decodes its block range through the shard
+    protocol (nafcodec_amd.sharding.decode_sharded: one all-gather of 64 bytes, then the LZ windows point to point).
+    Every rank checks its share against the tiled fixture (position-keyed checksum of exactly its range)."""
+    import numpy as np
+    import shutil
+    import tempfile
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "tests"))
+    import zstd_ref
+    from nafcodec_amd.decoder import Decoder
+    from nafcodec_amd.sharding import decode_sharded
+    have = torch.tensor([1 if zstd_ref.available() else 0], dtype=torch.int64, device=tdev)
+    dist.all_reduce(have, op=dist.ReduceOp.MIN)
+    if int(have.item()) == 0:
+        return None
+    one, period = real_genome_period(lib, device)
+    copies = copies_per_gpu * world
+    path = os.path.join("/dev/shm" if shutil.disk_usage("/dev/shm").free > 3 * copies * len(one) else tempfile.gettempdir(),
+                        "nafgpu_bench_real_%s.naf" % os.environ.get("MASTER_PORT", "0"))
+    meta = torch.zeros(2, dtype=torch.int64, device=tdev)
+    if rank == 0:
+        arc, payload_len, n_bases = real_genome_archive(one, copies)
+        with open(path, "wb") as f:
+            f.write(arc)
+        del arc
+        meta = torch.tensor([payload_len, n_bases], dtype=torch.int64, device=tdev)
+    dist.broadcast(meta, src=0)
+    payload_len, n_bases = int(meta[0]), int(meta[1])
+    dec = Decoder(path, device=device, shard_rank=rank, shard_count=world, shard_protocol=True, _lib=lib)
+    dist.barrier()
+    if rank == 0:
+        os.unlink(path)                                     # (mapped by every rank: the pages stay)
+    try:
+        def sync():
+            dist.barrier()
+            if tdev == "cuda":
+                torch.cuda.synchronize()
+            lib.c.nafgpu_device_synchronize(device)
+        for _ in range(warmup):
+            res = decode_sharded(dec, dist, torch, tdev)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = decode_sharded(dec, dist, torch, tdev)
+        sync()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # this rank's share against the tiled fixture: bases [base_offset, base_offset + n) of the period repeated
+        P, off, n = len(period), int(res.base_offset) % len(period), int(res.n_bases)
+        want = np.tile(period, (off + n + P - 1) // P)[off:off + n].tobytes() if n else b""
+        ok = res.sharded == 1 and (n == 0 or res.base_offset % 4096 == 0)
+        ok = ok and dec.hash_device(res.d_sequence, n, int(res.base_offset) // 4096) == lib.c.nafgpu_hash64_host_at(want, n, int(res.base_offset) // 4096)
+        del want
+        tot = torch.tensor([n, 0 if ok else 1, int(res.seq_compressed_bytes)], dtype=torch.int64, device=tdev)
+        dist.all_reduce(tot)
+        if int(tot[1]) != 0 or int(tot[0]) != n_bases:
+            raise RuntimeError("real-genome leg, rank %d: the shards do not add up to the tiled fixture" % rank)
+        ms = 1e3 * elapsed / steps
+        alg = payload_len + n_bases
+        return {"workload": "sequence of the reference fixture NZ_AAEN01000029 x %d (%d per GPU), libzstd level 1 streaming, ONE archive, %d block ranges "
+                            "through the shard protocol (all-gather of 64 B + LZ windows point to point); every rank's share equals the tiled fixture's"
+                            % (copies, copies_per_gpu, world),
+                "n_gpus": world, "bases": n_bases, "steps": steps, "ms_per_step": round(ms, 3), "value": round(n_bases / ms / 1e6, 1), "unit": "Gbases/s",
+                "algorithmic_GBps": round(alg / (ms * 1e-3) / 1e9, 1), "compressed_bytes_read_by_all": int(tot[2])}
+    finally:
+        dec.close()
 
 
 def _ffi_mod():
@@ -232,7 +328,9 @@ def committed_traffic(n_bases):
                     j = json.load(f)
             except (OSError, ValueError):
                 continue
-            if "40e9 bases" in j.get("command", "") and n_bases == DEFAULT_BASES:
+            # the summary names the workload it was taken on (older ones: in the command text, the default size)
+            same = j.get("n_bases") == n_bases or ("n_bases" not in j and "40e9 bases" in j.get("command", "") and n_bases == DEFAULT_BASES)
+            if same:
                 best = int(j["FETCH_SIZE_bytes"] + j["WRITE_SIZE_bytes"])
     return best
 
@@ -407,6 +505,9 @@ def main():
         if not ok:
             raise RuntimeError("rank %d: decoded bases / offsets differ from the writer's checksums" % rank)
 
+    real_sharded = None
+    if world > 1 and args.real_copies_per_gpu:               # sections WITH LZ sequences over the same ranks (every rank takes part)
+        real_sharded = real_genome_sharded_leg(lib, dist, torch, tdev, device, rank, world, args.real_copies_per_gpu)
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = total_bases * args.steps / elapsed / 1e9
@@ -446,6 +547,8 @@ def main():
         }
         if args.real_copies and world == 1 and not args.rehearsal_lib:
             line["path"]["real_genome"] = real_genome_leg(lib, device, args.real_copies)
+        if real_sharded is not None:
+            line["path"]["real_genome"] = real_sharded
         if not args.no_cpu and world == 1:       # reported baseline, rank 0 at N=1 only
             line["cpu_baseline"], checked = cpu_baseline(lib, args.cpu_sample_bases, args.mask, device)
             line["config"]["oracle_checked_bases"] = checked

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NAFGPU_ABI_VERSION 1
+#define NAFGPU_ABI_VERSION 2
 
 /* ---- status / error kinds ------------------------------------------------
  * Mirrors nafcodec::Error (nafcodec/src/error.rs:4-11) plus the std::io kinds
@@ -80,7 +80,9 @@ typedef struct {
     uint8_t mask;                /* mod.rs:145  default 1 */
     uint8_t spec_mask;           /* 0 = reference behaviour incl. the record-end mask quirk
                                     (mod.rs:410-415); 1 = lower-case every masked base */
-    uint8_t reserved[2];
+    uint8_t shard_protocol;      /* 1: the decoder is driven through nafgpu_shard_* (below): sections WITH LZ sequences are
+                                    sharded too, and the Quality section as well as the Sequence section */
+    uint8_t reserved[1];
     uint64_t buffer_size;        /* mod.rs:110: accepted for API parity; sizes the host read-back window */
     int32_t device;              /* HIP device ordinal; -1 = current device */
     int32_t shard_rank;          /* multi-GPU: this process decodes shard `shard_rank` of `shard_count` */
@@ -195,6 +197,7 @@ typedef struct {
      * UTF-8 -- where the reference returns Error::Utf8 (reader.rs:108-109) or panics (mod.rs:362,368) */
     uint32_t utf8_invalid;
     uint32_t reserved4;
+    uint64_t quality_offset;     /* shard protocol: index in the Quality section of d_quality[0] (0 otherwise) */
 } nafgpu_device_result;
 
 int nafgpu_decode_all_device(nafgpu_decoder *dec, nafgpu_device_result *out);
@@ -202,6 +205,42 @@ int nafgpu_decode_all_device(nafgpu_decoder *dec, nafgpu_device_result *out);
  * Idempotent; decode_all_device / next call it implicitly.  Lets a caller separate "compressed
  * bytes resident in HBM" from the decode itself. */
 int nafgpu_upload(nafgpu_decoder *dec);
+
+/* ---- shard protocol: ONE archive over several GPUs, sections with LZ sequences included --------
+ * A section is one Zstandard frame: a block may copy from up to a window in front of it and inherits three repeat
+ * offsets.  Every rank (opts.shard_rank of opts.shard_count, opts.shard_protocol = 1) walks the whole block directory
+ * and decodes one contiguous block range; what a range needs from the ranges in front of it arrives in two steps:
+ *
+ *   nafgpu_shard_begin    entropy decode of the range (Huffman literals, FSE sequences), block sizes, and the range's
+ *                         repeat-offset map -- nothing here needs the other ranks.  Fills `mine`.
+ *   (all-gather of the 64-byte nafgpu_shard_summary: RCCL over xGMI; the only collective)
+ *   nafgpu_shard_place    every rank now knows where its range begins in the decoded section, which repeat offsets it
+ *                         inherits and how much of the window in front of it exists: literals to their places and all
+ *                         matches that do not reach -- directly or through other matches -- into that window.
+ *   nafgpu_shard_halo     how many bytes this rank receives from rank - 1 (recv_bytes) and sends to rank + 1
+ *                         (send_bytes: the last window of its output), and whether what it sends is final already
+ *                         (tail_ready; always 1 for the first rank and wherever no pending match touches the tail).
+ *   nafgpu_shard_export_tail / nafgpu_shard_import_halo    the point-to-point step (ncclSend / ncclRecv): a rank whose
+ *                         tail is ready sends first and receives afterwards, the others receive, finish, send.
+ *                         `dst` / `src` are device (or host) buffers of send_bytes / recv_bytes; import also runs what
+ *                         was waiting for the window.
+ *   nafgpu_shard_finish   mask, record table placement; the result describes this rank's share of the Sequence and the
+ *                         Quality sections (d_sequence / base_offset / n_bases, d_quality / quality_offset / n_quality).
+ * Sections without LZ sequences take the same calls (recv_bytes = send_bytes = 0).  `section`: 0 Sequence, 1 Quality. */
+typedef struct {
+    uint64_t decoded[2];         /* elements (decoded zstd bytes) of this rank's block range; [0] Sequence, [1] Quality */
+    uint64_t frame_tail[2];      /* of which: behind the start of the last frame that begins inside the range (all, if none does) */
+    uint32_t rep_map[2][3];      /* the range's repeat-offset map: the three offsets it leaves behind, as values or as
+                                    "inherited offset k minus d" tokens (plan.h: kRepToken) */
+    uint8_t failed[2];           /* the rank could not decode its range (every rank then reports the error) */
+    uint8_t reserved[6];
+} nafgpu_shard_summary;          /* 64 bytes, no pointers: gathered as it is */
+int nafgpu_shard_begin(nafgpu_decoder *dec, nafgpu_shard_summary *mine);
+int nafgpu_shard_place(nafgpu_decoder *dec, const nafgpu_shard_summary *all, int n_ranks);
+int nafgpu_shard_halo(nafgpu_decoder *dec, int section, uint64_t *recv_bytes, uint64_t *send_bytes, int *tail_ready);
+int nafgpu_shard_export_tail(nafgpu_decoder *dec, int section, void *dst, uint64_t n);
+int nafgpu_shard_import_halo(nafgpu_decoder *dec, int section, const void *src, uint64_t n);
+int nafgpu_shard_finish(nafgpu_decoder *dec, nafgpu_device_result *out);
 
 /* ---- text output on the device (what a consumer of the iterator does next, cf. unnaf) ----
  * FASTA, or FASTQ when the archive has a Quality section and opts.quality is set, of the records the
@@ -302,9 +341,13 @@ int nafgpu_hash64_device(const nafgpu_decoder *dec, const void *d_ptr, uint64_t 
 /* same, for a buffer that starts at 4 KiB chunk `first_chunk` of a larger object: the values of
  * consecutive shards add up (mod 2^64) to the checksum of the whole object */
 int nafgpu_hash64_device_at(const nafgpu_decoder *dec, const void *d_ptr, uint64_t n, uint64_t first_chunk, uint64_t *out);
+uint64_t nafgpu_hash64_host_at(const uint8_t *p, uint64_t n, uint64_t first_chunk);
 
 /* library / device identification, for logs */
 int nafgpu_abi_version(void);
+/* tests and measurements only: after nafgpu_test_hooks(1) the library reads its NAFGPU_* experiment variables
+ *  from the environment; by default it reads none of them. */
+void nafgpu_test_hooks(int enable);
 int nafgpu_device_info(int device, char *name, size_t cap, uint64_t *hbm_bytes, int *compute_units);
 
 #ifdef __cplusplus

@@ -25,7 +25,7 @@ class Error(Structure):
 
 class Opts(Structure):
     _fields_ = [("id", c_uint8), ("comment", c_uint8), ("sequence", c_uint8), ("quality", c_uint8),
-                ("mask", c_uint8), ("spec_mask", c_uint8), ("reserved", c_uint8 * 2),
+                ("mask", c_uint8), ("spec_mask", c_uint8), ("shard_protocol", c_uint8), ("reserved", c_uint8 * 1),
                 ("buffer_size", c_uint64), ("device", c_int32), ("shard_rank", c_int32),
                 ("shard_count", c_int32), ("tile_mib", c_int32)]
 
@@ -58,7 +58,13 @@ class DeviceResult(Structure):
                 ("n_huf_launches", c_uint32), ("reserved3", c_uint32), ("lz_residue_matches", c_uint64),
                 ("base_offset", c_uint64),
                 ("d_id_end", c_void_p), ("d_comment_end", c_void_p), ("n_ids", c_uint64), ("n_comments", c_uint64),
-                ("utf8_invalid", c_uint32), ("reserved4", c_uint32)]
+                ("utf8_invalid", c_uint32), ("reserved4", c_uint32), ("quality_offset", c_uint64)]
+
+
+class ShardSummary(Structure):
+    """nafgpu_shard_summary: 64 bytes, gathered over the ranks as it is."""
+    _fields_ = [("decoded", c_uint64 * 2), ("frame_tail", c_uint64 * 2), ("rep_map", (c_uint32 * 3) * 2),
+                ("failed", c_uint8 * 2), ("reserved", c_uint8 * 6)]
 
 
 class TextResult(Structure):
@@ -93,7 +99,9 @@ EXPORTS = [
     "nafgpu_upload", "nafgpu_device_synchronize", "nafgpu_hash64_device_at",
     "nafgpu_format_device", "nafgpu_copy_to_host", "nafgpu_synth_head",
     "nafgpu_encoder_opts_default", "nafgpu_encoder_opts_from_flags", "nafgpu_encoder_new", "nafgpu_encoder_push",
-    "nafgpu_encoder_finish", "nafgpu_encoder_free",
+    "nafgpu_encoder_finish", "nafgpu_encoder_free", "nafgpu_test_hooks",
+    "nafgpu_hash64_host_at", "nafgpu_shard_begin", "nafgpu_shard_place", "nafgpu_shard_halo", "nafgpu_shard_export_tail",
+    "nafgpu_shard_import_halo", "nafgpu_shard_finish",
 ]
 
 
@@ -141,11 +149,21 @@ class Library:
         L.nafgpu_synth_free.restype = None
         L.nafgpu_hash64_host.argtypes = [c_char_p, c_uint64]
         L.nafgpu_hash64_host.restype = c_uint64
+        L.nafgpu_hash64_host_at.argtypes = [c_char_p, c_uint64, c_uint64]
+        L.nafgpu_hash64_host_at.restype = c_uint64
         L.nafgpu_hash64_device.argtypes = [c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]
         L.nafgpu_hash64_device_at.argtypes = [c_void_p, c_void_p, c_uint64, c_uint64, POINTER(c_uint64)]
         L.nafgpu_device_info.argtypes = [c_int, c_char_p, c_size_t, POINTER(c_uint64), POINTER(c_int)]
         L.nafgpu_format_device.argtypes = [c_void_p, POINTER(TextResult)]
         L.nafgpu_copy_to_host.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p]
+        L.nafgpu_shard_begin.argtypes = [c_void_p, POINTER(ShardSummary)]
+        L.nafgpu_shard_place.argtypes = [c_void_p, c_void_p, c_int]
+        L.nafgpu_shard_halo.argtypes = [c_void_p, c_int, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_int)]
+        L.nafgpu_shard_export_tail.argtypes = [c_void_p, c_int, c_void_p, c_uint64]
+        L.nafgpu_shard_import_halo.argtypes = [c_void_p, c_int, c_void_p, c_uint64]
+        L.nafgpu_shard_finish.argtypes = [c_void_p, POINTER(DeviceResult)]
+        L.nafgpu_test_hooks.argtypes = [c_int]
+        L.nafgpu_test_hooks.restype = None
 
     # ---- helpers ---------------------------------------------------------------------------
     def zstd_decompress(self, payload: bytes, size: int, device: int = -1) -> bytes:

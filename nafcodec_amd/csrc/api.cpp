@@ -141,12 +141,13 @@ struct nafgpu_decoder {
 namespace {
 
 Failure ensure_uploaded(nafgpu_decoder *d, bool for_iterator);
+Failure after_decode(nafgpu_decoder *d);
 
-// Decoded output of this many bytes per tile (0: no tiling): nafgpu_opts.tile_mib, NAFGPU_TILE_MIB, or -- when the
+// Decoded output of this many bytes per tile (0: no tiling): nafgpu_opts.tile_mib (tests: NAFGPU_TILE_KIB), or -- when the
 // selected sections would not fit beside each other in the device's free memory -- a sixteenth of that memory.
 uint64_t tile_blocks_for(const nafgpu_decoder *d) {
     uint64_t tile_bytes = static_cast<uint64_t>(d->opts.tile_mib > 0 ? d->opts.tile_mib : 0) << 20;
-    if (const char *e = std::getenv("NAFGPU_TILE_KIB")) tile_bytes = std::strtoull(e, nullptr, 10) << 10;   // tests: tiles far below a MiB
+    if (const char *e = hook_env("NAFGPU_TILE_KIB")) tile_bytes = std::strtoull(e, nullptr, 10) << 10;   // tests: tiles far below a MiB
     if (!tile_bytes) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
@@ -170,26 +171,8 @@ Failure ensure_decoded(nafgpu_decoder *d, bool for_iterator) {
     if (!f.ok()) return f;
     f = d->job.decode();
     if (!f.ok()) return d->fatal = f;
-    // small sections come back to the host whole; sequence / quality through sliding windows
-    auto fetch = [&](int s, std::vector<uint8_t> *dst) -> Failure {
-        if (!d->job.job(s).ready() || !d->job.section_failure(s).ok()) return Failure();
-        dst->resize(static_cast<size_t>(d->job.section_size(s)));
-        return d->job.copy_to_host(dst->data(), d->job.d_section(s), dst->size());
-    };
-    if (!(f = fetch(kIds, &d->ids)).ok()) return d->fatal = f;
-    if (!(f = fetch(kComments, &d->comments)).ok()) return d->fatal = f;
-    if (d->job.job(kLengths).ready() && d->job.section_failure(kLengths).ok()) {
-        d->rec_ends.resize(static_cast<size_t>(d->job.n_records()));
-        f = d->job.copy_to_host(d->rec_ends.data(), d->job.d_rec_ends(), d->rec_ends.size() * sizeof(uint64_t));
-        if (!f.ok()) return d->fatal = f;
-    }
-    const uint64_t window = std::max<uint64_t>(d->opts.buffer_size, uint64_t(64) << 20);
-    d->seq_win.bind(&d->job, kSequence, d->header.sequence_type <= 1 ? 2 : 1, d->job.n_sequence_bytes(), window);
-    d->qual_win.bind(&d->job, kQuality, 1, d->job.section_size(kQuality), window);
-    // MaskReader yields units until their sum reaches the nucleotide count (reader.rs:200-202);
-    // a record ending beyond what the units cover raises "failed to get mask unit" (mod.rs:430-435)
-    const uint64_t total = d->sec[kSequence].present ? d->sec[kSequence].original_size : 0;
-    d->mask_covered = d->job.mask_sum() >= total ? UINT64_MAX : d->job.mask_sum();
+    f = after_decode(d);
+    if (!f.ok()) return f;
     d->decoded = true;
     return Failure();
 }
@@ -208,6 +191,7 @@ Failure ensure_uploaded(nafgpu_decoder *d, bool for_iterator) {
         ao.spec_mask = d->opts.spec_mask != 0;
         ao.shard_count = d->opts.shard_count > 1 ? static_cast<uint32_t>(d->opts.shard_count) : 1u;
         ao.shard_rank = d->opts.shard_rank > 0 ? static_cast<uint32_t>(d->opts.shard_rank) : 0u;
+        ao.shard_protocol = d->opts.shard_protocol != 0 && ao.shard_count > 1;
         d->tile_blocks = tile_blocks_for(d);
         d->tiled_output = d->tile_blocks != 0 && for_iterator;
         ao.tile_blocks = d->tile_blocks;
@@ -278,6 +262,86 @@ Failure errno_failure(const char *what, int e) {
     else if (e == EISDIR) kind = NAFGPU_IO_IS_A_DIRECTORY;
     else if (e == EACCES || e == EPERM) kind = NAFGPU_IO_PERMISSION_DENIED;
     return Failure::io(kind, std::string(what) + ": " + std::strerror(e), e);
+}
+
+// the small sections and the record table come back to the host; windows over sequence / quality are bound
+Failure after_decode(nafgpu_decoder *d) {
+    Failure f;
+    auto fetch = [&](int s, std::vector<uint8_t> *dst) -> Failure {
+        if (!d->job.job(s).ready() || !d->job.section_failure(s).ok()) return Failure();
+        dst->resize(static_cast<size_t>(d->job.section_size(s)));
+        return d->job.copy_to_host(dst->data(), d->job.d_section(s), dst->size());
+    };
+    if (!(f = fetch(kIds, &d->ids)).ok()) return d->fatal = f;
+    if (!(f = fetch(kComments, &d->comments)).ok()) return d->fatal = f;
+    if (d->job.job(kLengths).ready() && d->job.section_failure(kLengths).ok()) {
+        d->rec_ends.resize(static_cast<size_t>(d->job.n_records()));
+        f = d->job.copy_to_host(d->rec_ends.data(), d->job.d_rec_ends(), d->rec_ends.size() * sizeof(uint64_t));
+        if (!f.ok()) return d->fatal = f;
+    }
+    const uint64_t window = std::max<uint64_t>(d->opts.buffer_size, uint64_t(64) << 20);
+    d->seq_win.bind(&d->job, kSequence, d->header.sequence_type <= 1 ? 2 : 1, d->job.n_sequence_bytes(), window);
+    d->qual_win.bind(&d->job, kQuality, 1, d->job.section_size(kQuality), window);
+    // MaskReader yields units until their sum reaches the nucleotide count (reader.rs:200-202);
+    // a record ending beyond what the units cover raises "failed to get mask unit" (mod.rs:430-435)
+    const uint64_t total = d->sec[kSequence].present ? d->sec[kSequence].original_size : 0;
+    d->mask_covered = d->job.mask_sum() >= total ? UINT64_MAX : d->job.mask_sum();
+    return Failure();
+}
+
+void fill_result(nafgpu_decoder *d, nafgpu_device_result *out) {
+    std::memset(out, 0, sizeof *out);
+    const ArchiveJob &j = d->job;
+    out->d_sequence = d->use[kSequence] ? j.d_sequence() : nullptr;
+    const bool nuc = d->header.sequence_type <= 1;
+    // bases held by this decoder: the whole section, or (sharded) global bases [base0, base1)
+    const uint64_t total_bases = d->use[kSequence] ? (nuc ? d->sec[kSequence].original_size : j.job(kSequence).total_size()) : 0;
+    const uint64_t base0 = std::min(j.sequence_offset(), total_bases);
+    const uint64_t base1 = std::min(j.sequence_offset() + j.n_sequence_bytes(), total_bases);
+    out->n_bases = base1 - base0;
+    out->base_offset = base0;
+    out->sharded = j.job(kSequence).ready() && j.job(kSequence).sharded() ? 1 : 0;
+    if (d->use[kLengths] && !d->rec_ends.empty()) {
+        // first record that STARTS in this shard (start_k = end_{k-1}); carry: the shard begins inside a record
+        const auto it = std::lower_bound(d->rec_ends.begin(), d->rec_ends.end(), base0);   // first end >= base0
+        uint64_t k = static_cast<uint64_t>(it - d->rec_ends.begin());                     // records ending before base0 ... k-1
+        const bool at_start = base0 == 0 || (k > 0 && d->rec_ends[k - 1] == base0) || (it != d->rec_ends.end() && *it == base0);
+        if (it != d->rec_ends.end() && *it == base0) k += 1;      // record k ends exactly here: the next one starts here
+        out->carry = at_start ? 0 : 1;
+        out->first_record = at_start ? k : k + 1;
+    }
+    out->d_quality = j.d_section(kQuality);
+    out->n_quality = j.section_size(kQuality);
+    out->d_record_end = d->use[kLengths] ? j.d_rec_ends() : nullptr;
+    out->n_records = j.n_records();
+    out->d_ids = j.d_section(kIds);
+    out->n_ids_bytes = j.section_size(kIds);
+    out->d_comments = j.d_section(kComments);
+    out->n_comments_bytes = j.section_size(kComments);
+    out->packed_bytes = j.packed_bytes();
+    out->compressed_bytes = j.compressed_bytes();
+    // compressed bytes of the sequence section this process reads: its block range's when the section is sharded
+    out->seq_compressed_bytes = !d->use[kSequence] ? 0
+                                : (j.job(kSequence).ready() && j.job(kSequence).n_tiles() == 1 ? j.job(kSequence).source_bytes()
+                                                                                              : d->sec[kSequence].compressed_size);
+    out->n_zstd_blocks = j.job(kSequence).n_blocks();
+    out->n_huf_streams = j.job(kSequence).n_streams();
+    const StageTimes &t = j.times();
+    out->ms_total = t.total;
+    out->ms_huf = t.huf;
+    out->ms_unpack = t.unpack;
+    out->ms_seq_lz = t.seq_lz;
+    out->ms_other = t.other;
+    out->n_huf_launches = t.huf_launches;
+    for (int s = 0; s < kNumSections; s++) out->lz_residue_matches += j.job(s).lz_residue();
+    out->ms_host_plan = j.host_plan_ms();
+    out->ms_h2d = j.h2d_ms();
+    out->d_id_end = d->use[kIds] ? j.d_id_ends() : nullptr;
+    out->d_comment_end = d->use[kComments] ? j.d_com_ends() : nullptr;
+    out->n_ids = d->use[kIds] ? j.n_ids() : 0;
+    out->n_comments = d->use[kComments] ? j.n_comments() : 0;
+    out->utf8_invalid = j.utf8_invalid();
+    out->quality_offset = j.quality_offset();
 }
 
 }  // namespace
@@ -370,7 +434,11 @@ int nafgpu_open_path(const char *path, const nafgpu_opts *opts, nafgpu_decoder *
         ::close(fd);
         if (!buf.empty()) {
             void *m = mmap(nullptr, buf.size(), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-            if (m == MAP_FAILED) return NAFGPU_E_DEVICE;
+            if (m == MAP_FAILED) {
+                Failure f = errno_failure("mmap", errno);
+                f.to_c(err);
+                return f.status;
+            }
             std::memcpy(m, buf.data(), buf.size());
             d->map = m;
             d->map_len = buf.size();
@@ -420,7 +488,7 @@ int nafgpu_open_io(nafgpu_read_fn read, nafgpu_seek_fn seek, void *ctx, const na
         }
         if (!buf.empty()) {
             void *m = mmap(nullptr, buf.size(), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-            if (m == MAP_FAILED) return NAFGPU_E_DEVICE;
+            if (m == MAP_FAILED) return io_fail("mmap", -static_cast<int64_t>(errno));
             std::memcpy(m, buf.data(), buf.size());
             d->map = m;
             d->map_len = buf.size();
@@ -432,7 +500,7 @@ int nafgpu_open_io(nafgpu_read_fn read, nafgpu_seek_fn seek, void *ctx, const na
     const size_t total = static_cast<size_t>(end - pos0);
     if (total == 0) return open_common(std::move(d), out, err);
     void *m = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-    if (m == MAP_FAILED) return NAFGPU_E_DEVICE;
+    if (m == MAP_FAILED) return io_fail("mmap", -static_cast<int64_t>(errno));
     d->map = m;
     d->map_len = total;
     d->bytes = static_cast<const uint8_t *>(m);
@@ -551,62 +619,88 @@ int nafgpu_next(nafgpu_decoder *d, nafgpu_record *rec) {
 
 int nafgpu_decode_all_device(nafgpu_decoder *d, nafgpu_device_result *out) {
     if (!d || !out) return NAFGPU_E_INVALID_ARG;
+    if (d->opts.shard_protocol && d->opts.shard_count > 1)
+        return fail(d, Failure::make(NAFGPU_E_INVALID_ARG, "this decoder was opened for the shard protocol: use nafgpu_shard_begin / _place / _finish"));
     d->decoded = false;                                                    // every call re-runs the kernels
     Failure f = ensure_decoded(d, false);
     if (!f.ok()) return fail(d, f);
     for (int s = 0; s < kNumSections; s++)
         if (d->use[s] && !d->job.section_failure(s).ok()) return fail(d, d->job.section_failure(s));
-    std::memset(out, 0, sizeof *out);
-    const ArchiveJob &j = d->job;
-    out->d_sequence = d->use[kSequence] ? j.d_sequence() : nullptr;
-    const bool nuc = d->header.sequence_type <= 1;
-    // bases held by this decoder: the whole section, or (sharded) global bases [base0, base1)
-    const uint64_t total_bases = d->use[kSequence] ? (nuc ? d->sec[kSequence].original_size : j.job(kSequence).total_size()) : 0;
-    const uint64_t base0 = std::min(j.sequence_offset(), total_bases);
-    const uint64_t base1 = std::min(j.sequence_offset() + j.n_sequence_bytes(), total_bases);
-    out->n_bases = base1 - base0;
-    out->base_offset = base0;
-    out->sharded = j.job(kSequence).ready() && j.job(kSequence).sharded() ? 1 : 0;
-    if (d->use[kLengths] && !d->rec_ends.empty()) {
-        // first record that STARTS in this shard (start_k = end_{k-1}); carry: the shard begins inside a record
-        const auto it = std::lower_bound(d->rec_ends.begin(), d->rec_ends.end(), base0);   // first end >= base0
-        uint64_t k = static_cast<uint64_t>(it - d->rec_ends.begin());                     // records ending before base0 ... k-1
-        const bool at_start = base0 == 0 || (k > 0 && d->rec_ends[k - 1] == base0) || (it != d->rec_ends.end() && *it == base0);
-        if (it != d->rec_ends.end() && *it == base0) k += 1;      // record k ends exactly here: the next one starts here
-        out->carry = at_start ? 0 : 1;
-        out->first_record = at_start ? k : k + 1;
+    fill_result(d, out);
+    return NAFGPU_OK;
+}
+
+// ---- the shard protocol (include/nafgpu.h) -------------------------------------------------------------------------
+int nafgpu_shard_begin(nafgpu_decoder *d, nafgpu_shard_summary *mine) {
+    if (!d || !mine) return NAFGPU_E_INVALID_ARG;
+    if (!d->opts.shard_protocol || d->opts.shard_count <= 1)
+        return fail(d, Failure::make(NAFGPU_E_INVALID_ARG, "the shard protocol needs opts.shard_protocol = 1 and shard_count > 1"));
+    if (!d->fatal.ok()) return fail(d, d->fatal);
+    d->decoded = false;
+    Failure f = ensure_uploaded(d, false);
+    if (!f.ok()) return fail(d, f);
+    ShardSummary m[2];
+    f = d->job.shard_begin(m);
+    if (!f.ok()) return fail(d, f.status == NAFGPU_E_DEVICE ? (d->fatal = f) : f);
+    std::memset(mine, 0, sizeof *mine);
+    for (int w = 0; w < 2; w++) {
+        mine->decoded[w] = m[w].decoded;
+        mine->frame_tail[w] = m[w].frame_tail;
+        for (int k = 0; k < 3; k++) mine->rep_map[w][k] = m[w].rep_map[k];
+        mine->failed[w] = m[w].failed ? 1 : 0;
     }
-    out->d_quality = j.d_section(kQuality);
-    out->n_quality = j.section_size(kQuality);
-    out->d_record_end = d->use[kLengths] ? j.d_rec_ends() : nullptr;
-    out->n_records = j.n_records();
-    out->d_ids = j.d_section(kIds);
-    out->n_ids_bytes = j.section_size(kIds);
-    out->d_comments = j.d_section(kComments);
-    out->n_comments_bytes = j.section_size(kComments);
-    out->packed_bytes = j.packed_bytes();
-    out->compressed_bytes = j.compressed_bytes();
-    // compressed bytes of the sequence section this process reads: its block range's when the section is sharded
-    out->seq_compressed_bytes = !d->use[kSequence] ? 0
-                                : (j.job(kSequence).ready() && j.job(kSequence).n_tiles() == 1 ? j.job(kSequence).source_bytes()
-                                                                                              : d->sec[kSequence].compressed_size);
-    out->n_zstd_blocks = j.job(kSequence).n_blocks();
-    out->n_huf_streams = j.job(kSequence).n_streams();
-    const StageTimes &t = j.times();
-    out->ms_total = t.total;
-    out->ms_huf = t.huf;
-    out->ms_unpack = t.unpack;
-    out->ms_seq_lz = t.seq_lz;
-    out->ms_other = t.other;
-    out->n_huf_launches = t.huf_launches;
-    for (int s = 0; s < kNumSections; s++) out->lz_residue_matches += j.job(s).lz_residue();
-    out->ms_host_plan = j.host_plan_ms();
-    out->ms_h2d = j.h2d_ms();
-    out->d_id_end = d->use[kIds] ? j.d_id_ends() : nullptr;
-    out->d_comment_end = d->use[kComments] ? j.d_com_ends() : nullptr;
-    out->n_ids = d->use[kIds] ? j.n_ids() : 0;
-    out->n_comments = d->use[kComments] ? j.n_comments() : 0;
-    out->utf8_invalid = j.utf8_invalid();
+    return NAFGPU_OK;
+}
+
+int nafgpu_shard_place(nafgpu_decoder *d, const nafgpu_shard_summary *all, int n_ranks) {
+    if (!d || !all || n_ranks != d->opts.shard_count) return NAFGPU_E_INVALID_ARG;
+    std::vector<ShardSummary> sq(static_cast<size_t>(n_ranks)), ql(static_cast<size_t>(n_ranks));
+    for (int r = 0; r < n_ranks; r++)
+        for (int w = 0; w < 2; w++) {
+            ShardSummary &t = w == 0 ? sq[static_cast<size_t>(r)] : ql[static_cast<size_t>(r)];
+            t.decoded = all[r].decoded[w];
+            t.frame_tail = all[r].frame_tail[w];
+            for (int k = 0; k < 3; k++) t.rep_map[k] = all[r].rep_map[w][k];
+            t.failed = all[r].failed[w] != 0;
+        }
+    Failure f = d->job.shard_place(sq.data(), ql.data(), static_cast<uint32_t>(n_ranks));
+    if (!f.ok()) return fail(d, f.status == NAFGPU_E_DEVICE ? (d->fatal = f) : f);
+    return NAFGPU_OK;
+}
+
+int nafgpu_shard_halo(nafgpu_decoder *d, int section, uint64_t *recv_bytes, uint64_t *send_bytes, int *tail_ready) {
+    if (!d || !recv_bytes || !send_bytes || !tail_ready || section < 0 || section > 1) return NAFGPU_E_INVALID_ARG;
+    bool ready = true;
+    Failure f = d->job.shard_halo(section, recv_bytes, send_bytes, &ready);
+    *tail_ready = ready ? 1 : 0;
+    if (!f.ok()) return fail(d, f.status == NAFGPU_E_DEVICE ? (d->fatal = f) : f);
+    return NAFGPU_OK;
+}
+
+int nafgpu_shard_export_tail(nafgpu_decoder *d, int section, void *dst, uint64_t n) {
+    if (!d || section < 0 || section > 1 || (n && !dst)) return NAFGPU_E_INVALID_ARG;
+    Failure f = d->job.shard_export(section, dst, n);
+    if (!f.ok()) return fail(d, f.status == NAFGPU_E_DEVICE ? (d->fatal = f) : f);
+    return NAFGPU_OK;
+}
+
+int nafgpu_shard_import_halo(nafgpu_decoder *d, int section, const void *src, uint64_t n) {
+    if (!d || section < 0 || section > 1 || (n && !src)) return NAFGPU_E_INVALID_ARG;
+    Failure f = d->job.shard_import(section, src, n);
+    if (!f.ok()) return fail(d, f.status == NAFGPU_E_DEVICE ? (d->fatal = f) : f);
+    return NAFGPU_OK;
+}
+
+int nafgpu_shard_finish(nafgpu_decoder *d, nafgpu_device_result *out) {
+    if (!d || !out) return NAFGPU_E_INVALID_ARG;
+    Failure f = d->job.shard_finish();
+    if (!f.ok()) return fail(d, d->fatal = f);
+    f = after_decode(d);
+    if (!f.ok()) return fail(d, f);
+    d->decoded = true;
+    for (int s = 0; s < kNumSections; s++)
+        if (d->use[s] && !d->job.section_failure(s).ok()) return fail(d, d->job.section_failure(s));
+    fill_result(d, out);
     return NAFGPU_OK;
 }
 
@@ -657,6 +751,8 @@ int nafgpu_hash64_device_at(const nafgpu_decoder *d, const void *d_ptr, uint64_t
 }
 
 uint64_t nafgpu_hash64_host(const uint8_t *p, uint64_t n) { return hash64_host(p, n); }
+
+uint64_t nafgpu_hash64_host_at(const uint8_t *p, uint64_t n, uint64_t first_chunk) { return hash64_host(p, n, first_chunk); }
 
 int nafgpu_zstd_decompress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *produced, int device,
                            nafgpu_error *err) {
@@ -709,6 +805,8 @@ int nafgpu_zstd_decompress(const uint8_t *src, size_t n, uint8_t *dst, size_t ca
 }
 
 int nafgpu_abi_version(void) { return NAFGPU_ABI_VERSION; }
+
+void nafgpu_test_hooks(int enable) { set_test_hooks(enable != 0); }
 
 int nafgpu_device_info(int device, char *name, size_t cap, uint64_t *hbm_bytes, int *compute_units) {
     int count = 0;

@@ -4,10 +4,15 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <atomic>
 #include <chrono>
 #include <cstring>
 
 namespace nafgpu {
+
+static std::atomic<bool> g_test_hooks{false};
+void set_test_hooks(bool on) { g_test_hooks.store(on); }
+const char *hook_env(const char *name) { return g_test_hooks.load() ? std::getenv(name) : nullptr; }
 
 namespace {
 inline bool hip_ok(hipError_t e) { return e == hipSuccess; }
@@ -148,33 +153,64 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
     if ((master_.seq_blocks.empty() && master_.known_out != expect_size) ||
         expect_size > static_cast<uint64_t>(master_.blk_size.size()) * kBlockMax)     // untrusted: no block decodes to more than 128 KiB
         return Failure::io(NAFGPU_IO_INVALID_DATA, "zstd: decoded size differs from the size recorded in the archive");
-    // ---- this process's block range (a shard of a section without LZ sequences, else everything)
+    // ---- this process's block range: a shard of a section without LZ sequences -- or, when the ranks run the shard
+    // protocol, of any section -- else everything
     uint32_t b0 = 0, b1 = static_cast<uint32_t>(master_blocks_);
-    sharded_ = shard_range(master_, opt.shard_rank, opt.shard_count, &b0, &b1);
+    sharded_ = shard_range(master_, opt.shard_rank, opt.shard_count, &b0, &b1, opt.shard_protocol);
+    has_lz_ = !master_.seq_blocks.empty();
+    proto_lz_ = sharded_ && opt.shard_protocol && has_lz_;
     out0_ = 0;
     out1_ = expect_size;
-    if (sharded_) {
+    if (sharded_ && !has_lz_) {
         for (uint32_t b = 0; b < b0; b++) out0_ += master_.blk_size[b];
         out1_ = out0_;
         for (uint32_t b = b0; b < b1; b++) out1_ += master_.blk_size[b];
     }
+    ranges_.clear();
+    frame_first_.clear();
+    seq_blk_.clear();
+    seq_frame_.clear();
+    if (sharded_ && opt.shard_protocol) {                  // what the placement needs of the walk once the master plan is gone
+        for (uint32_t r = 0; r < opt.shard_count; r++) {
+            uint32_t a = 0, e = 0;
+            shard_range(master_, r, opt.shard_count, &a, &e, true);
+            ranges_.push_back({a, e});
+        }
+        for (const ZPlan::Frame &f : master_.frames) frame_first_.push_back(f.first_blk);
+        for (const SeqBlock &sb : master_.seq_blocks) {
+            seq_blk_.push_back(sb.blk);
+            seq_frame_.push_back(sb.frame_first_blk);
+        }
+    }
+    if (proto_lz_) {                                       // where the range begins in the decoded section is learnt from the other ranks
+        out0_ = out1_ = 0;
+        decoded_ = 0;
+    }
     // ---- tiles
-    const uint64_t tb = opt.tile_blocks ? opt.tile_blocks : (static_cast<uint64_t>(b1 - b0) ? b1 - b0 : 1);
+    // (a range that exchanges windows with its neighbours is decoded in one piece)
+    const uint64_t tb = opt.tile_blocks && !proto_lz_ ? opt.tile_blocks : (static_cast<uint64_t>(b1 - b0) ? b1 - b0 : 1);
     for (uint64_t b = b0; b < b1 || tiles_.empty(); b += tb) {
         tiles_.push_back(Tile{static_cast<uint32_t>(b), static_cast<uint32_t>(std::min<uint64_t>(b + tb, b1))});
         if (b1 == b0) break;
     }
-    has_lz_ = !master_.seq_blocks.empty();
     sec_known_ = master_.known_out;
     sec_seqs_ = master_.n_sequences;
     const bool lz = has_lz_;
     // the window of a tile that follows another: its matches may reach that far back
-    halo_cap_ = (lz && tiles_.size() > 1) ? std::min<uint64_t>(std::max<uint64_t>(master_.window_max, 1), expect_size) : 0;
+    halo_cap_ = (lz && (tiles_.size() > 1 || (proto_lz_ && b0 > 0))) ? std::min<uint64_t>(std::max<uint64_t>(master_.window_max, 1), expect_size) : 0;
     if (halo_cap_ > 0xF0000000ull) return Failure::io(NAFGPU_IO_INVALID_DATA, "zstd: window too large to decode in tiles");
     tile_cap_ = 0;
     const uint64_t mult = t_char_ ? 2 : 1;
-    bool ok = d_status_.alloc(64) && d_counters_.alloc(128);
-    if (tiled_output()) {
+    out_shift_ = 0;
+    halo_pending_ = false;
+    lz_args_valid_ = false;
+    send_elems_ = 0;
+    bool ok = d_status_.alloc(64) && d_counters_.alloc(256);
+    if (proto_lz_) {
+        // [room for the window in front][the range: at most a full block per block]
+        out_shift_ = halo_cap_ * mult;
+        ok = ok && d_out_.alloc_items(halo_cap_ + static_cast<uint64_t>(b1 - b0) * kBlockMax, mult, 64);
+    } else if (tiled_output()) {
         uint64_t most = 0;
         for (const Tile &t : tiles_) most = std::max<uint64_t>(most, t.b1 - t.b0);
         tile_cap_ = most * kBlockMax;
@@ -208,6 +244,7 @@ Failure SectionJob::load_tile(uint32_t t, hipStream_t stream) {
     const bool lz = has_lz_;
     // LZ window in front of the tile: min(window, decoded so far in this process's range)
     halo_elems_ = (lz && t > 0) ? std::min<uint64_t>(halo_cap_, tile_pos0_ - out0_) : 0;
+    if (proto_lz_) halo_elems_ = 0;                        // (learnt in shard_place; the pseudo block is there from the start)
     const double t0 = now_ms();
     if (tiles_.size() == 1 && !sharded_) {
         plan_ = std::move(master_);                        // the whole section: nothing to re-base, nothing selected again
@@ -216,7 +253,7 @@ Failure SectionJob::load_tile(uint32_t t, hipStream_t stream) {
         plan_.src_hi = plan_.blk_off.empty() ? 0 : plan_.blk_off.back();
         pack_tasks_public(&plan_);
     } else {
-        select_zplan(master_, tile.b0, tile.b1, halo_elems_, &plan_);
+        select_zplan(master_, tile.b0, tile.b1, halo_elems_, &plan_, proto_lz_ && halo_cap_ != 0);
     }
     plan_ms_ += static_cast<float>(now_ms() - t0);
     n_blocks_ = plan_.blk_size.size();
@@ -243,7 +280,7 @@ Failure SectionJob::load_tile(uint32_t t, hipStream_t stream) {
         }
         xxh_live_ = live;
     }
-    if (std::getenv("NAFGPU_DEBUG_PLAN")) {
+    if (hook_env("NAFGPU_DEBUG_PLAN")) {
         std::fprintf(stderr, "[nafgpu] section plan: tile %u of %zu, %zu blocks, %zu streams, %zu seq blocks, %llu sequences, literal buffer %llu B, source %llu B; task classes:",
                      t, tiles_.size(), n_blocks_, n_streams_, n_seq_blocks_, static_cast<unsigned long long>(plan_.n_sequences),
                      static_cast<unsigned long long>(plan_.lit_bytes), static_cast<unsigned long long>(plan_.src_hi - plan_.src_lo));
@@ -298,6 +335,19 @@ Failure SectionJob::load_tile(uint32_t t, hipStream_t stream) {
 // tile at a time -- the last window bytes the tiles before it left.
 Failure SectionJob::decode_tile(uint32_t t, hipStream_t stream, StageTimer *timer, hipStream_t aux) {
     if (!ready_) return Failure();
+    if (t == 0 && tiles_done_ != 0) {
+        // a new pass over the section (nafgpu_decode_all_device re-runs the kernels on every call): everything the
+        // tiles carry from one to the next goes back to its state in front of the first
+        tiles_done_ = 0;
+        tile_pos0_ = out0_;
+        tile_len_ = 0;
+        rep_carry_[0] = 1;
+        rep_carry_[1] = 4;
+        rep_carry_[2] = 8;
+        carry_frame_ = 0xFFFFFFFFu;
+        carry_same_frame_ = false;
+        xxh_live_ = false;
+    }
     if (t >= tiles_.size() || t != tiles_done_) return Failure::make(NAFGPU_E_INVALID_ARG, "tiles are decoded in order");
     const uint64_t mult = t_char_ ? 2 : 1;
     if (t > 0) {
@@ -346,7 +396,7 @@ Failure SectionJob::decode_tile(uint32_t t, hipStream_t stream, StageTimer *time
 // address the output as base + blk_base[block] + offset inside the block.
 uint8_t *SectionJob::tile_out_base() const {
     const uint64_t mult = t_char_ ? 2 : 1;
-    if (tiled_output()) return d_out_.bytes() + (halo_cap_ - halo_elems_) * mult;
+    if (tiled_output() || proto_lz_) return d_out_.bytes() + (halo_cap_ - halo_elems_) * mult;
     return d_out_.bytes() + (tile_pos0_ - halo_elems_ - out0_) * mult;
 }
 
@@ -376,15 +426,17 @@ void SectionJob::run_k2_ahead(hipStream_t st) {
 
 void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
     if (!ready_) return;
+    bool early = false;
+    run_front(stream, timer, aux, &early);
+    run_back(stream, timer, aux, early, 0);
+}
+
+// What needs nothing but the compressed bytes: the status reset, K1's classes bound for the literal buffer (on `aux`), K2.
+void SectionJob::run_front(hipStream_t stream, StageTimer *timer, hipStream_t aux, bool *early_out) {
     uint32_t *status = d_status_.as<uint32_t>();
     const bool k2_done = k2_ahead_ && hip_ok(hipStreamWaitEvent(stream, ev_k2_, 0));
     k2_ahead_ = false;
     if (!k2_done) (void)hipMemsetAsync(status, 0, 64, stream);
-    auto launch_class = [&](const HufClass &c, hipStream_t st, uint8_t *out_base) {
-        launch_huf_decode(st, d_src_, d_tasks_.as<HufTask>(), c, d_tbl_copies_.as<HufTblCopy>(), d_streams_.as<HufStream>(),
-                          d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(), d_seq_blocks_.as<SeqBlock>(),
-                          d_seqs_.as<Seq>(), d_dicts_.bytes(), t_char_ != 0, t_char_, status);
-    };
     // Streams bound for the literal buffer need nothing from K2 (their destinations are the plan's): they start on `aux`
     // now, beside k_seq_states -- a chain per block that keeps one wave per CU busy and leaves the rest of the chip idle.
     bool early = false;
@@ -398,7 +450,10 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
                     hip_ok(hipStreamWaitEvent(aux, ev_early_fork_, 0));
             if (early) {
                 for (const HufClass &c : classes_)
-                    if (c.to_lit) launch_class(c, aux, nullptr);
+                    if (c.to_lit)
+                        launch_huf_decode(aux, d_src_, d_tasks_.as<HufTask>(), c, d_tbl_copies_.as<HufTblCopy>(), d_streams_.as<HufStream>(),
+                                          d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), nullptr, d_lit_.bytes(), d_seq_blocks_.as<SeqBlock>(),
+                                          d_seqs_.as<Seq>(), d_dicts_.bytes(), t_char_ != 0, t_char_, status);
                 (void)hipEventRecord(ev_early_join_, aux);
             }
         }
@@ -412,9 +467,95 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
                           status);
         if (timer) timer->end(stream);
     }
+    *early_out = early;
+}
+
+// The arguments of K4 for the loaded selection (phase: see LzArgs); allocates the scratch of the chosen route.
+void SectionJob::fill_lz_args(LzArgs *out, uint32_t phase) {
+    uint32_t *status = d_status_.as<uint32_t>();
+    LzArgs la{};
+    la.blocks = d_seq_blocks_.as<SeqBlock>();
+    la.n_blocks = static_cast<uint32_t>(n_seq_blocks_);
+    la.n_sequences = plan_.n_sequences;
+    la.n_elems = proto_lz_ ? halo_elems_ + decoded_
+                           : (tiles_.size() == 1 ? expect_ : halo_elems_ + static_cast<uint64_t>(n_blocks_ - plan_.halo) * kBlockMax);   // (tile: an upper bound)
+    la.seqs = d_seqs_.as<Seq>();
+    la.lit = d_lit_.bytes();
+    la.blk_base = d_blk_base_.as<uint64_t>();
+    la.rep_final = d_rep_final_.as<uint32_t>();
+    la.rep_init = d_rep_init_.as<uint32_t>();
+    la.rep_scratch = d_rep_scratch_.as<uint32_t>();
+    // repeat offsets in front of the first block: the frame's initial ones, what the tile before left behind, or
+    // (shard protocol) what the ranks in front leave behind
+    const bool continues = plan_.first_frame_continues && loaded_tile_ > 0 && carry_same_frame_;
+    la.rep_continues = plan_.first_frame_continues ? 1u : 0u;
+    for (int k = 0; k < 3; k++) la.rep_carry[k] = proto_lz_ ? shard_carry_[k] : (continues ? rep_carry_[k] : (k == 0 ? 1u : (k == 1 ? 4u : 8u)));
+    la.rep_out = reinterpret_cast<uint32_t *>(d_counters_.bytes() + 64);
+    la.meta = d_meta_.as<SeqMeta>();
+    la.blk_pending = d_blk_pending_.as<uint32_t>();
+    la.out = tile_out_base();
+    la.t_char = t_char_;
+    la.status = status;
+    la.counters = d_counters_.as<unsigned long long>();
+    la.phase = phase;
+    la.n_sel_blocks = static_cast<uint32_t>(n_blocks_);
+    la.halo_wait = proto_lz_ ? halo_elems_ : 0;
+    la.tail_elems = send_elems_;
+    // Dense or sparse?  Where the matches are a good part of the output (level-3 DNA, quality strings) the frame is
+    // swept element by element (one word of scratch per output element, allocated on the first run and kept);
+    // a handful of matches in gigabytes of literals (real genomes at level 1) are visited one by one.
+    const uint64_t sec_known = sec_known_, sec_seqs = sec_seqs_;                            // (the whole section's figures: every tile decides alike)
+    const uint64_t match_elems = expect_ > sec_known ? expect_ - sec_known : 0;             // known_out = everything but the match bytes
+    const char *force = hook_env("NAFGPU_LZ_MODE");                                         // tests: "dense" / "sparse"
+    // Swept: matches are a fifth of the output or more (level-3 DNA, a quarter of it matches at random distances: 16.3 ms
+    // swept against 17.5 match by match) and there is enough of them to pay for the sweeps -- many sequences, or a
+    // megabyte of match bytes in a few long ones (the Length section of equal-length reads is one block-long run per
+    // block, each copying from the block before: a chain no fixed number of passes gets through).
+    bool dense = (sec_seqs >= 4096 || match_elems >= (1u << 20)) && match_elems * 5 >= expect_;
+    if (force) dense = force[0] == 'd';
+    lz_dense_ = false;
+    if (dense && d_pj_dist_.alloc_items(la.n_elems, sizeof(uint32_t), 64) && d_pj_tiles_.alloc_items(lz_pj_tiles(la.n_elems), sizeof(uint32_t), 64)) {
+        la.pj_dist = d_pj_dist_.as<uint32_t>();
+        la.pj_tiles = d_pj_tiles_.as<uint32_t>();
+        // the late sweeps work from lists of what is pending (a third of the elements at most); without memory for
+        // them the sweeps simply go on over all of D
+        la.pj_list_cap = la.n_elems / 3 + 4096;
+        if (la.n_elems < (1ull << 32) && d_pj_list_[0].alloc_items(la.pj_list_cap, sizeof(uint32_t), 64) &&
+            d_pj_list_[1].alloc_items(la.pj_list_cap, sizeof(uint32_t), 64)) {
+            la.pj_list[0] = d_pj_list_[0].as<uint32_t>();
+            la.pj_list[1] = d_pj_list_[1].as<uint32_t>();
+        }
+        lz_dense_ = true;
+    } else {
+        // the pending lists are an accelerator: without memory for them every pass walks the blocks
+        const bool lists = plan_.n_sequences < (1ull << 40) && n_seq_blocks_ < (1ull << 24) &&
+                           d_lz_list_[0].alloc_items(plan_.n_sequences, sizeof(uint64_t), 16) &&
+                           d_lz_list_[1].alloc_items(plan_.n_sequences, sizeof(uint64_t), 16);
+        la.plist[0] = lists ? d_lz_list_[0].as<uint64_t>() : nullptr;
+        la.plist[1] = lists ? d_lz_list_[1].as<uint64_t>() : nullptr;
+        la.roff = d_roff_.alloc_items(plan_.n_sequences, sizeof(uint32_t), 16) ? d_roff_.as<uint32_t>() : nullptr;
+        // the index of "first sequence at or after every 128th element" pays when sequences are everywhere; a few
+        // thousand sequences in gigabytes of output are found by binary search
+        const bool index = plan_.n_sequences < 0xFFFFFFFFull && plan_.n_sequences * 1024 >= la.n_elems &&
+                           d_lz_index_.alloc_items((la.n_elems >> 7) + 2, sizeof(uint32_t));
+        la.cidx = index ? d_lz_index_.as<uint32_t>() : nullptr;
+        la.n_idx_chunks = (la.n_elems >> 7) + 2;
+    }
+    *out = la;
+}
+
+// Everything that addresses the output: the block bases, raw / RLE copies, K1's remaining classes, K4, frame checksums.
+// phase: 0 = the selection is complete in itself; 1 = (shard protocol) the window in front of it has not arrived yet.
+void SectionJob::run_back(hipStream_t stream, StageTimer *timer, hipStream_t aux, bool early, uint32_t phase) {
+    uint32_t *status = d_status_.as<uint32_t>();
+    auto launch_class = [&](const HufClass &c, hipStream_t st, uint8_t *out_base) {
+        launch_huf_decode(st, d_src_, d_tasks_.as<HufTask>(), c, d_tbl_copies_.as<HufTblCopy>(), d_streams_.as<HufStream>(),
+                          d_pool_.as<uint16_t>(), d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(), d_seq_blocks_.as<SeqBlock>(),
+                          d_seqs_.as<Seq>(), d_dicts_.bytes(), t_char_ != 0, t_char_, status);
+    };
     if (timer) timer->begin(stream, StageTimer::kOther);
     // total of the selection's block sizes: known for the whole section and for ranges without LZ sequences; a tile
-    // of a section with sequences is added up by the host (decode_tile)
+    // of a section with sequences is added up by the host (decode_tile), a shard's by the ranks together (shard_place)
     const uint64_t expect_sel = tiles_.size() == 1 && !sharded_ ? expect_
                                 : (!has_lz_ ? halo_elems_ + plan_.known_out : ~0ull);
     launch_scan_blocks(stream, d_blk_size_.as<uint32_t>(), n_blocks_, d_blk_base_.as<uint64_t>(), d_scan_tmp_.bytes(),
@@ -426,9 +567,7 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
                      d_blk_base_.as<uint64_t>(), out_base, d_lit_.bytes(), ascii, t_char_, status);
     if (timer) timer->end(stream);
     // K1, one launch per class.  Streams that write the section output (blocks without sequences, and -- segment by
-    // segment -- blocks with a few) and streams that feed the literal buffer (blocks with many sequences).  When
-    // both kinds exist the literal-buffer classes run on `aux` beside the others, so the launches share the chip
-    // instead of each ending in a half-empty tail; K4 then waits for both.  One timed span covers the phase.
+    // segment -- blocks with a few) and streams that feed the literal buffer (blocks with many sequences).
     // The classes are independent of each other.  The one with the most tasks goes to `stream`, the others to `aux`
     // beside it: a class of a few tasks (the tail of a section; streams bound for the literal buffer) takes a whole
     // task's time -- 2.5 ms on one CU for 64 streams -- which back to back was a fifth of a real-genome decode, and
@@ -459,74 +598,17 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
         if (timer) timer->end(stream);
     }
     if (early) (void)hipStreamWaitEvent(stream, ev_early_join_, 0);   // the literal buffer is complete from here on
+    lz_args_valid_ = false;
     if (n_seq_blocks_) {
         if (timer) timer->begin(stream, StageTimer::kSeqLz);
-        LzArgs la{};
-        la.blocks = d_seq_blocks_.as<SeqBlock>();
-        la.n_blocks = static_cast<uint32_t>(n_seq_blocks_);
-        la.n_sequences = plan_.n_sequences;
-        la.n_elems = tiles_.size() == 1 ? expect_ : halo_elems_ + static_cast<uint64_t>(n_blocks_ - plan_.halo) * kBlockMax;   // (tile: an upper bound)
-        la.seqs = d_seqs_.as<Seq>();
-        la.lit = d_lit_.bytes();
-        la.blk_base = d_blk_base_.as<uint64_t>();
-        la.rep_final = d_rep_final_.as<uint32_t>();
-        la.rep_init = d_rep_init_.as<uint32_t>();
-        la.rep_scratch = d_rep_scratch_.as<uint32_t>();
-        // repeat offsets in front of the first block: the frame's initial ones, or what the tile before left behind
-        const bool continues = plan_.first_frame_continues && loaded_tile_ > 0 && carry_same_frame_;
-        la.rep_continues = plan_.first_frame_continues ? 1u : 0u;
-        for (int k = 0; k < 3; k++) la.rep_carry[k] = continues ? rep_carry_[k] : (k == 0 ? 1u : (k == 1 ? 4u : 8u));
-        la.rep_out = reinterpret_cast<uint32_t *>(d_counters_.bytes() + 64);
-        la.meta = d_meta_.as<SeqMeta>();
-        la.blk_pending = d_blk_pending_.as<uint32_t>();
-        la.out = out_base;
-        la.t_char = t_char_;
-        la.status = status;
-        la.counters = d_counters_.as<unsigned long long>();
-        // Dense or sparse?  Where the matches are a good part of the output (level-3 DNA, quality strings) the frame is
-        // swept element by element (one word of scratch per output element, allocated on the first run and kept);
-        // a handful of matches in gigabytes of literals (real genomes at level 1) are visited one by one.
-        const uint64_t sec_known = sec_known_, sec_seqs = sec_seqs_;                            // (the whole section's figures: every tile decides alike)
-        const uint64_t match_elems = expect_ > sec_known ? expect_ - sec_known : 0;             // known_out = everything but the match bytes
-        const char *force = std::getenv("NAFGPU_LZ_MODE");                                      // tests: "dense" / "sparse"
-        // Swept: matches are a fifth of the output or more (level-3 DNA, a quarter of it matches at random distances: 16.3 ms
-        // swept against 17.5 match by match) and there is enough of them to pay for the sweeps -- many sequences, or a
-        // megabyte of match bytes in a few long ones (the Length section of equal-length reads is one block-long run per
-        // block, each copying from the block before: a chain no fixed number of passes gets through).
-        bool dense = (sec_seqs >= 4096 || match_elems >= (1u << 20)) && match_elems * 5 >= expect_;
-        if (force) dense = force[0] == 'd';
-        lz_dense_ = false;
-        if (dense && d_pj_dist_.alloc_items(la.n_elems, sizeof(uint32_t), 64) && d_pj_tiles_.alloc_items(lz_pj_tiles(la.n_elems), sizeof(uint32_t), 64)) {
-            la.pj_dist = d_pj_dist_.as<uint32_t>();
-            la.pj_tiles = d_pj_tiles_.as<uint32_t>();
-            // the late sweeps work from lists of what is pending (a third of the elements at most); without memory for
-            // them the sweeps simply go on over all of D
-            la.pj_list_cap = la.n_elems / 3 + 4096;
-            if (la.n_elems < (1ull << 32) && d_pj_list_[0].alloc_items(la.pj_list_cap, sizeof(uint32_t), 64) &&
-                d_pj_list_[1].alloc_items(la.pj_list_cap, sizeof(uint32_t), 64)) {
-                la.pj_list[0] = d_pj_list_[0].as<uint32_t>();
-                la.pj_list[1] = d_pj_list_[1].as<uint32_t>();
-            }
-            lz_dense_ = true;
+        fill_lz_args(&la_, phase);
+        la_ascii_ = ascii;
+        if (!la_.pj_dist && !la_.roff) {                       // (cannot happen short of a device out of memory: flag the section)
+            (void)hipMemsetAsync(status, 0xFF, 4, stream);
         } else {
-            // the pending lists are an accelerator: without memory for them every pass walks the blocks
-            const bool lists = plan_.n_sequences < (1ull << 40) && n_seq_blocks_ < (1ull << 24) &&
-                               d_lz_list_[0].alloc_items(plan_.n_sequences, sizeof(uint64_t), 16) &&
-                               d_lz_list_[1].alloc_items(plan_.n_sequences, sizeof(uint64_t), 16);
-            la.plist[0] = lists ? d_lz_list_[0].as<uint64_t>() : nullptr;
-            la.plist[1] = lists ? d_lz_list_[1].as<uint64_t>() : nullptr;
-            la.roff = d_roff_.alloc_items(plan_.n_sequences, sizeof(uint32_t), 16) ? d_roff_.as<uint32_t>() : nullptr;
-            // the index of "first sequence at or after every 128th element" pays when sequences are everywhere; a few
-            // thousand sequences in gigabytes of output are found by binary search
-            const bool index = plan_.n_sequences < 0xFFFFFFFFull && plan_.n_sequences * 1024 >= la.n_elems &&
-                               d_lz_index_.alloc_items((la.n_elems >> 7) + 2, sizeof(uint32_t));
-            la.cidx = index ? d_lz_index_.as<uint32_t>() : nullptr;
-            la.n_idx_chunks = (la.n_elems >> 7) + 2;
-            if (!la.roff) {                                    // (cannot happen short of a device out of memory: flag the section)
-                (void)hipMemsetAsync(status, 0xFF, 4, stream);
-            }
+            launch_lz_execute(stream, la_, ascii);
+            lz_args_valid_ = true;
         }
-        if (la.pj_dist || la.roff) launch_lz_execute(stream, la, ascii);
         if (timer) timer->end(stream);
     }
     if (!xxh_segs_.empty()) {                                  // Content_Checksum of the frames that carry one
@@ -537,6 +619,179 @@ void SectionJob::run(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
                             out_base, ascii, t_char_, carry + t, carry + (t ^ 1u), status);
         if (timer) timer->end(stream);
     }
+}
+
+// ------------------------------------------------------------------ the shard protocol (one section)
+void SectionJob::range_of(uint32_t rank, uint32_t *b0, uint32_t *b1) const {
+    *b0 = ranges_[rank].first;
+    *b1 = ranges_[rank].second;
+}
+
+// The repeat offsets rank `rank`'s first block with sequences inherits: {1, 4, 8} at the start of a frame, else what
+// the last block with sequences in front of it -- same frame, some rank before -- leaves behind: that rank's map
+// applied to what IT inherits.
+void SectionJob::carry_for(uint32_t rank, const ShardSummary *all, uint32_t out[3]) const {
+    out[0] = 1;
+    out[1] = 4;
+    out[2] = 8;
+    const uint32_t b0 = ranges_[rank].first, b1 = ranges_[rank].second;
+    const size_t k = std::lower_bound(seq_blk_.begin(), seq_blk_.end(), b0) - seq_blk_.begin();   // its first block with sequences
+    if (k == seq_blk_.size() || seq_blk_[k] >= b1 || k == 0) return;
+    if (seq_frame_[k - 1] != seq_frame_[k]) return;          // that block begins its frame's sequences
+    uint32_t q = rank;                                       // the rank that holds the block with sequences in front of it
+    while (q > 0) {
+        q--;
+        if (seq_blk_[k - 1] >= ranges_[q].first && seq_blk_[k - 1] < ranges_[q].second) break;
+    }
+    uint32_t in[3];
+    carry_for(q, all, in);
+    bool bad = false;
+    for (int j = 0; j < 3; j++) out[j] = rep_compose(all[q].rep_map[j], in, &bad);
+    if (bad) out[0] = out[1] = out[2] = 0;                   // (corrupt: an offset of zero is flagged by the kernels)
+}
+
+void SectionJob::shard_begin(hipStream_t stream, StageTimer *timer, hipStream_t aux) {
+    if (!ready_) return;
+    if (!proto_lz_) return;                                  // everything about this range is known from the walk: shard_place runs it
+    // the pseudo block in front has no size yet: positions are relative to the range's first element
+    halo_elems_ = 0;
+    halo_word_ = 0;
+    if (plan_.halo) (void)hipMemcpyAsync(d_blk_size_.bytes(), &halo_word_, 4, hipMemcpyHostToDevice, stream);
+    begin_early_ = false;
+    run_front(stream, timer, aux, &begin_early_);            // (run_back waits for the classes that started early)
+    uint32_t *status = d_status_.as<uint32_t>();
+    launch_scan_blocks(stream, d_blk_size_.as<uint32_t>(), n_blocks_, d_blk_base_.as<uint64_t>(), d_scan_tmp_.bytes(), ~0ull, status);
+    if (n_seq_blocks_)
+        launch_rep_map(stream, d_seq_blocks_.as<SeqBlock>(), static_cast<uint32_t>(n_seq_blocks_), d_rep_final_.as<uint32_t>(),
+                       d_rep_scratch_.as<uint32_t>(), plan_.first_frame_continues ? 1u : 0u,
+                       reinterpret_cast<uint32_t *>(d_counters_.bytes() + 192), status);
+}
+
+Failure SectionJob::shard_summary(hipStream_t stream, ShardSummary *mine) {
+    *mine = ShardSummary();
+    if (!ready_) return Failure();
+    const uint32_t b0 = ranges_[opt_.shard_rank].first, b1 = ranges_[opt_.shard_rank].second;
+    // the last frame that begins inside the range
+    uint32_t last_frame = 0xFFFFFFFFu;
+    for (uint32_t f : frame_first_)
+        if (f >= b0 && f < b1) last_frame = f;
+    if (!proto_lz_) {
+        mine->decoded = out1_ - out0_;
+        mine->frame_tail = mine->decoded;                    // (no sequences anywhere: nobody looks at it)
+        return Failure();
+    }
+    uint64_t total = 0, at_frame = 0;
+    uint32_t map[3] = {mine->rep_map[0], mine->rep_map[1], mine->rep_map[2]};
+    bool ok = hip_ok(hipMemcpyAsync(&total, d_blk_base_.as<uint64_t>() + n_blocks_, 8, hipMemcpyDeviceToHost, stream));
+    if (last_frame != 0xFFFFFFFFu)
+        ok = ok && hip_ok(hipMemcpyAsync(&at_frame, d_blk_base_.as<uint64_t>() + (last_frame - b0 + plan_.halo), 8, hipMemcpyDeviceToHost, stream));
+    if (n_seq_blocks_) ok = ok && hip_ok(hipMemcpyAsync(map, d_counters_.bytes() + 192, sizeof map, hipMemcpyDeviceToHost, stream));
+    if (!ok) return Failure::make(NAFGPU_E_DEVICE, "shard summary read-back failed");
+    Failure f = check(stream);                               // synchronises
+    if (!f.ok()) {
+        mine->failed = true;
+        return f;
+    }
+    decoded_ = total;
+    mine->decoded = total;
+    mine->frame_tail = last_frame != 0xFFFFFFFFu ? total - at_frame : total;
+    for (int k = 0; k < 3; k++) mine->rep_map[k] = map[k];
+    return Failure();
+}
+
+Failure SectionJob::shard_place(const ShardSummary *all, uint32_t n_ranks, hipStream_t stream, StageTimer *timer, hipStream_t aux) {
+    if (!ready_) return Failure();
+    if (n_ranks != opt_.shard_count || ranges_.size() != n_ranks) return Failure::make(NAFGPU_E_INVALID_ARG, "shard summaries of another world size");
+    const uint32_t me = opt_.shard_rank;
+    for (uint32_t r = 0; r < n_ranks; r++)
+        if (all[r].failed) return Failure::io(NAFGPU_IO_INVALID_DATA, "zstd: another rank could not decode its part of the section");
+    if (!proto_lz_) {                                        // a section without sequences: ranges known from the walk, nothing to wait for
+        bool early = false;
+        run_front(stream, timer, aux, &early);
+        run_back(stream, timer, aux, early, 0);
+        return Failure();
+    }
+    uint64_t before = 0, sum = 0;
+    for (uint32_t r = 0; r < n_ranks; r++) {
+        if (r < me) before += all[r].decoded;
+        sum += all[r].decoded;
+    }
+    if (sum != expect_) return Failure::io(NAFGPU_IO_INVALID_DATA, status_text(kStSizeMismatch));
+    out0_ = before;
+    out1_ = before + decoded_;
+    tile_pos0_ = out0_;
+    tile_len_ = decoded_;
+    // how much of the window in front of rank r exists: the decoded elements between the start of the frame its first
+    // block continues and that block -- nothing when the block begins a frame
+    auto window_of = [&](uint32_t r) -> uint64_t {
+        if (r == 0 || r >= n_ranks) return 0;
+        const uint32_t rb0 = ranges_[r].first;
+        if (rb0 >= master_blocks_) return 0;                 // (an empty range at the end)
+        for (uint32_t f : frame_first_)
+            if (f == rb0) return 0;
+        uint64_t avail = 0;
+        for (uint32_t q = r; q-- > 0;) {
+            const uint32_t qb0 = ranges_[q].first, qb1 = ranges_[q].second;
+            bool starts = false;
+            for (uint32_t f : frame_first_) starts = starts || (f >= qb0 && f < qb1);
+            avail += starts ? all[q].frame_tail : all[q].decoded;
+            if (starts) break;
+        }
+        return std::min<uint64_t>(avail, halo_cap_ ? halo_cap_ : std::min<uint64_t>(std::max<uint64_t>(plan_.window_max, 1), expect_));
+    };
+    halo_elems_ = plan_.halo ? window_of(me) : 0;
+    send_elems_ = window_of(me + 1);
+    if (send_elems_ > halo_elems_ + decoded_) return Failure::make(NAFGPU_E_INVALID_ARG, "internal: the next rank's window exceeds what this rank holds");
+    carry_for(me, all, shard_carry_);
+    halo_word_ = static_cast<uint32_t>(halo_elems_);
+    if (plan_.halo) (void)hipMemcpyAsync(d_blk_size_.bytes(), &halo_word_, 4, hipMemcpyHostToDevice, stream);
+    halo_pending_ = halo_elems_ != 0;
+    run_back(stream, timer, aux, begin_early_, 1);
+    return Failure();
+}
+
+Failure SectionJob::tail_ready(hipStream_t stream, bool *ready) {
+    *ready = true;
+    if (!ready_ || !proto_lz_ || !send_elems_) return Failure();
+    if (!halo_pending_) {                                    // nothing was left waiting (or it has been finished since)
+        if (!hip_ok(hipStreamSynchronize(stream))) return Failure::make(NAFGPU_E_DEVICE, "device failure in the shard protocol");
+        return Failure();
+    }
+    unsigned long long flag = 0;
+    if (n_seq_blocks_ && lz_args_valid_) {
+        if (!hip_ok(hipMemcpyAsync(&flag, d_counters_.as<unsigned long long>() + 19, 8, hipMemcpyDeviceToHost, stream)) ||
+            !hip_ok(hipStreamSynchronize(stream)))
+            return Failure::make(NAFGPU_E_DEVICE, "device failure in the shard protocol");
+    }
+    // (a range smaller than the next rank's window passes part of its own window on)
+    *ready = flag == 0 && send_elems_ <= decoded_;
+    return Failure();
+}
+
+Failure SectionJob::export_tail(void *dst, uint64_t n, hipStream_t stream) {
+    if (!ready_ || !proto_lz_ || n != tail_send_bytes()) return Failure::make(NAFGPU_E_INVALID_ARG, "tail size differs from what the next rank waits for");
+    if (!n) return Failure();
+    const uint64_t mult = t_char_ ? 2 : 1;
+    const uint8_t *end = d_out_.bytes() + out_shift_ + decoded_ * mult;
+    if (!hip_ok(hipMemcpyAsync(dst, end - n, n, hipMemcpyDefault, stream)) || !hip_ok(hipStreamSynchronize(stream)))
+        return Failure::make(NAFGPU_E_DEVICE, "copy of the tail failed");
+    return Failure();
+}
+
+Failure SectionJob::import_halo(const void *src, uint64_t n, hipStream_t stream, StageTimer *timer) {
+    if (!ready_ || !proto_lz_ || n != halo_recv_bytes()) return Failure::make(NAFGPU_E_INVALID_ARG, "window size differs from what this rank waits for");
+    if (!n) return Failure();
+    if (!hip_ok(hipMemcpyAsync(tile_out_base(), src, n, hipMemcpyDefault, stream))) return Failure::make(NAFGPU_E_DEVICE, "copy of the window failed");
+    if (halo_pending_ && n_seq_blocks_ && lz_args_valid_) {
+        if (timer) timer->begin(stream, StageTimer::kSeqLz);
+        la_.phase = 2;
+        launch_lz_execute(stream, la_, la_ascii_);
+        if (timer) timer->end(stream);
+    }
+    halo_pending_ = false;
+    // (the source buffer is the caller's: it may go as soon as this returns)
+    if (!hip_ok(hipStreamSynchronize(stream))) return Failure::make(NAFGPU_E_DEVICE, "device failure while finishing a shard");
+    return Failure();
 }
 
 Failure SectionJob::check(hipStream_t stream) {
@@ -611,9 +866,10 @@ Failure ArchiveJob::upload(const uint8_t *bytes, size_t n, const nafgpu_header &
         if (s == kSequence && is_nuc_) expect = (expect + 1) / 2;     // nucleotides -> packed bytes
         SectionOptions so;
         so.t_char = (s == kSequence && is_nuc_) ? (h.sequence_type == 1 ? 'U' : 'T') : 0;
-        if (s == kSequence && opt.shard_count > 1) {
+        if ((s == kSequence || (s == kQuality && opt.shard_protocol)) && opt.shard_count > 1) {
             so.shard_rank = opt.shard_rank;
             so.shard_count = opt.shard_count;
+            so.shard_protocol = opt.shard_protocol;
         }
         if (s == kSequence || s == kQuality) {                        // the two sections that can be large
             so.tile_blocks = opt.tile_blocks;
@@ -649,7 +905,7 @@ Failure ArchiveJob::upload(const uint8_t *bytes, size_t n, const nafgpu_header &
     return Failure();
 }
 
-Failure ArchiveJob::decode() {
+void ArchiveJob::decode_front() {
     (void)hipSetDevice(device_);
     timer_.reset();
     uint32_t *status = d_status_.as<uint32_t>();
@@ -660,29 +916,36 @@ Failure ArchiveJob::decode() {
     // Sections in file order.  The record table (LengthReader) and the mask run table (MaskReader) only need
     // the small Length / Mask sections, which come before the sequence: their scans run on the second stream
     // beside the sequence decode and are joined before the mask is applied.
-    const bool want_mask = job_[kMask].ready() && job_[kSequence].ready() && job_[kLengths].ready();
+    want_mask_ = job_[kMask].ready() && job_[kSequence].ready() && job_[kLengths].ready();
     for (int s = 0; s <= kMask; s++) job_[s].run(stream_, &timer_, aux_stream_);
-    bool scans_forked = false;
-    auto scans = [&](hipStream_t st) {
-        if (job_[kLengths].ready())                                // LengthReader, reader.rs:48-67
-            launch_scan_runs_u32(st, job_[kLengths].out(), rec_cap_, d_rec_ends_.as<uint64_t>(), rec_cap_, d_scan_tmp_.bytes(),
-                                 &totals[0], status);
-        if (want_mask)                                             // MaskReader, reader.rs:198-231
-            launch_scan_runs_u8(st, job_[kMask].out(), mask_cap_, d_mask_ends_.as<uint64_t>(), mask_cap_, d_scan_tmp_.bytes(),
-                                &totals[1], status);
-    };
+    scans_forked_ = false;
     // (with a Mask section the run table is tens of megabytes: its scan beside the sequence decode slows K1 down by more
     //  than the scan takes alone -- 12.8 against 11.95 + 0.5 ms -- so then the scans wait until the sequence is done)
-    if (aux_stream_ && job_[kSequence].ready() && !want_mask) {
+    if (aux_stream_ && job_[kSequence].ready() && !want_mask_) {
         if (!ev_fork_) (void)hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming);
         if (!ev_join_) (void)hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming);
-        scans_forked = ev_fork_ && ev_join_ && hip_ok(hipEventRecord(ev_fork_, stream_)) &&
-                       hip_ok(hipStreamWaitEvent(aux_stream_, ev_fork_, 0));
+        scans_forked_ = ev_fork_ && ev_join_ && hip_ok(hipEventRecord(ev_fork_, stream_)) &&
+                        hip_ok(hipStreamWaitEvent(aux_stream_, ev_fork_, 0));
     }
-    if (scans_forked) {
-        scans(aux_stream_);
+    if (scans_forked_) {
+        run_table_scans(aux_stream_);
         (void)hipEventRecord(ev_join_, aux_stream_);
     }
+}
+
+void ArchiveJob::run_table_scans(hipStream_t st) {
+    uint32_t *status = d_status_.as<uint32_t>();
+    ScanTotals *totals = d_totals_.as<ScanTotals>();
+    if (job_[kLengths].ready())                                // LengthReader, reader.rs:48-67
+        launch_scan_runs_u32(st, job_[kLengths].out(), rec_cap_, d_rec_ends_.as<uint64_t>(), rec_cap_, d_scan_tmp_.bytes(),
+                             &totals[0], status);
+    if (want_mask_)                                            // MaskReader, reader.rs:198-231
+        launch_scan_runs_u8(st, job_[kMask].out(), mask_cap_, d_mask_ends_.as<uint64_t>(), mask_cap_, d_scan_tmp_.bytes(),
+                            &totals[1], status);
+}
+
+Failure ArchiveJob::decode() {
+    decode_front();
     // The sequence and quality sections: one resident tile each (kernels only), or tile after tile -- all of them
     // now when the whole output is resident, the first one when the output is held a tile at a time (the
     // iterator asks for the next ones, advance_tile).
@@ -712,15 +975,20 @@ Failure ArchiveJob::decode() {
             }
         }
     }
+    return decode_back();
+}
+
+Failure ArchiveJob::decode_back() {
+    uint32_t *status = d_status_.as<uint32_t>();
+    ScanTotals *totals = d_totals_.as<ScanTotals>();
     timer_.begin(stream_, StageTimer::kOther);
-    if (scans_forked)
+    if (scans_forked_)
         (void)hipStreamWaitEvent(stream_, ev_join_, 0);
     else
-        scans(stream_);
+        run_table_scans(stream_);
     // (nucleotide sequence sections come out of their SectionJob already expanded to ASCII:
     //  SequenceReader::read_nucleotide, reader.rs:121-172, is fused into the zstd kernels)
-    want_mask_ = want_mask;
-    if (want_mask) apply_mask_to_held();                           // mod.rs:386-388, 402-441
+    if (want_mask_) apply_mask_to_held();                          // mod.rs:386-388, 402-441
     timer_.end(stream_);
     // ids / comments: CStringReader (reader.rs:22-30) as a scan; UTF-8 validity of every text section
     // (into_string().expect at mod.rs:362,368; from_utf8 at reader.rs:108-109) as one flag word
@@ -758,9 +1026,68 @@ Failure ArchiveJob::decode() {
         if (!job_[s].ready() || job_[s].n_tiles() > 1) continue;   // (tiles were checked one by one)
         Failure f = job_[s].check(stream_);
         if (f.status == NAFGPU_E_DEVICE) return f;
-        if (!f.ok()) fail_[s] = f;
+        if (!f.ok() && fail_[s].ok()) fail_[s] = f;
     }
     return Failure();
+}
+
+// ------------------------------------------------------------------ the shard protocol (whole archive)
+static int proto_section(int which) { return which == 0 ? kSequence : kQuality; }
+
+Failure ArchiveJob::shard_begin(ShardSummary mine[2]) {
+    decode_front();
+    for (int w = 0; w < 2; w++) job_[proto_section(w)].shard_begin(stream_, &timer_, aux_stream_);
+    for (int w = 0; w < 2; w++) {
+        const int s = proto_section(w);
+        mine[w] = ShardSummary();
+        if (!job_[s].ready()) continue;
+        if (!job_[s].in_protocol()) return Failure::make(NAFGPU_E_INVALID_ARG, "the decoder was not opened for the shard protocol (opts.shard_protocol, shard_count > 1)");
+        Failure f = job_[s].shard_summary(stream_, &mine[w]);
+        if (f.status == NAFGPU_E_DEVICE) return f;
+        if (!f.ok()) {
+            fail_[s] = f;
+            mine[w].failed = true;
+        }
+    }
+    return Failure();
+}
+
+Failure ArchiveJob::shard_place(const ShardSummary *seq_all, const ShardSummary *qual_all, uint32_t n_ranks) {
+    (void)hipSetDevice(device_);
+    for (int w = 0; w < 2; w++) {
+        const int s = proto_section(w);
+        if (!job_[s].ready()) continue;
+        Failure f = job_[s].shard_place(w == 0 ? seq_all : qual_all, n_ranks, stream_, &timer_, aux_stream_);
+        if (f.status == NAFGPU_E_DEVICE || f.status == NAFGPU_E_INVALID_ARG) return f;
+        if (!f.ok() && fail_[s].ok()) fail_[s] = f;
+    }
+    return Failure();
+}
+
+Failure ArchiveJob::shard_halo(int which, uint64_t *recv_bytes, uint64_t *send_bytes, bool *tail_ready) {
+    (void)hipSetDevice(device_);
+    SectionJob &j = job_[proto_section(which)];
+    *recv_bytes = *send_bytes = 0;
+    *tail_ready = true;
+    if (!j.ready() || !j.in_protocol()) return Failure();
+    *recv_bytes = j.halo_recv_bytes();
+    *send_bytes = j.tail_send_bytes();
+    return j.tail_ready(stream_, tail_ready);
+}
+
+Failure ArchiveJob::shard_export(int which, void *dst, uint64_t n) {
+    (void)hipSetDevice(device_);
+    return job_[proto_section(which)].export_tail(dst, n, stream_);
+}
+
+Failure ArchiveJob::shard_import(int which, const void *src, uint64_t n) {
+    (void)hipSetDevice(device_);
+    return job_[proto_section(which)].import_halo(src, n, stream_, &timer_);
+}
+
+Failure ArchiveJob::shard_finish() {
+    (void)hipSetDevice(device_);
+    return decode_back();
 }
 
 // Lower-cases the masked runs inside the part of the sequence that is in HBM right now: this process's whole

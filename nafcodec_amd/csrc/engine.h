@@ -84,6 +84,17 @@ struct SectionOptions {
     uint32_t shard_rank = 0, shard_count = 1;   // decode only this rank's contiguous block range (sections without LZ sequences)
     uint64_t tile_blocks = 0;        // > 0: decode in tiles of at most this many zstd blocks
     bool tiled_output = false;       // the output buffer holds ONE tile (and the LZ window in front of it) at a time
+    bool shard_protocol = false;     // the ranks exchange what their ranges need from each other (shard_begin / shard_place / ...):
+                                     // a section with LZ sequences is sharded too
+};
+
+// What one rank tells the others about its block range of one section (nafgpu_shard_summary holds two of these, spread
+// over its arrays).
+struct ShardSummary {
+    uint64_t decoded = 0;            // elements the range decodes to
+    uint64_t frame_tail = 0;         // of which: behind the start of the last frame that begins inside the range
+    uint32_t rep_map[3] = {kRepToken | (0u << 24), kRepToken | (1u << 24), kRepToken | (2u << 24)};   // identity
+    bool failed = false;
 };
 
 // One Zstandard-compressed NAF section on the device.
@@ -109,13 +120,27 @@ public:
     // (repeat offsets, position, the LZ window).  Tile t's output then is tile_data() .. + tile_len() elements.
     uint32_t n_tiles() const { return static_cast<uint32_t>(tiles_.size()); }
     Failure decode_tile(uint32_t t, hipStream_t stream, StageTimer *timer, hipStream_t aux = nullptr);
+    // ---- the shard protocol (SectionOptions.shard_protocol; include/nafgpu.h has the sequence of calls)
+    // enqueues what needs nothing from the other ranks: entropy decode, block sizes, the range's repeat-offset map
+    void shard_begin(hipStream_t stream, StageTimer *timer, hipStream_t aux);
+    // synchronises; what the other ranks need to know
+    Failure shard_summary(hipStream_t stream, ShardSummary *mine);
+    // all[r] = rank r's summary of this section: places the range, enqueues literals and every match that does not
+    // depend on the window in front of the range
+    Failure shard_place(const ShardSummary *all, uint32_t n_ranks, hipStream_t stream, StageTimer *timer, hipStream_t aux);
+    uint64_t halo_recv_bytes() const { return halo_elems_ * (t_char_ ? 2 : 1); }   // (valid after shard_place)
+    uint64_t tail_send_bytes() const { return send_elems_ * (t_char_ ? 2 : 1); }
+    Failure tail_ready(hipStream_t stream, bool *ready);           // synchronises
+    Failure export_tail(void *dst, uint64_t n, hipStream_t stream);   // the last tail_send_bytes() of [window in front | this range's output]
+    Failure import_halo(const void *src, uint64_t n, hipStream_t stream, StageTimer *timer);   // ... and finishes what waited for it
+    bool in_protocol() const { return ready_ && opt_.shard_protocol && opt_.shard_count > 1; }
     uint32_t tiles_done() const { return tiles_done_; }
     uint64_t tile_pos0() const { return tile_pos0_; }             // decoded-byte position (in the section) of the loaded tile's first byte
     uint64_t tile_len() const { return tile_len_; }               // decoded bytes of the loaded tile (known once it is decoded)
     const uint8_t *tile_data() const;                             // device address of the loaded tile's first output byte
 
-    const uint8_t *out() const { return d_out_.bytes(); }
-    uint8_t *out_mut() const { return d_out_.bytes(); }
+    const uint8_t *out() const { return d_out_.bytes() + out_shift_; }
+    uint8_t *out_mut() const { return d_out_.bytes() + out_shift_; }
     uint64_t size() const { return out1_ - out0_; }                 // decoded zstd bytes of this process's range (the whole section unless sharded)
     uint64_t total_size() const { return expect_; }                 // decoded zstd bytes of the whole section
     uint64_t shard_out0() const { return out0_; }
@@ -138,6 +163,11 @@ private:
     };
     Failure load_tile(uint32_t t, hipStream_t stream);
     uint8_t *tile_out_base() const;                               // address of the loaded selection's local position 0
+    void run_front(hipStream_t stream, StageTimer *timer, hipStream_t aux, bool *early);   // status reset, K1's literal-buffer classes beside K2
+    void run_back(hipStream_t stream, StageTimer *timer, hipStream_t aux, bool early, uint32_t phase);   // scan, copies, K1, K4, checksums
+    void fill_lz_args(LzArgs *la, uint32_t phase);
+    void range_of(uint32_t rank, uint32_t *b0, uint32_t *b1) const;
+    void carry_for(uint32_t rank, const ShardSummary *all, uint32_t out[3]) const;
     ZPlan master_, plan_;                                         // the walk; the loaded tile's launchable plan
     std::vector<Tile> tiles_;
     SectionOptions opt_;
@@ -151,6 +181,18 @@ private:
     uint64_t sec_known_ = 0, sec_seqs_ = 0;                       // the whole section: decoded bytes that are not match bytes; sequences
     uint64_t lz_residue_ = 0;
     uint64_t out0_ = 0, out1_ = 0;
+    // shard protocol
+    bool proto_lz_ = false;                                       // this range waits for (or feeds) a window: section with LZ sequences, several ranks
+    uint64_t out_shift_ = 0;                                      // bytes in front of the range's output in d_out_ (room for the window)
+    uint64_t send_elems_ = 0, decoded_ = 0;                       // elements the next rank's window takes from here; elements of this range
+    uint32_t shard_carry_[3] = {1, 4, 8};                         // the repeat offsets the range inherits
+    uint32_t halo_word_ = 0;                                      // (staging of the pseudo block's size)
+    bool halo_pending_ = false, lz_args_valid_ = false, begin_early_ = false;
+    std::vector<std::pair<uint32_t, uint32_t>> ranges_;           // every rank's block range
+    std::vector<uint32_t> frame_first_;                           // first block of every frame of the section
+    std::vector<uint32_t> seq_blk_, seq_frame_;                   // block / frame (its first block) of every block with sequences
+    LzArgs la_{};
+    bool la_ascii_ = false;
     uint64_t expect_ = 0, n_blocks_ = 0, n_streams_ = 0, n_tasks_ = 0, n_copies_ = 0, n_seq_blocks_ = 0;
     uint64_t master_blocks_ = 0, master_streams_ = 0, src_resident_ = 0;
     std::vector<HufClass> classes_;
@@ -180,6 +222,7 @@ struct ArchiveOptions {
     bool want[kNumSections] = {true, true, true, true, true, true};
     bool spec_mask = false;
     uint32_t shard_rank = 0, shard_count = 1;   // block-range sharding of the sequence section
+    bool shard_protocol = false;                // ... of the quality section too, and of sections with LZ sequences (shard_begin / ...)
     uint64_t tile_blocks = 0;                   // > 0: sequence / quality sections are decoded in tiles of at most this many zstd blocks
     bool tiled_output = false;                  // ... whose output is held one tile at a time (iterator path; not for decode_all_device)
 };
@@ -194,6 +237,15 @@ public:
                    const ArchiveOptions &opt);
     // (re)runs every kernel; synchronises; fills times
     Failure decode();
+    // The shard protocol (include/nafgpu.h: nafgpu_shard_*): the same decode in steps, between which the ranks exchange
+    // what their block ranges need from each other.  Sections: 0 = Sequence, 1 = Quality.
+    Failure shard_begin(ShardSummary mine[2]);
+    Failure shard_place(const ShardSummary *seq_all, const ShardSummary *qual_all, uint32_t n_ranks);
+    Failure shard_halo(int which, uint64_t *recv_bytes, uint64_t *send_bytes, bool *tail_ready);
+    Failure shard_export(int which, void *dst, uint64_t n);
+    Failure shard_import(int which, const void *src, uint64_t n);
+    Failure shard_finish();
+    uint64_t quality_offset() const { return job_[kQuality].ready() ? job_[kQuality].shard_out0() : 0; }
     // output held a tile at a time (iterator path): decodes the next tile of section s into the tile buffer
     Failure advance_tile(int s);
     SectionJob &job_mut(int s) { return job_[s]; }
@@ -242,6 +294,10 @@ private:
     bool is_nuc_ = false;
     void apply_mask_to_held();
     bool want_mask_ = false;
+    void decode_front();                        // status reset, the small sections, the record / mask table scans beside what follows
+    Failure decode_back();                      // scans joined, mask, names, UTF-8; synchronises; totals and per-section checks
+    bool scans_forked_ = false;
+    void run_table_scans(hipStream_t st);
     SectionJob job_[kNumSections];
     Failure fail_[kNumSections];
     DevBuf d_rec_ends_, d_mask_ends_, d_scan_tmp_, d_totals_, d_status_, d_hash_;

@@ -9,6 +9,12 @@
 
 namespace nafgpu {
 
+// Test / measurement switches (NAFGPU_LZ_MODE, NAFGPU_PJ_MAX_DIST, NAFGPU_TILE_KIB, NAFGPU_K2_LANES, NAFGPU_DEBUG_PLAN) are
+// read from the environment only after nafgpu_test_hooks(1): a variable that leaks into the environment of another
+// caller of the library changes nothing.  Returns the variable's value, or null.
+const char *hook_env(const char *name);
+void set_test_hooks(bool on);
+
 struct ScanTotals {          // written by the scan kernels
     uint64_t sum;            // sum of all values
     uint64_t count;          // number of run terminators (runs modes) or elements (exclusive mode)
@@ -107,12 +113,22 @@ struct LzArgs {
     uint32_t *pj_tiles;          // dense: pending elements per tile of 2048 (lz_pj_tiles(n_elems) words)
     uint32_t *pj_list[2];        // dense, optional: two lists of pending element indices, pj_list_cap entries each (k_pj_list)
     uint64_t pj_list_cap;
-    unsigned long long *counters;// 8 words: [0] matches still pending (sparse), [1] matches left to the one-workgroup stage, [4..6] stage counters
+    unsigned long long *counters;// 32 words: [0] matches still pending (sparse), [1] matches left to the one-workgroup stage, [4..6] stage counters, ... (kernels.hip: kCtr*)
     uint8_t *out;
     uint32_t t_char;
     uint32_t *status;
+    // the shard protocol (engine.cpp): see lz_execute
+    uint32_t phase;              // 0: everything; 1: the window in front has not arrived yet; 2: it has -- finish
+    uint32_t n_sel_blocks;       // blocks of the loaded selection (blk_base[n_sel_blocks] = its elements)
+    uint64_t halo_wait;          // phase 1 / 2: elements of the pseudo block in front
+    uint64_t tail_elems;         // phase 1: the next shard waits for the last this-many elements
 };
 uint64_t lz_pj_tiles(uint64_t n_elems);
+// The repeat-offset map of a whole run of blocks (shard protocol): what the three offsets behind the last block are in
+// terms of the three in front of the first -- values, or kRepToken tokens -- from k_seq_values' per-block maps.
+// rep_scratch as in LzArgs; map_out: 3 words on the device.
+void launch_rep_map(hipStream_t stream, const SeqBlock *blocks, uint32_t n_blocks, const uint32_t *rep_final, uint32_t *rep_scratch,
+                    uint32_t continues, uint32_t *map_out, uint32_t *status);
 void launch_lz_execute(hipStream_t stream, const LzArgs &args, bool ascii);
 
 // K5: 4-bit -> IUPAC ASCII; t_char = 'T' (DNA) or 'U' (RNA)

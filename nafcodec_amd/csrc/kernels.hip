@@ -1562,6 +1562,11 @@ __device__ inline void unpack_dword(uint32_t w, uint32_t t0, uint32_t t1, uint32
 // ASCII = true: the output is the expanded base stream (two characters per packed byte), so a
 // match of `ml` packed bytes at distance `off` copies ml 16-bit elements at distance off, and
 // literals are expanded while they are scattered.  The ASCII buffer itself is the LZ window.
+// the section's counter words (SectionJob::d_counters_, 32 x u64): [0] matches still pending (sparse), [1] matches the launched
+// passes left to the one-workgroup stage, [4..6] rotating counters of the stage in use, bytes 64..75 the repeat offsets behind
+// the last block, [10..13] the pending lists of the sweeps, and for the shard protocol:
+constexpr uint32_t kCtrLeft = 16, kCtrWhich = 17, kCtrPass = 18;   // sparse: survivors of the last pass -- how many, in which list, the next pass number
+constexpr uint32_t kCtrTail = 19;                                  // 1: something still pending lies in the tail the next shard waits for
 constexpr uint32_t kLzShort = 48;        // runs up to this many elements are copied by their own thread
 constexpr uint32_t kLzPasses = 24;       // launched passes: the first walks every block, the others the list of what is still pending;
                                          // what they leave goes to ONE workgroup (k_lz_finish_small), then to the frame-order walk
@@ -1618,8 +1623,10 @@ __global__ __launch_bounds__(256) void k_rep_partial(const SeqBlock *__restrict_
     if (bad) flag_error(status, kStBadOffset, 0xFFFFFFFEu);
 }
 
+// (final_out: where the map of all chunks together goes -- with tokens for c0..c2 that is the map of the whole range,
+//  which a shard hands to the ranks behind it before anybody knows a concrete triple)
 __global__ void k_rep_scan(uint32_t n_chunks, const uint32_t *__restrict__ partial, uint32_t *chunk_init, uint32_t c0, uint32_t c1,
-                           uint32_t c2, uint32_t *status) {
+                           uint32_t c2, uint32_t *final_out, uint32_t *status) {
     if (status[0] != 0 || blockIdx.x != 0 || threadIdx.x != 0) return;
     uint32_t cur[3] = {c0, c1, c2};                        // {1, 4, 8}, or what the tile in front left behind
     bool bad = false;
@@ -1633,6 +1640,11 @@ __global__ void k_rep_scan(uint32_t n_chunks, const uint32_t *__restrict__ parti
         cur[0] = n0;
         cur[1] = n1;
         cur[2] = n2;
+    }
+    if (final_out) {
+        final_out[0] = cur[0];
+        final_out[1] = cur[1];
+        final_out[2] = cur[2];
     }
     if (bad) flag_error(status, kStBadOffset, 0xFFFFFFFEu);
 }
@@ -1815,8 +1827,9 @@ __global__ __launch_bounds__(256) void k_lz_index(const SeqMeta *__restrict__ me
 // are literals (final since k_lz_literals / K1); bytes of match g are final once meta[g].flag holds an
 // earlier pass number.  mdst[] (match start positions) is sorted: sequences are stored in frame order.
 __device__ inline bool lz_range_final(uint64_t lo, uint64_t hi, const SeqMeta *meta, const uint32_t *cidx, uint64_t g_self,
-                                      uint32_t pass) {
+                                      uint32_t pass, uint64_t halo_end = 0) {
     if (hi <= lo) return true;
+    if (lo < halo_end) return false;                     // reaches into the window in front of a shard, which has not arrived yet
     uint64_t g;
     if (cidx) {                                          // the sequence before the first one of lo's chunk may reach into the range
         const uint64_t f = cidx[lo >> kLzIdxShift];
@@ -1847,7 +1860,7 @@ __global__ __launch_bounds__(256) void k_lz_match_pass(const SeqBlock *__restric
                                                        const uint32_t *__restrict__ cidx, uint32_t *blk_pending,
                                                        uint32_t *roff, unsigned long long *remaining, const uint32_t *__restrict__ rep_init,
                                                        const uint64_t *__restrict__ blk_base, uint8_t *out_bytes, uint32_t pass,
-                                                       uint64_t *plist, unsigned long long *pcount, uint32_t *status) {
+                                                       uint64_t *plist, unsigned long long *pcount, uint64_t halo_end, uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
     __shared__ uint32_t s_long[256];
@@ -1888,7 +1901,7 @@ __global__ __launch_bounds__(256) void k_lz_match_pass(const SeqBlock *__restric
                     const uint64_t src = mpos - off;
                     const uint64_t need_hi = src + q.ml < mpos ? src + q.ml : mpos;   // the rest is the match itself
                     roff[g] = off;                               // kept for the pointer-jumping stage
-                    if (lz_range_final(src, need_hi, meta, cidx, g, pass)) {
+                    if (lz_range_final(src, need_hi, meta, cidx, g, pass, halo_end)) {
                         if (q.ml <= kLzShort) {
                             Elem *d = out + mpos;
                             const Elem *s = out + src;
@@ -1937,7 +1950,7 @@ __global__ __launch_bounds__(256) void k_lz_match_list(const uint64_t *__restric
                                                        SeqMeta *meta, const uint32_t *__restrict__ cidx,
                                                        uint32_t *blk_pending, const uint32_t *__restrict__ roff,
                                                        unsigned long long *remaining,
-                                                       uint8_t *out_bytes, uint32_t pass, const uint32_t *status) {
+                                                       uint8_t *out_bytes, uint32_t pass, uint64_t halo_end, const uint32_t *status) {
     const unsigned long long *nin = lcount + pass % 3u;
     unsigned long long *nout = lcount + (pass + 1u) % 3u;
     if (blockIdx.x == 0 && threadIdx.x == 0) lcount[(pass + 2u) % 3u] = 0;
@@ -1971,7 +1984,7 @@ __global__ __launch_bounds__(256) void k_lz_match_list(const uint64_t *__restric
             const uint64_t mpos = meta[g].pos;
             const uint64_t src = mpos - off;
             const uint64_t need_hi = src + q.ml < mpos ? src + q.ml : mpos;
-            if (lz_range_final(src, need_hi, meta, cidx, g, pass)) {
+            if (lz_range_final(src, need_hi, meta, cidx, g, pass, halo_end)) {
                 if (q.ml <= kLzShort) {
                     Elem *d = out + mpos;
                     const Elem *sp = out + src;
@@ -2019,22 +2032,38 @@ template <bool ASCII>
 __global__ __launch_bounds__(1024) void k_lz_finish_small(uint64_t *l0, uint64_t *l1, unsigned long long *lcount, uint32_t first_pass,
                                                           const Seq *__restrict__ seqs, SeqMeta *meta, const uint32_t *__restrict__ cidx,
                                                           uint32_t *blk_pending, const uint32_t *__restrict__ roff,
-                                                          unsigned long long *counters, uint8_t *out_bytes, const uint32_t *status) {
+                                                          unsigned long long *counters, uint8_t *out_bytes, uint64_t halo_end, uint32_t resume,
+                                                          const uint64_t *__restrict__ n_total, uint64_t tail_elems, const uint32_t *status) {
+    // halo_end / resume / n_total / tail_elems: the shard protocol.  With the window in front of the shard still unknown
+    // (halo_end > 0) whatever reaches into it survives; the survivors' list, its length and the next pass number are left in
+    // counters[kCtrLeft], [kCtrWhich] (which list) and [kCtrPass], and counters[kCtrTail] says whether one of them lies in the last tail_elems elements
+    // (which the next shard waits for).  resume = 1 picks that list up again once the window has arrived.
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
-    __shared__ unsigned long long s_n, s_nout;
+    __shared__ unsigned long long s_n, s_nout, s_left;
     __shared__ uint64_t s_long[1024];
-    __shared__ uint32_t s_done, s_abort, s_nlong;
+    __shared__ uint32_t s_done, s_abort, s_nlong, s_pass, s_which, s_tail;
     const uint32_t tid = threadIdx.x;
     if (tid == 0) {
         s_abort = status[0];
-        s_n = lcount[first_pass % 3u];
-        counters[1] = s_n;                                 // statistics: matches the launched passes left over
+        if (resume) {
+            s_n = counters[kCtrLeft];
+            s_which = static_cast<uint32_t>(counters[kCtrWhich]);
+            s_pass = static_cast<uint32_t>(counters[kCtrPass]);
+        } else {
+            s_n = lcount[first_pass % 3u];
+            s_which = first_pass & 1u;
+            s_pass = first_pass;
+            counters[1] = s_n;                             // statistics: matches the launched passes left over
+        }
+        s_left = s_n;
+        s_tail = 0;
     }
     __syncthreads();
     if (s_abort) return;
-    uint64_t *lin = (first_pass & 1u) ? l1 : l0, *lout = (first_pass & 1u) ? l0 : l1;
-    for (uint32_t pass = first_pass; s_n != 0; pass++) {
+    uint64_t *lin = s_which ? l1 : l0, *lout = s_which ? l0 : l1;
+    uint32_t pass = s_pass;
+    for (; s_n != 0; pass++) {
         const unsigned long long n = s_n;
         if (tid == 0) {
             s_nout = 0;
@@ -2053,7 +2082,7 @@ __global__ __launch_bounds__(1024) void k_lz_finish_small(uint64_t *l0, uint64_t
                 const uint64_t mpos = meta[g].pos;
                 const uint64_t src = mpos - off;
                 const uint64_t need_hi = src + q.ml < mpos ? src + q.ml : mpos;
-                if (lz_range_final(src, need_hi, meta, cidx, g, pass)) {
+                if (lz_range_final(src, need_hi, meta, cidx, g, pass, halo_end)) {
                     if (q.ml <= kLzShort) {
                         Elem *d = out + mpos;
                         const Elem *sp = out + src;
@@ -2083,12 +2112,29 @@ __global__ __launch_bounds__(1024) void k_lz_finish_small(uint64_t *l0, uint64_t
         __syncthreads();
         if (tid == 0) {
             atomicAdd(counters, ~static_cast<unsigned long long>(done) + 1ull);   // remaining -= done
+            s_left = left;
             s_n = done * 8ull >= n ? left : 0;             // slow progress: stop here, the frame-order walk finishes
         }
         uint64_t *t = lin;
         lin = lout;
         lout = t;
         __syncthreads();
+    }
+    // what is left (in `lin`), for a later resume; and whether any of it lies in the tail the next shard waits for
+    const unsigned long long left = s_left;
+    if (tail_elems) {
+        const uint64_t total = *n_total, tail_lo = total > tail_elems ? total - tail_elems : 0;
+        for (unsigned long long i = tid; i < left; i += 1024) {
+            const uint64_t g = lin[i] & ((1ull << 40) - 1ull);
+            if (meta[g].pos + seqs[g].ml > tail_lo) s_tail = 1;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        counters[kCtrLeft] = left;
+        counters[kCtrWhich] = lin == l1 ? 1ull : 0ull;
+        counters[kCtrPass] = pass;
+        counters[kCtrTail] = s_tail;
     }
 }
 
@@ -2106,8 +2152,12 @@ __global__ __launch_bounds__(1024) void k_lz_finish_small(uint64_t *l0, uint64_t
 // whoever finds its source final has the value in the same look-up, whenever that source was written.
 constexpr uint32_t kPjTile = 2048;           // elements per tile (256 threads x 8)
 constexpr uint32_t kPjFinal = 0xFFFF0000u;   // D >= kPjFinal: final, and the low 16 bits ARE the element (byte / two characters)
+constexpr uint32_t kPjWait = kPjFinal - 1u;  // an element of the window in front of a shard whose value has not arrived yet (shard protocol):
+                                             // not pending, not final -- whoever copies from it stays pending, and no distance reaches this value
+__device__ inline bool pj_pending(uint32_t v) { return v - 1u < kPjWait - 1u; }   // 1 <= v < kPjWait: a distance
 constexpr uint32_t kPjShort = 16;            // k_pj_fill: matches up to this long are filled by the thread that looked at them
 constexpr uint32_t kPjLocal = 4;             // jumps inside the tile (LDS) before a sweep looks into memory
+constexpr uint32_t kPjFinishSweeps = 4;      // a shard's sweeps after the window in front of it has arrived
 constexpr uint32_t kPjSweeps = 24;           // a sweep at least halves every chain: 2^24 matches deep; what is left after them goes to the
                                              // frame-order walk (every launch that finds nothing left still costs its 4-5 us: 40 of them
                                              // plus as many k_pj_list were 0.4 ms per section)
@@ -2157,7 +2207,7 @@ __global__ __launch_bounds__(256) void k_pj_fill(const SeqBlock *__restrict__ bl
                 bool bad = false;
                 const uint32_t off = rep_resolve(q.off, init, &bad);
                 const uint64_t mpos = obase + q.opos + q.ll;
-                if (bad || off > mpos - fstart || off >= kPjFinal) {   // reaches before the frame (corrupt) / beyond any legal window
+                if (bad || off > mpos - fstart || off >= kPjWait) {    // reaches before the frame (corrupt) / beyond any legal window
                     flag_error(status, kStBadOffset, sb.blk);
                 } else if (q.ml <= kPjShort) {              // a short match (the usual kind in quality strings): its own thread
                     for (uint32_t k = 0; k < q.ml; k++) D[mpos + k] = k < off ? off : off * (k / off + 1u);
@@ -2340,7 +2390,7 @@ __global__ __launch_bounds__(256, 6) void k_pj_sweep(uint32_t *D, uint8_t *out_b
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) {
                     const uint32_t li = tid * 4 + half * (kPjTile / 2) + k, d = v[half][k];
-                    if (d == 0 || d >= kPjFinal || d > li) continue;           // literal / final / source outside the tile
+                    if (!pj_pending(d) || d > li) continue;                     // literal / final / source outside the tile
                     const uint32_t ws = s_D[li - d];
                     if (ws >= kPjFinal) {
                         v[half][k] = ws;                                        // (mark and element of the source: ours too)
@@ -2355,14 +2405,14 @@ __global__ __launch_bounds__(256, 6) void k_pj_sweep(uint32_t *D, uint8_t *out_b
         for (uint32_t half = 0; half < 2; half++)
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {
-                const bool pending = v[half][k] != 0 && v[half][k] < kPjFinal;   // else: literal / final already
+                const bool pending = pj_pending(v[half][k]);                       // else: literal / final already
                 w[half][k] = pending ? D[p[half] + k - v[half][k]] : 1u;
             }
 #pragma unroll
         for (uint32_t half = 0; half < 2; half++)
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {             // a literal as the source (D == 0): its element is in the output only
-                const bool pending = v[half][k] != 0 && v[half][k] < kPjFinal;
+                const bool pending = pj_pending(v[half][k]);
                 if (pending && w[half][k] == 0) e[half][k] = out[p[half] + k - v[half][k]];
             }
         uint32_t remaining = 0, survivors = 0;
@@ -2371,7 +2421,7 @@ __global__ __launch_bounds__(256, 6) void k_pj_sweep(uint32_t *D, uint8_t *out_b
             bool changed = v[half][0] != v0[half][0] || v[half][1] != v0[half][1] || v[half][2] != v0[half][2] || v[half][3] != v0[half][3];
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {
-                const bool pending = v[half][k] != 0 && v[half][k] < kPjFinal;
+                const bool pending = pj_pending(v[half][k]);
                 if (!pending) continue;
                 const uint32_t ws = w[half][k];
                 if (ws == 0 || ws >= kPjFinal) {
@@ -2425,11 +2475,11 @@ __global__ __launch_bounds__(256, 6) void k_pj_sweep(uint32_t *D, uint8_t *out_b
 
 // A pass over the list of pending elements (see above): sweep `sweep` reads what sweep - 1 listed and lists what it leaves.
 template <bool ASCII>
-__global__ __launch_bounds__(256) void k_pj_list(uint32_t *D, const uint8_t *out_bytes, unsigned long long *pcount, const uint32_t *list_in,
+__global__ __launch_bounds__(256) void k_pj_list(uint32_t *D, uint8_t *out_bytes, unsigned long long *pcount, const uint32_t *list_in,
                                                  uint32_t *list_out, uint64_t list_cap, unsigned long long *lstate, uint32_t sweep,
-                                                 uint32_t max_dist, const uint32_t *status) {
+                                                 uint32_t max_dist, uint32_t emit, const uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
-    const Elem *out = reinterpret_cast<const Elem *>(out_bytes);
+    Elem *out = reinterpret_cast<Elem *>(out_bytes);
     __shared__ PjLister<kPjBatch + 256> s_list;
     const uint32_t tid = threadIdx.x;
     const unsigned long long listing = lstate[3];
@@ -2453,11 +2503,12 @@ __global__ __launch_bounds__(256) void k_pj_list(uint32_t *D, const uint8_t *out
         if (i < n_in) {
             const uint32_t p = list_in[i];
             const uint32_t v = D[p];
-            if (v != 0 && v < kPjFinal) {
+            if (pj_pending(v)) {
                 const uint32_t ws = D[p - v];
                 if (ws == 0 || ws >= kPjFinal) {
                     const Elem el = ws == 0 ? out[p - v] : static_cast<Elem>(ws & 0xFFFFu);
                     D[p] = kPjFinal | el;
+                    if (emit) out[p] = el;                                      // (after k_pj_emit has run: the finishing passes of a shard)
                 } else {
                     if (static_cast<uint64_t>(v) + ws < max_dist) D[p] = v + ws;
                     mine++;
@@ -2480,10 +2531,14 @@ __global__ __launch_bounds__(256) void k_pj_list(uint32_t *D, const uint8_t *out
 // After the sweeps: every element that a sweep made final goes from its word of D to the output (the sweeps themselves
 // do not write the output: one sequential pass here instead of a scattered one-element store per element and sweep).
 template <bool ASCII>
-__global__ __launch_bounds__(256) void k_pj_emit(const uint32_t *__restrict__ D, uint8_t *out_bytes, uint64_t n_elems, const uint32_t *status) {
+__global__ __launch_bounds__(256) void k_pj_emit(const uint32_t *__restrict__ D, uint8_t *out_bytes, uint64_t n_elems,
+                                                 const unsigned long long *skip_if, unsigned long long skip_max, const uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
     if (status[0] != 0) return;
+    // (a shard's finishing passes: when they all ran from the list -- list mode since a sweep <= skip_max, before they began --
+    //  they wrote the output themselves)
+    if (skip_if && *skip_if != 0 && *skip_if <= skip_max) return;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256 * 4;
     for (uint64_t p = (static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x) * 4; p < n_elems; p += stride) {
         if (n_elems - p >= 4) {
@@ -2510,6 +2565,46 @@ __global__ __launch_bounds__(256) void k_pj_emit(const uint32_t *__restrict__ D,
             }
         }
     }
+}
+
+// ---- shard protocol: the window in front of a shard arrives after everything that does not depend on it is done ----
+__global__ __launch_bounds__(256) void k_fill_u32(uint32_t *p, uint64_t n, uint32_t v) {
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * 256) p[i] = v;
+}
+
+// the window has arrived (it is in the output buffer, elements [0, n_halo)): its elements become final words of D
+template <bool ASCII>
+__global__ __launch_bounds__(256) void k_pj_halo_words(uint32_t *D, const uint8_t *out_bytes, uint64_t n_halo) {
+    using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
+    const Elem *out = reinterpret_cast<const Elem *>(out_bytes);
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n_halo; i += static_cast<uint64_t>(gridDim.x) * 256)
+        D[i] = kPjFinal | out[i];
+}
+
+// Dense sections: does anything still pending (it waits for the window) lie in the last tail_elems elements -- what the
+// next shard waits for?  From the list of pending elements when the sweeps ended in list mode, else from the tiles' counts.
+__global__ __launch_bounds__(256) void k_pj_tail_check(const uint32_t *list, const unsigned long long *lstate, uint32_t last_sweep,
+                                                       uint64_t list_cap, const uint32_t *tile_pending, const unsigned long long *pcount,
+                                                       const uint64_t *n_total, uint64_t tail_elems, unsigned long long *flag) {
+    const uint64_t total = *n_total, tail_lo = total > tail_elems ? total - tail_elems : 0;
+    if (pcount[last_sweep % 3u] == 0) return;              // nothing pending at all
+    bool hit = false;
+    const uint64_t me = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x, stride = static_cast<uint64_t>(gridDim.x) * 256;
+    if (lstate[3] != 0) {
+        unsigned long long n = lstate[last_sweep % 3u];
+        if (n > list_cap) n = list_cap;
+        for (uint64_t i = me; i < n; i += stride) hit = hit || list[i] >= tail_lo;
+    } else {
+        const uint64_t t0 = tail_lo / kPjTile, t1 = (total + kPjTile - 1) / kPjTile;
+        for (uint64_t t = t0 + me; t < t1; t += stride) hit = hit || tile_pending[t] != 0;
+    }
+    if (hit) *flag = 1;
+}
+
+// the 32 counter words of a section's LZ stages ([0] = sequences, [4] = dense ? 1 : 0, everything else 0)
+__global__ void k_lz_init_counters(unsigned long long *counters, unsigned long long n_sequences, unsigned long long dense) {
+    const uint32_t t = threadIdx.x;
+    if (t < 32) counters[t] = t == 0 ? n_sequences : (t == 4 ? dense : 0ull);
 }
 
 template <bool ASCII>
@@ -2957,10 +3052,8 @@ __global__ __launch_bounds__(256) void k_hash64(const uint8_t *__restrict__ p, u
 void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *blocks, uint32_t n_blocks,
                        const SeqCell *cells, Seq *seqs, SeqMeta *meta, uint32_t *blk_size, uint32_t *rep_final, uint32_t *status) {
     if (!n_blocks) return;
-    static const uint32_t forced = [] {                   // NAFGPU_K2_LANES: measurements only
-        const char *e = std::getenv("NAFGPU_K2_LANES");
-        return e ? static_cast<uint32_t>(std::atoi(e)) : 0u;
-    }();
+    const char *k2e = hook_env("NAFGPU_K2_LANES");        // measurements only (nafgpu_test_hooks)
+    const uint32_t forced = k2e ? static_cast<uint32_t>(std::atoi(k2e)) : 0u;
     uint32_t lanes = forced ? forced : (n_blocks + 359u) / 360u;     // about one wave per CU ...
     lanes = forced ? lanes : (lanes < 16 ? 16 : lanes);              // ... of at least 16 lanes (measured: see above)
     lanes = lanes < 1 ? 1 : (lanes > 64 ? 64 : lanes);
@@ -3087,87 +3180,138 @@ void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *ta
 // largest distance a pointer-jumping element may hold (32-bit D, the top 256 values mark final elements);
 // NAFGPU_PJ_MAX_DIST lowers it so that a test can reach the "chain longer than D can express" fallback on a small input
 static uint32_t pj_max_dist() {
-    const char *e = std::getenv("NAFGPU_PJ_MAX_DIST");     // read per call: a test switches it inside one process
-    const uint32_t v = e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : kPjFinal;
-    return v < kPjFinal ? v : kPjFinal;
+    const char *e = hook_env("NAFGPU_PJ_MAX_DIST");        // read per call: a test switches it inside one process
+    const uint32_t v = e ? static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) : kPjWait;
+    return v < kPjWait ? v : kPjWait;
 }
 
 template <bool ASCII>
 static void lz_execute(hipStream_t stream, const LzArgs &a) {
-    const uint32_t n_chunks = (a.n_blocks + kRepChunk - 1) / kRepChunk;
-    uint32_t *partial = a.rep_scratch, *chunk_init = a.rep_scratch + 3 * static_cast<size_t>(n_chunks);
-    hipLaunchKernelGGL(k_rep_partial, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, a.blocks, a.n_blocks, a.rep_final, partial,
-                       a.rep_continues, a.status);
-    hipLaunchKernelGGL(k_rep_scan, dim3(1), dim3(1), 0, stream, n_chunks, partial, chunk_init, a.rep_carry[0], a.rep_carry[1],
-                       a.rep_carry[2], a.status);
-    hipLaunchKernelGGL(k_rep_apply, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, a.blocks, a.n_blocks, a.rep_final,
-                       chunk_init, a.rep_init, a.rep_continues, a.rep_out, a.status);
+    // a.phase (the shard protocol, engine.cpp): 0 = everything.  1 = the window in front of this shard (the pseudo block's
+    // a.halo_wait elements) has not arrived: everything that does not depend on it -- whatever copies from it, directly or
+    // not, stays pending, the frame-order walk does not run -- and a look at whether the last a.tail_elems elements (the next
+    // shard's window) are final.  2 = it has arrived (same buffers): the pending rest, then the frame-order walk.
+    const bool wait = a.phase == 1 && a.halo_wait != 0, finish = a.phase == 2;
     const uint32_t grid = a.n_blocks < 256u * 8u ? a.n_blocks : 256u * 8u;
-    if (!a.pj_dist)
-        hipLaunchKernelGGL(k_lz_literals<ASCII>, dim3(a.n_blocks), dim3(256), 0, stream, a.blocks, a.seqs, a.lit, a.blk_base,
-                           a.meta, a.blk_pending, a.out, a.t_char, a.status);
+    const uint64_t *n_total = a.blk_base + a.n_sel_blocks;   // (on the device) elements of the selection, pseudo block included
+    if (!finish) {
+        const uint32_t n_chunks = (a.n_blocks + kRepChunk - 1) / kRepChunk;
+        uint32_t *partial = a.rep_scratch, *chunk_init = a.rep_scratch + 3 * static_cast<size_t>(n_chunks);
+        hipLaunchKernelGGL(k_rep_partial, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, a.blocks, a.n_blocks, a.rep_final, partial,
+                           a.rep_continues, a.status);
+        hipLaunchKernelGGL(k_rep_scan, dim3(1), dim3(1), 0, stream, n_chunks, partial, chunk_init, a.rep_carry[0], a.rep_carry[1],
+                           a.rep_carry[2], static_cast<uint32_t *>(nullptr), a.status);
+        hipLaunchKernelGGL(k_rep_apply, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, a.blocks, a.n_blocks, a.rep_final,
+                           chunk_init, a.rep_init, a.rep_continues, a.rep_out, a.status);
+        if (!a.pj_dist)
+            hipLaunchKernelGGL(k_lz_literals<ASCII>, dim3(a.n_blocks), dim3(256), 0, stream, a.blocks, a.seqs, a.lit, a.blk_base,
+                               a.meta, a.blk_pending, a.out, a.t_char, a.status);
+    }
     if (a.pj_dist) {
         // ---- dense: every element learns its source distance (the same walk puts the literals in place), then the frame
         // is swept (see k_pj_sweep)
         const uint32_t max_dist = pj_max_dist();
-        (void)hipMemsetAsync(a.pj_dist, 0, static_cast<size_t>(a.n_elems) * sizeof(uint32_t), stream);
-        hipLaunchKernelGGL(k_pj_fill<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.rep_init, a.blk_base,
-                           a.pj_dist, a.lit, a.blk_pending, a.out, a.t_char, a.status);
         uint64_t tiles = (a.n_elems + kPjTile - 1) / kPjTile;
         if (tiles > 256u * 16u) tiles = 256u * 16u;
         unsigned long long *pcount = a.counters + 4;       // [4..6]: pending elements, rotating (k_pj_sweep)
         unsigned long long *lstate = a.counters + 10;      // [10..12]: lengths of the pending lists, rotating; [13]: listing since sweep ...
-        (void)hipMemsetAsync(lstate, 0, 4 * sizeof(unsigned long long), stream);
         uint32_t *lists[2] = {a.pj_list[0], a.pj_list[1]};
         const bool can_list = lists[0] && lists[1] && a.n_elems < (1ull << 32);
         uint64_t lg = (a.pj_list_cap / 8 + 255) / 256;     // (a list is at most pj_list_cap long: eight entries per thread and round at that size)
         const uint32_t list_grid = static_cast<uint32_t>(lg < 1 ? 1 : (lg > 256u * 8u ? 256u * 8u : lg));
-        for (uint32_t sweep = 1; sweep <= kPjSweeps; sweep++) {
+        uint64_t eg = (a.n_elems / 4 + 255) / 256;
+        if (eg > 256u * 16u) eg = 256u * 16u;
+        if (eg == 0) eg = 1;
+        uint32_t sweep0 = 1, sweep1 = kPjSweeps;
+        if (!finish) {
+            (void)hipMemsetAsync(a.pj_dist, 0, static_cast<size_t>(a.n_elems) * sizeof(uint32_t), stream);
+            if (wait)
+                hipLaunchKernelGGL(k_fill_u32, dim3(static_cast<uint32_t>(std::min<uint64_t>((a.halo_wait + 255) / 256, 2048))), dim3(256), 0, stream,
+                                   a.pj_dist, a.halo_wait, kPjWait);
+            hipLaunchKernelGGL(k_pj_fill<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.rep_init, a.blk_base,
+                               a.pj_dist, a.lit, a.blk_pending, a.out, a.t_char, a.status);
+            (void)hipMemsetAsync(lstate, 0, 4 * sizeof(unsigned long long), stream);
+        } else {
+            // the window is in the output buffer now: its elements become final words, and a few more sweeps -- chains were
+            // jumped down to their first element inside the window while it was away -- finish what waited for them
+            if (a.halo_wait)
+                hipLaunchKernelGGL(k_pj_halo_words<ASCII>, dim3(static_cast<uint32_t>(std::min<uint64_t>((a.halo_wait + 255) / 256, 2048))), dim3(256), 0,
+                                   stream, a.pj_dist, a.out, a.halo_wait);
+            sweep0 = kPjSweeps + 1;
+            sweep1 = kPjSweeps + kPjFinishSweeps;
+        }
+        for (uint32_t sweep = sweep0; sweep <= sweep1; sweep++) {
             hipLaunchKernelGGL(k_pj_sweep<ASCII>, dim3(static_cast<uint32_t>(tiles)), dim3(256), 0, stream, a.pj_dist, a.out,
                                a.pj_tiles, pcount, a.n_elems, sweep, max_dist, can_list ? lists[sweep & 1u] : nullptr, a.pj_list_cap,
                                lstate, a.status);
             if (can_list && sweep >= 2)
                 hipLaunchKernelGGL(k_pj_list<ASCII>, dim3(list_grid), dim3(256), 0, stream, a.pj_dist, a.out, pcount,
-                                   lists[(sweep & 1u) ^ 1u], lists[sweep & 1u], a.pj_list_cap, lstate, sweep, max_dist, a.status);
+                                   lists[(sweep & 1u) ^ 1u], lists[sweep & 1u], a.pj_list_cap, lstate, sweep, max_dist, finish ? 1u : 0u, a.status);
         }
-        {
-            uint64_t eg = (a.n_elems / 4 + 255) / 256;
-            if (eg > 256u * 16u) eg = 256u * 16u;
-            hipLaunchKernelGGL(k_pj_emit<ASCII>, dim3(static_cast<uint32_t>(eg ? eg : 1)), dim3(256), 0, stream, a.pj_dist, a.out, a.n_elems, a.status);
+        // (finish: the list passes wrote the output themselves; sweeps over all of D did not)
+        hipLaunchKernelGGL(k_pj_emit<ASCII>, dim3(static_cast<uint32_t>(eg)), dim3(256), 0, stream, a.pj_dist, a.out, a.n_elems,
+                           finish ? static_cast<const unsigned long long *>(lstate + 3) : static_cast<const unsigned long long *>(nullptr),
+                           static_cast<unsigned long long>(kPjSweeps), a.status);
+        if (wait) {
+            if (a.tail_elems)
+                hipLaunchKernelGGL(k_pj_tail_check, dim3(64), dim3(256), 0, stream, can_list ? lists[kPjSweeps & 1u] : nullptr, lstate, kPjSweeps,
+                                   a.pj_list_cap, a.pj_tiles, pcount, n_total, a.tail_elems, a.counters + kCtrTail);
+            return;
         }
         // anything still pending (a distance that would not fit 32 bits): frame order
         hipLaunchKernelGGL(k_lz_matches_ordered<ASCII>, dim3(1), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs,
-                           static_cast<SeqMeta *>(nullptr), a.blk_pending, a.rep_init, a.blk_base, a.out, pcount + kPjSweeps % 3u, a.status);
+                           static_cast<SeqMeta *>(nullptr), a.blk_pending, a.rep_init, a.blk_base, a.out, pcount + sweep1 % 3u, a.status);
         return;
     }
     // ---- sparse: matches one by one; pass 1 walks the blocks, the later ones the list of what is still pending
-    if (a.cidx) {
-        uint64_t ib = (a.n_idx_chunks + 255) / 256;
-        if (ib > 256u * 16u) ib = 256u * 16u;
-        hipLaunchKernelGGL(k_lz_index, dim3(static_cast<uint32_t>(ib)), dim3(256), 0, stream, a.meta, a.n_sequences, a.n_idx_chunks,
-                           a.cidx, a.status);
-    }
-    if (!a.plist[0] || !a.plist[1]) {                      // no memory for the pending lists: every pass walks the blocks
-        for (uint32_t pass = 1; pass <= kLzPasses; pass++)
-            hipLaunchKernelGGL(k_lz_match_pass<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.meta,
-                               a.cidx, a.blk_pending, a.roff, a.counters, a.rep_init, a.blk_base, a.out, pass, nullptr,
-                               nullptr, a.status);
-    } else {
-        unsigned long long *lcount = a.counters + 4;       // [4..6]: lengths of the pending lists, rotating (k_lz_match_list)
-        hipLaunchKernelGGL(k_lz_match_pass<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.meta, a.cidx,
-                           a.blk_pending, a.roff, a.counters, a.rep_init, a.blk_base, a.out, 1u, a.plist[0], lcount + 2u, a.status);
-        uint64_t lgrid = (a.n_sequences + 255) / 256;
-        if (lgrid > 256u * 8u) lgrid = 256u * 8u;
-        for (uint32_t pass = 2; pass <= kLzPasses; pass++)   // pass k reads list k & 1 (its length in lcount[k % 3]): pass 1 wrote list 0 / lcount[2]
-            hipLaunchKernelGGL(k_lz_match_list<ASCII>, dim3(static_cast<uint32_t>(lgrid)), dim3(256), 0, stream, a.plist[pass & 1u],
-                               a.plist[(pass & 1u) ^ 1u], lcount, a.seqs, a.meta, a.cidx, a.blk_pending, a.roff, a.counters, a.out,
-                               pass, a.status);
-        hipLaunchKernelGGL(k_lz_finish_small<ASCII>, dim3(1), dim3(1024), 0, stream, a.plist[0], a.plist[1], lcount, kLzPasses + 1u,
-                           a.seqs, a.meta, a.cidx, a.blk_pending, a.roff, a.counters, a.out, a.status);
+    const uint64_t halo_end = wait ? a.halo_wait : 0;
+    const bool lists = a.plist[0] && a.plist[1];
+    if (!finish) {
+        if (a.cidx) {
+            uint64_t ib = (a.n_idx_chunks + 255) / 256;
+            if (ib > 256u * 16u) ib = 256u * 16u;
+            hipLaunchKernelGGL(k_lz_index, dim3(static_cast<uint32_t>(ib)), dim3(256), 0, stream, a.meta, a.n_sequences, a.n_idx_chunks,
+                               a.cidx, a.status);
+        }
+        if (!lists) {                                          // no memory for the pending lists: every pass walks the blocks
+            for (uint32_t pass = 1; pass <= kLzPasses; pass++)
+                hipLaunchKernelGGL(k_lz_match_pass<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.meta,
+                                   a.cidx, a.blk_pending, a.roff, a.counters, a.rep_init, a.blk_base, a.out, pass, nullptr,
+                                   nullptr, halo_end, a.status);
+            if (wait) (void)hipMemsetAsync(a.counters + kCtrTail, 0xFF, 8, stream);   // (not looked at: the next shard waits until this one is whole)
+        } else {
+            unsigned long long *lcount = a.counters + 4;       // [4..6]: lengths of the pending lists, rotating (k_lz_match_list)
+            hipLaunchKernelGGL(k_lz_match_pass<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.meta, a.cidx,
+                               a.blk_pending, a.roff, a.counters, a.rep_init, a.blk_base, a.out, 1u, a.plist[0], lcount + 2u, halo_end, a.status);
+            uint64_t lgrid = (a.n_sequences + 255) / 256;
+            if (lgrid > 256u * 8u) lgrid = 256u * 8u;
+            for (uint32_t pass = 2; pass <= kLzPasses; pass++)   // pass k reads list k & 1 (its length in lcount[k % 3]): pass 1 wrote list 0 / lcount[2]
+                hipLaunchKernelGGL(k_lz_match_list<ASCII>, dim3(static_cast<uint32_t>(lgrid)), dim3(256), 0, stream, a.plist[pass & 1u],
+                                   a.plist[(pass & 1u) ^ 1u], lcount, a.seqs, a.meta, a.cidx, a.blk_pending, a.roff, a.counters, a.out,
+                                   pass, halo_end, a.status);
+            hipLaunchKernelGGL(k_lz_finish_small<ASCII>, dim3(1), dim3(1024), 0, stream, a.plist[0], a.plist[1], lcount, kLzPasses + 1u,
+                               a.seqs, a.meta, a.cidx, a.blk_pending, a.roff, a.counters, a.out, halo_end, 0u, n_total,
+                               wait ? a.tail_elems : 0, a.status);
+        }
+        if (wait) return;
+    } else if (lists) {
+        // the window has arrived: the survivors' list once more, without the limit
+        hipLaunchKernelGGL(k_lz_finish_small<ASCII>, dim3(1), dim3(1024), 0, stream, a.plist[0], a.plist[1], a.counters + 4, 0u,
+                           a.seqs, a.meta, a.cidx, a.blk_pending, a.roff, a.counters, a.out, uint64_t(0), 1u, n_total, uint64_t(0), a.status);
     }
     // deep chains of a sparse section: frame order (returns at once when nothing is pending)
     hipLaunchKernelGGL(k_lz_matches_ordered<ASCII>, dim3(1), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.meta,
                        a.blk_pending, a.rep_init, a.blk_base, a.out, a.counters, a.status);
+}
+
+void launch_rep_map(hipStream_t stream, const SeqBlock *blocks, uint32_t n_blocks, const uint32_t *rep_final, uint32_t *rep_scratch,
+                    uint32_t continues, uint32_t *map_out, uint32_t *status) {
+    if (!n_blocks) return;
+    const uint32_t n_chunks = (n_blocks + kRepChunk - 1) / kRepChunk;
+    uint32_t *partial = rep_scratch, *chunk_init = rep_scratch + 3 * static_cast<size_t>(n_chunks);
+    hipLaunchKernelGGL(k_rep_partial, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, blocks, n_blocks, rep_final, partial, continues, status);
+    hipLaunchKernelGGL(k_rep_scan, dim3(1), dim3(1), 0, stream, n_chunks, partial, chunk_init, kRepToken | (0u << 24), kRepToken | (1u << 24),
+                       kRepToken | (2u << 24), map_out, status);
 }
 
 uint64_t lz_pj_tiles(uint64_t n_elems) { return (n_elems + kPjTile - 1) / kPjTile; }
@@ -3175,12 +3319,11 @@ uint64_t lz_pj_tiles(uint64_t n_elems) { return (n_elems + kPjTile - 1) / kPjTil
 void launch_lz_execute(hipStream_t stream, const LzArgs &a, bool ascii) {
     if (!a.n_blocks) return;
     // [0] matches still pending (sparse), [1] matches the launched passes left to the one-workgroup stage,
-    // [4..6] rotating counters of the stage in use (k_lz_match_list / k_pj_sweep)
-    static thread_local unsigned long long staged[8];      // (the copy is asynchronous: the source must outlive this call)
-    for (int i = 0; i < 8; i++) staged[i] = 0;
-    staged[0] = a.n_sequences;
-    if (a.pj_dist) staged[4] = 1;                          // "pending before the first sweep": anything but 0
-    (void)hipMemcpyAsync(a.counters, staged, sizeof staged, hipMemcpyHostToDevice, stream);
+    // [4..6] rotating counters of the stage in use (k_lz_match_list / k_pj_sweep); set on the device: per-launch
+    // constants do not go through host storage that the next section's launch would overwrite
+    if (a.phase != 2)
+        hipLaunchKernelGGL(k_lz_init_counters, dim3(1), dim3(32), 0, stream, a.counters, static_cast<unsigned long long>(a.n_sequences),
+                           a.pj_dist ? 1ull : 0ull);   // [4] = "pending before the first sweep": anything but 0
     if (ascii)
         lz_execute<true>(stream, a);
     else

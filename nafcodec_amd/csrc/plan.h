@@ -123,6 +123,22 @@ static_assert(sizeof(SeqMeta) == 16, "SeqMeta layout");
 // and k_rep_chain later walks the blocks in frame order to turn every block's final triple into
 // the next block's initial one.
 constexpr uint32_t kRepToken = 0x80000000u;
+// `tok` (an offset, or "inherited rep[slot] - d") applied after the map / triple `f`: maps compose.  The host side of
+// the kernels' rep_apply_entry (shard protocol: the ranks' maps are put together on the host).
+inline uint32_t rep_compose(uint32_t tok, const uint32_t *f, bool *bad) {
+    if (!(tok & kRepToken)) return tok;
+    const uint32_t fv = f[(tok >> 24) & 3u], d = tok & 0xFFFFFFu;
+    if (!(fv & kRepToken)) {
+        if (fv <= d) {
+            *bad = true;
+            return 1;
+        }
+        return fv - d;
+    }
+    const uint32_t d2 = (fv & 0xFFFFFFu) + d;
+    if (d2 > 0xFFFFFFu) *bad = true;
+    return (fv & 0xFF000000u) | (d2 & 0xFFFFFFu);
+}
 
 // device status words
 enum : uint32_t {

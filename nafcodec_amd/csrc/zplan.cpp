@@ -832,16 +832,25 @@ std::string walk_zstd(const uint8_t *payload, size_t n, ZPlan *master, bool *tru
     return std::string();
 }
 
-bool shard_range(const ZPlan &master, uint32_t shard_rank, uint32_t shard_count, uint32_t *b0_out, uint32_t *b1_out) {
-    if (shard_count <= 1 || !master.seq_blocks.empty() || master.blk_size.empty()) return false;
-    // contiguous block ranges balanced by decoded bytes; block boundaries only
-    const uint64_t total = master.known_out;
+bool shard_range(const ZPlan &master, uint32_t shard_rank, uint32_t shard_count, uint32_t *b0_out, uint32_t *b1_out, bool with_lz) {
+    if (shard_count <= 1 || master.blk_size.empty()) return false;
+    if (!master.seq_blocks.empty() && !with_lz) return false;
+    // contiguous block ranges balanced by decoded bytes; block boundaries only.  The decoded size of a block with
+    // sequences is literals + match bytes, the second of which only the device learns: it counts as a full block.
+    const uint32_t nb = static_cast<uint32_t>(master.blk_size.size());
+    size_t sb = 0;
+    auto weight = [&](uint32_t b) -> uint64_t {
+        while (sb < master.seq_blocks.size() && master.seq_blocks[sb].blk < b) sb++;
+        return sb < master.seq_blocks.size() && master.seq_blocks[sb].blk == b ? kBlockMax : master.blk_size[b];
+    };
+    uint64_t total = 0;
+    for (uint32_t b = 0; b < nb; b++) total += weight(b);
+    sb = 0;
     const uint64_t lo_target = total / shard_count * shard_rank + std::min<uint64_t>(shard_rank, total % shard_count);
     const uint64_t hi_target = total / shard_count * (shard_rank + 1) + std::min<uint64_t>(shard_rank + 1, total % shard_count);
     uint64_t pos = 0;
     uint32_t b0 = 0, b1 = 0;
     bool have0 = false;
-    const uint32_t nb = static_cast<uint32_t>(master.blk_size.size());
     for (uint32_t b = 0; b <= nb; b++) {                 // a block belongs to the shard its first byte falls in
         if (!have0 && (pos >= lo_target || b == nb)) {
             b0 = b;
@@ -851,7 +860,7 @@ bool shard_range(const ZPlan &master, uint32_t shard_rank, uint32_t shard_count,
             b1 = b;
             break;
         }
-        if (b < nb) pos += master.blk_size[b];
+        if (b < nb) pos += weight(b);
     }
     if (shard_rank + 1 == shard_count) b1 = nb;
     *b0_out = b0;
@@ -859,13 +868,13 @@ bool shard_range(const ZPlan &master, uint32_t shard_rank, uint32_t shard_count,
     return true;
 }
 
-void select_zplan(const ZPlan &m, uint32_t b0, uint32_t b1, uint64_t halo_elems, ZPlan *out) {
+void select_zplan(const ZPlan &m, uint32_t b0, uint32_t b1, uint64_t halo_elems, ZPlan *out, bool force_halo) {
     ZPlan &p = *out;
     p = ZPlan();
     const uint32_t nb = static_cast<uint32_t>(m.blk_size.size());
     if (b1 > nb) b1 = nb;
     if (b0 > b1) b0 = b1;
-    const uint32_t halo = halo_elems ? 1u : 0u;
+    const uint32_t halo = (halo_elems || force_halo) ? 1u : 0u;
     p.sel_blk0 = b0;
     p.sel_blk1 = b1;
     p.halo = halo;

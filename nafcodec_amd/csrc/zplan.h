@@ -70,14 +70,17 @@ struct ZPlan {
 // `truncated` is set when the payload ends early (maps to Io(UnexpectedEof)).
 std::string walk_zstd(const uint8_t *payload, size_t n, ZPlan *master, bool *truncated);
 // The shard_rank-th of shard_count contiguous block ranges balanced by decoded bytes (block boundaries only).
-// Only for a master without LZ sequences (every block is then independent once treeless chains are resolved,
-// which the walk has done); returns false otherwise.
-bool shard_range(const ZPlan &master, uint32_t shard_rank, uint32_t shard_count, uint32_t *b0, uint32_t *b1);
+// A master without LZ sequences: every block is independent once treeless chains are resolved, which the walk has
+// done.  With sequences (with_lz; else false is returned for such a master) the decoded size of a block is not
+// known on the host -- a block with sequences counts as a full one -- and the shards then depend on each other
+// through the LZ window and the repeat offsets (engine.cpp: the shard protocol).
+bool shard_range(const ZPlan &master, uint32_t shard_rank, uint32_t shard_count, uint32_t *b0, uint32_t *b1, bool with_lz = false);
 // The launchable plan of blocks [b0, b1): task lists re-based to the range (block indices, literal-buffer and
 // sequence offsets, table pools holding only what the range uses), tasks packed into launch classes.
 // halo_elems > 0: block 0 of the selection is a pseudo block of that size standing for the decoded bytes in
 // front of the range (the LZ window of a tile); frames begun in front of the range then start at it.
-void select_zplan(const ZPlan &master, uint32_t b0, uint32_t b1, uint64_t halo_elems, ZPlan *out);
+// force_halo: the pseudo block exists whatever halo_elems says (a shard learns its size later).
+void select_zplan(const ZPlan &master, uint32_t b0, uint32_t b1, uint64_t halo_elems, ZPlan *out, bool force_halo = false);
 // packs the tasks of a plan that holds a whole walk (no selection needed)
 void pack_tasks_public(ZPlan *plan);
 // walk + (shard) + select: the whole section, or one shard of it, in one call

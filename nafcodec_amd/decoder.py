@@ -45,7 +45,7 @@ class Decoder:
     """lib.pyi:35-67.  `file` is a path or a binary file-like object."""
 
     def __init__(self, file, *, id=True, comment=True, sequence=True, quality=True, mask=True, buffer_size=None,
-                 device=-1, spec_mask=False, shard_rank=0, shard_count=1, _lib=None):
+                 device=-1, spec_mask=False, shard_rank=0, shard_count=1, shard_protocol=False, _lib=None):
         self._lib = _lib or _ffi.default()
         self._h = None
         opts = _ffi.Opts()
@@ -55,6 +55,7 @@ class Decoder:
         opts.buffer_size = io.DEFAULT_BUFFER_SIZE if buffer_size is None else int(buffer_size)  # lib.rs:350-354
         opts.device = device
         opts.shard_rank, opts.shard_count = shard_rank, shard_count   # bulk device path only (decode_all_device)
+        opts.shard_protocol = int(bool(shard_protocol))               # ... or the shard protocol (nafcodec_amd.sharding)
         h, err = c_void_p(), _ffi.Error()
         if isinstance(file, (str, bytes, os.PathLike)):
             path = os.fsencode(file)
@@ -196,6 +197,41 @@ class Decoder:
             err = _ffi.Error()
             self._lib.c.nafgpu_last_error(self._h, byref(err))
             _raise(err)
+        return res
+
+    # ---- the shard protocol (include/nafgpu.h: nafgpu_shard_*; nafcodec_amd.sharding drives it) ----
+    def _check(self, rc):
+        if rc != _ffi.OK:
+            err = _ffi.Error()
+            self._lib.c.nafgpu_last_error(self._h, byref(err))
+            _raise(err)
+
+    def shard_begin(self):
+        """-> this rank's 64-byte summary (bytes)"""
+        mine = _ffi.ShardSummary()
+        self._check(self._lib.c.nafgpu_shard_begin(self._h, byref(mine)))
+        return bytes(mine)
+
+    def shard_place(self, summaries):
+        """summaries: the ranks' summaries back to back (bytes-like, 64 bytes per rank, rank order)"""
+        buf = ctypes.create_string_buffer(bytes(summaries), len(summaries))
+        self._check(self._lib.c.nafgpu_shard_place(self._h, ctypes.cast(buf, c_void_p), len(summaries) // ctypes.sizeof(_ffi.ShardSummary)))
+
+    def shard_halo(self, section):
+        """-> (recv_bytes, send_bytes, tail_ready) for section 0 (Sequence) / 1 (Quality)"""
+        recv, send, ready = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_int()
+        self._check(self._lib.c.nafgpu_shard_halo(self._h, section, byref(recv), byref(send), byref(ready)))
+        return recv.value, send.value, bool(ready.value)
+
+    def shard_export_tail(self, section, ptr, n):
+        self._check(self._lib.c.nafgpu_shard_export_tail(self._h, section, ptr, n))
+
+    def shard_import_halo(self, section, ptr, n):
+        self._check(self._lib.c.nafgpu_shard_import_halo(self._h, section, ptr, n))
+
+    def shard_finish(self):
+        res = _ffi.DeviceResult()
+        self._check(self._lib.c.nafgpu_shard_finish(self._h, byref(res)))
         return res
 
     def format_device(self):

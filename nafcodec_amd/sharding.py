@@ -54,3 +54,80 @@ def gather_placement(dist, torch, bases, packed_bytes, first_record, carry, tota
                           total_bases=int(g[:, 0].sum()), total_packed=int(g[:, 1].sum()),
                           total_records=int(total_records),
                           carries=[int(x) for x in g[:, 3]], first_records=firsts)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The shard protocol: sections WITH LZ sequences over several GPUs (include/nafgpu.h: nafgpu_shard_*).
+#
+# A block range of such a section needs two things from the ranges in front of it: the repeat offsets they leave behind
+# and the last window of their output.  Both arrive without a rank waiting for more than it must:
+#   1. every rank entropy-decodes its range (Huffman literals, FSE sequences) and puts together its block sizes and its
+#      repeat-offset map;
+#   2. ONE all-gather of 64 bytes per rank (RCCL over xGMI): decoded sizes and maps -- every rank now knows where its
+#      range begins, which repeat offsets it inherits and how large the window in front of it is;
+#   3. every rank places its literals and resolves every match that does not reach -- directly or through other
+#      matches -- into that window;
+#   4. the windows travel down the line, point to point (ncclSend / ncclRecv, at most window_size bytes each): a rank
+#      whose last window is final already (nothing pending touches it: the usual case) sends at once and receives
+#      afterwards, the others receive, finish, send; the serial part is the handful of matches that waited.
+SUMMARY_BYTES = 64
+
+
+def decode_sharded(dec, dist, torch, device, buffers=None):
+    """One sharded decode of `dec` (a Decoder opened with shard_rank / shard_count / shard_protocol=True) over the
+    process group: returns the nafgpu_device_result of this rank's share.  `device`: "cuda" (RCCL) or "cpu" (gloo)."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mine = torch.frombuffer(bytearray(dec.shard_begin()), dtype=torch.uint8).to(device)
+    everyone = torch.empty(SUMMARY_BYTES * world, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(everyone, mine)
+    dec.shard_place(everyone.cpu().numpy().tobytes())
+    for section in (0, 1):
+        recv_n, send_n, ready = dec.shard_halo(section)
+        pending = None
+        sbuf = rbuf = None
+        if send_n and rank + 1 < world:
+            sbuf = torch.empty(send_n, dtype=torch.uint8, device=device)
+        if send_n and rank + 1 < world and ready:           # the tail is final: it leaves before anything is received
+            dec.shard_export_tail(section, sbuf.data_ptr(), send_n)
+            pending = dist.isend(sbuf, rank + 1)
+        if recv_n and rank > 0:
+            rbuf = torch.empty(recv_n, dtype=torch.uint8, device=device)
+            dist.recv(rbuf, rank - 1)
+            if device != "cpu":
+                torch.cuda.current_stream().synchronize()
+            dec.shard_import_halo(section, rbuf.data_ptr(), recv_n)
+        if send_n and rank + 1 < world and not ready:
+            dec.shard_export_tail(section, sbuf.data_ptr(), send_n)
+            pending = dist.isend(sbuf, rank + 1)
+        if pending is not None:
+            pending.wait()
+    return dec.shard_finish()
+
+
+def decode_sharded_local(decoders):
+    """The same protocol with every rank in THIS process (tests, and several shards on one GPU): `decoders` are the
+    ranks' Decoders in rank order; windows are handed over through host buffers.  Returns their results."""
+    import ctypes
+    world = len(decoders)
+    everyone = b"".join(d.shard_begin() for d in decoders)
+    for d in decoders:
+        d.shard_place(everyone)
+    for section in (0, 1):
+        info = [d.shard_halo(section) for d in decoders]
+        tails = {}
+
+        def export(r):
+            tails[r] = ctypes.create_string_buffer(info[r][1])
+            decoders[r].shard_export_tail(section, ctypes.cast(tails[r], ctypes.c_void_p), info[r][1])
+
+        for r in range(world - 1):                          # tails that are final leave before anything arrives, as over RCCL
+            if info[r][1] and info[r][2]:
+                export(r)
+        for r, d in enumerate(decoders):
+            recv_n, send_n, _ready = info[r]
+            if recv_n and r > 0:
+                assert len(tails[r - 1]) == recv_n, (r, recv_n, len(tails[r - 1]))
+                d.shard_import_halo(section, ctypes.cast(tails[r - 1], ctypes.c_void_p), recv_n)
+            if send_n and r + 1 < world and r not in tails:
+                export(r)
+    return [d.shard_finish() for d in decoders]

@@ -319,22 +319,165 @@ def check_sharding(lib, n_bases, mask, worlds=(2, 3, 5), seed=5):
             pos += r[4]
             ends.append(pos)
         starts = [0] + ends[:-1]
+        from nafcodec_amd.sharding import decode_sharded_local
         for world in worlds:
-            nxt, hsum = 0, 0
-            for rank in range(world):
-                d = Decoder(io.BytesIO(blob), shard_rank=rank, shard_count=world, **kw)
-                res = d.decode_all_device()
-                assert res.sharded == 1 and res.base_offset == nxt
-                assert res.n_bases == 0 or res.base_offset % 4096 == 0
-                hsum = (hsum + d.hash_device(res.d_sequence, res.n_bases, res.base_offset // 4096)) % (1 << 64)
-                want_first = sum(1 for st in starts if st < res.base_offset)
-                assert res.first_record == want_first, (world, rank, res.first_record, want_first)
-                assert res.carry == (0 if res.base_offset in starts or res.base_offset in (0, pos) else 1)
-                assert res.n_records == len(ends)
-                nxt = res.base_offset + res.n_bases
-            assert nxt == arc.n_bases and hsum == arc.seq_hash, (world, nxt, hsum)
+            for protocol in (False, True):           # decode_all_device per shard; the shard protocol (the same ranges, nothing to exchange)
+                nxt, hsum = 0, 0
+                decs = [Decoder(io.BytesIO(blob), shard_rank=rank, shard_count=world, shard_protocol=protocol, **kw) for rank in range(world)]
+                results = decode_sharded_local(decs) if protocol else [d.decode_all_device() for d in decs]
+                for d, res in zip(decs, results):
+                    assert res.sharded == 1 and res.base_offset == nxt
+                    assert res.n_bases == 0 or res.base_offset % 4096 == 0
+                    hsum = (hsum + d.hash_device(res.d_sequence, res.n_bases, res.base_offset // 4096)) % (1 << 64)
+                    want_first = sum(1 for st in starts if st < res.base_offset)
+                    assert res.first_record == want_first, (world, res.first_record, want_first)
+                    assert res.carry == (0 if res.base_offset in starts or res.base_offset in (0, pos) else 1)
+                    assert res.n_records == len(ends)
+                    nxt = res.base_offset + res.n_bases
+                    d.close()
+                assert nxt == arc.n_bases and hsum == arc.seq_hash, (world, protocol, nxt, hsum)
     finally:
         L.c.nafgpu_synth_free(ctypes.byref(arc))
+
+
+def raw_naf(packed=None, n_bases=0, text=None, lens=(), quality=None, level=1, frames=1, line_length=60):
+    """A NAF v1 DNA (packed: numpy uint8 array of 4-bit pairs) or v2 text archive put together from ready-made section
+    contents, the large sections written by libzstd in `frames` frames back to back (a frame ends with a short block and
+    the next one starts from fresh repeat offsets and an empty window: what the shard protocol has to get right)."""
+    import numpy as np
+    import zstd_ref
+
+    def comp(data, lvl=level, n_frames=1):
+        data = bytes(data)
+        if n_frames <= 1:
+            return zstd_ref.compress_magicless(data, lvl, True)
+        cut = [len(data) * k // n_frames for k in range(n_frames + 1)]
+        return b"".join(zstd_ref.compress_magicless(data[a:b], lvl, True) for a, b in zip(cut, cut[1:]))
+
+    words = nw.length_words(lens)
+    if packed is not None:
+        head = bytes([1, 0xF9, 0xEC, 1])
+        flags = 0x0A | (0x01 if quality is not None else 0)
+        secs = [(len(words), comp(words, 1)), (n_bases, comp(packed, level, frames))]
+    else:
+        head = bytes([1, 0xF9, 0xEC, 2, 3])
+        flags = 0x0A | (0x01 if quality is not None else 0)
+        secs = [(len(words), comp(words, 1)), (len(text), comp(text, level, frames))]
+    if quality is not None:
+        secs.append((len(quality), comp(quality, level, frames)))
+    blob = bytearray(head) + bytes([flags, 0x20]) + nw.varint(line_length) + nw.varint(len(lens))
+    for orig, payload in secs:
+        blob += nw.varint(orig) + nw.varint(len(payload)) + payload
+    return bytes(blob)
+
+
+def lz_shard_archives(scale=1):
+    """(name, archive bytes, expected sequence bytes, expected quality bytes or None, record lengths) -- archives whose
+    sections hold LZ sequences, for the shard protocol: the statistics of a real genome (the reference's fixture tiled,
+    libzstd level 1: a few far matches per block), level-3 DNA (a quarter of the bytes are matches at random distances:
+    swept), FASTQ-like reads with qualities (both sections swept, the Length section one long chain), the same in
+    several frames, and text with dense short-offset chains."""
+    import numpy as np
+    from conftest import golden_bytes
+    from oracle import oracle
+    rng = np.random.default_rng(99)
+    lut = np.frombuffer(nw.NUC.encode(), dtype=np.uint8)
+    code = np.zeros(256, dtype=np.uint8)
+    for i, c in enumerate(nw.NUC.encode()):
+        code[c] = i
+    out = []
+
+    def dna(name, packed, level, frames=1, lens=None, quality=None):
+        n_bases = 2 * len(packed)
+        want = np.empty(n_bases, dtype=np.uint8)
+        want[0::2] = lut[packed & 15]
+        want[1::2] = lut[packed >> 4]
+        lens = [n_bases] if lens is None else lens
+        out.append((name, raw_naf(packed=packed.tobytes(), n_bases=n_bases, lens=lens, quality=quality, level=level, frames=frames),
+                    want.tobytes(), quality, lens))
+
+    fixture = "".join(r.sequence.upper() for r in oracle.Decoder(golden_bytes("NZ_AAEN01000029.naf"))).encode()
+    nib = code[np.frombuffer(fixture, dtype=np.uint8)]
+    one = (nib[0:len(nib) & ~1:2] | (nib[1::2] << 4)).astype(np.uint8)
+    dna("real_genome_l1", np.tile(one[:len(one) // (4 if scale == 1 else 1)], 2 * scale), 1)
+    codes = np.array([1, 2, 4, 8], dtype=np.uint8)
+    n = 600_000 * scale
+    dna("random_dna_l3", (codes[rng.integers(0, 4, n)] | (codes[rng.integers(0, 4, n)] << 4)).astype(np.uint8), 3)
+    dna("random_dna_l3_frames", (codes[rng.integers(0, 4, n)] | (codes[rng.integers(0, 4, n)] << 4)).astype(np.uint8), 3, frames=3)
+    n_reads = 1500 * scale
+    nb = n_reads * 151 + (n_reads * 151 & 1)
+    nibs = codes[rng.integers(0, 4, nb)]
+    qalpha = np.frombuffer(b"#8CGGGGGGGGGG<AFFFJJJJJJJJJJJJJJ", dtype=np.uint8)
+    for lvl, frames in ((1, 1), (3, 2)):
+        qual = qalpha[rng.integers(0, len(qalpha), n_reads * 151)].tobytes()
+        packed = (nibs[0::2] | (nibs[1::2] << 4)).astype(np.uint8)
+        n_bases = n_reads * 151
+        want = np.empty(2 * len(packed), dtype=np.uint8)
+        want[0::2] = lut[packed & 15]
+        want[1::2] = lut[packed >> 4]
+        out.append(("fastq_like_l%d" % lvl, raw_naf(packed=packed.tobytes(), n_bases=n_bases, lens=[151] * n_reads, quality=qual, level=lvl, frames=frames),
+                    want.tobytes()[:n_bases], qual, [151] * n_reads))
+    dense = bytes(rng.choice(np.frombuffer(b"GGGGGGGJJJJF#", dtype=np.uint8), 400_000 * scale))
+    out.append(("text_dense_chains_frames", raw_naf(text=dense, lens=[len(dense)], level=3, frames=2), dense, None, [len(dense)]))
+    return out
+
+
+def check_lz_sharding(lib, scale=1, worlds=(2, 3, 8), names=None, force_modes=(None,)):
+    """The shard protocol (nafgpu_shard_*, nafcodec_amd.sharding.decode_sharded_local: every rank in this process) on
+    archives whose sections hold LZ sequences: every rank reports sharded = 1, the shards tile the Sequence and the Quality
+    sections, put together they are what the archive decodes to (and what the oracle says it decodes to), and first_record /
+    carry place every shard in the record table."""
+    import io
+    import os
+    from nafcodec_amd import _ffi
+    from nafcodec_amd.decoder import Decoder
+    from nafcodec_amd.sharding import decode_sharded_local
+    from oracle import oracle
+    L = lib or _ffi.default()
+    kw = {} if lib is None else {"_lib": lib}
+    for name, blob, want_seq, want_qual, lens in lz_shard_archives(scale):
+        if names is not None and name not in names:
+            continue
+        chk = oracle.Decoder(blob).drain(want_hash=True)                      # the checker's word on the whole archive
+        assert chk.n_bases == len(want_seq) and chk.seq_hash == L.c.nafgpu_hash64_host(want_seq, len(want_seq)), name
+        if want_qual is not None:
+            assert chk.qual_hash == L.c.nafgpu_hash64_host(want_qual, len(want_qual)), name
+        ends, pos = [], 0
+        for n in lens:
+            pos += n
+            ends.append(pos)
+        starts = [0] + ends[:-1]
+        for mode in force_modes:
+            if mode is not None:
+                L.c.nafgpu_test_hooks(1)
+                os.environ["NAFGPU_LZ_MODE"] = mode
+            try:
+                for world in worlds:
+                    decs = [Decoder(io.BytesIO(blob), shard_rank=r, shard_count=world, shard_protocol=True, **kw) for r in range(world)]
+                    res = decode_sharded_local(decs)
+                    nxt = qnxt = 0
+                    hsum, aligned = 0, True
+                    for d, x in zip(decs, res):
+                        assert x.sharded == 1 and x.base_offset == nxt and x.quality_offset == qnxt, (name, world, mode)
+                        got = d.copy_to_host(x.d_sequence, x.n_bases)
+                        assert got == want_seq[nxt:nxt + x.n_bases], (name, world, mode, "sequence of rank", decs.index(d))
+                        if want_qual is not None:
+                            assert d.copy_to_host(x.d_quality, x.n_quality) == want_qual[qnxt:qnxt + x.n_quality], (name, world, mode, "quality")
+                        aligned = aligned and x.base_offset % 4096 == 0
+                        if aligned:
+                            hsum = (hsum + d.hash_device(x.d_sequence, x.n_bases, x.base_offset // 4096)) % (1 << 64)
+                        assert x.first_record == sum(1 for st in starts if st < x.base_offset), (name, world)
+                        assert x.carry == (0 if x.base_offset in starts or x.base_offset in (0, pos) else 1), (name, world)
+                        assert x.n_records == len(lens)
+                        nxt += x.n_bases
+                        qnxt += x.n_quality
+                    assert nxt == len(want_seq) and qnxt == (len(want_qual) if want_qual is not None else 0), (name, world)
+                    if aligned:
+                        assert hsum == chk.seq_hash, (name, world, "summed checksums against the oracle's")
+                    for d in decs:
+                        d.close()
+            finally:
+                os.environ.pop("NAFGPU_LZ_MODE", None)
 
 
 def zstd_payload_cases(scale=1):

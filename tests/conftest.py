@@ -22,3 +22,9 @@ def golden_bytes(name):
 @pytest.fixture(scope="session")
 def golden():
     return golden_bytes
+
+
+def enable_hooks(lib=None):
+    """The library reads its NAFGPU_* experiment variables only after nafgpu_test_hooks(1) (include/nafgpu.h)."""
+    from nafcodec_amd import _ffi
+    (lib or _ffi.default()).c.nafgpu_test_hooks(1)

@@ -27,7 +27,7 @@ def test_bench_contract(world):
     subprocess.check_call(["make", "-s", "-C", csrc, "emu"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     env = dict(os.environ, OMP_NUM_THREADS="1")
     args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--bases", "600001", "--cpu-sample-bases", "200000",
-            "--rehearsal-lib", os.path.join(ROOT, "tests", "emu", "_build", "libnafgpu_emu.so")]
+            "--real-copies-per-gpu", "1", "--rehearsal-lib", os.path.join(ROOT, "tests", "emu", "_build", "libnafgpu_emu.so")]
     if world == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     else:
@@ -51,6 +51,9 @@ def test_bench_contract(world):
         assert j["config"]["oracle_checked_bases"] > 0
     else:
         assert "ONE archive" in j["config"]["sharding"]      # configs[4]: block ranges of one archive, not one archive per rank
+        if zstd_ref.available():                             # the archive WITH LZ sequences went through the shard protocol on the same ranks
+            real = j["path"]["real_genome"]
+            assert real["n_gpus"] == world and real["bases"] == 2 * 5488676 and "shard protocol" in real["workload"]
     assert "passed" in j["config"]["workload"]  # the full-size checksum check ran and held on every rank
 
 
@@ -66,7 +69,7 @@ def test_real_genome_leg_runs_and_checks_itself():
     import bench
     from nafcodec_amd import _ffi
     leg = bench.real_genome_leg(_ffi.Library(os.path.join(ROOT, "tests", "emu", "_build", "libnafgpu_emu.so")), 0, 1)
-    assert leg["bases"] == 5488676 and "bit-exact check passed" in leg["workload"]
+    assert leg["bases"] == 5488676 and "output checksum equals the tiled fixture" in leg["workload"]
     assert set(leg["roofline"]) >= {"bound", "achieved", "peak", "frac", "algorithmic_bytes_per_step"}
 
 
@@ -79,7 +82,7 @@ def test_three_ranks_share_the_one_gpu():
     env = dict(os.environ, OMP_NUM_THREADS="4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
-           "--bases", "2e9", "--no-cpu", "--rehearsal-one-gpu"]
+           "--bases", "2e9", "--no-cpu", "--rehearsal-one-gpu", "--real-copies-per-gpu", "200"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -87,6 +90,9 @@ def test_three_ranks_share_the_one_gpu():
     j = json.loads(lines[0])
     assert j["metric"].startswith("REHEARSAL") and j["value"] is None and j["n_gpus"] == world
     assert "ONE archive" in j["config"]["sharding"] and "passed" in j["config"]["workload"]
+    # ... and the real-genome archive (a few LZ sequences per block) through the shard protocol on the same three ranks
+    real = j["path"]["real_genome"]
+    assert real["n_gpus"] == world and real["bases"] == 600 * 5488676 and "shard protocol" in real["workload"]
 
 
 RCCL_PROBE = r"""

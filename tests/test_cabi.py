@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_ffi.EXPORTS)
     for name in declared:
         assert hasattr(lib.c, name), name
-    assert lib.c.nafgpu_abi_version() == 1
+    assert lib.c.nafgpu_abi_version() == 2
 
 
 def test_struct_layouts_match_header(lib):
@@ -33,6 +33,7 @@ def test_struct_layouts_match_header(lib):
     assert ctypes.sizeof(_ffi.Opts) == 32 and ctypes.sizeof(_ffi.Header) == 24
     assert ctypes.sizeof(_ffi.Field) == 24 and ctypes.sizeof(_ffi.Record) == 4 * 24 + 16
     assert ctypes.sizeof(_ffi.Error) == 16 + 192
+    assert ctypes.sizeof(_ffi.ShardSummary) == 64          # gathered over the ranks as it is (nafcodec_amd/sharding.py)
     o = _ffi.Opts()
     lib.c.nafgpu_opts_default(ctypes.byref(o))   # DecoderBuilder::new(), mod.rs:67-76
     assert (o.id, o.comment, o.sequence, o.quality, o.mask, o.buffer_size, o.device, o.shard_count) == (1, 1, 1, 1, 1, 4096, -1, 1)

@@ -66,6 +66,7 @@ def test_lz_stages_dense_and_sparse(emu, all_cases, monkeypatch):
     import io
     from nafcodec_amd.decoder import Decoder
     from oracle import oracle
+    emu.c.nafgpu_test_hooks(1)
     for mode in ("dense", "sparse"):
         monkeypatch.setenv("NAFGPU_LZ_MODE", mode)
         for name, blob, opts in all_cases:
@@ -83,6 +84,7 @@ def test_pointer_jumping_distance_limit_falls_back_to_frame_order(emu, all_cases
     """D holds 32-bit distances: a chain longer than that cannot be jumped to its end.  With the limit lowered
     to a few elements (NAFGPU_PJ_MAX_DIST) distances stop growing while elements still point at pending ones;
     what the sweeps then leave is finished in frame order -- and the bytes stay exact."""
+    emu.c.nafgpu_test_hooks(1)
     monkeypatch.setenv("NAFGPU_LZ_MODE", "dense")
     for limit in ("8", "64"):
         monkeypatch.setenv("NAFGPU_PJ_MAX_DIST", limit)
@@ -94,6 +96,15 @@ def test_pointer_jumping_distance_limit_falls_back_to_frame_order(emu, all_cases
 def test_block_range_sharding(emu):
     cases.check_sharding(emu, 3_000_001, True)
     cases.check_sharding(emu, 1_500_000, False, worlds=(2, 8))
+
+
+def test_shard_protocol_on_sections_with_lz_sequences(emu):
+    """SURVEY 8e for archives as found in the wild: sections WITH LZ sequences over 2 / 3 / 8 block ranges through the
+    shard protocol (nafgpu_shard_*) -- real-genome statistics, level-3 DNA in one and in three frames, FASTQ-like reads
+    (Sequence and Quality both sharded), dense chains in two frames; both match routes where the archive is small."""
+    cases.check_lz_sharding(emu, 1, worlds=(2, 3, 8), names=("real_genome_l1", "random_dna_l3_frames", "text_dense_chains_frames"))
+    cases.check_lz_sharding(emu, 1, worlds=(3,), names=("random_dna_l3", "fastq_like_l1", "fastq_like_l3"))
+    cases.check_lz_sharding(emu, 1, worlds=(2,), names=("random_dna_l3_frames", "text_dense_chains_frames"), force_modes=("dense", "sparse"))
 
 
 def test_synthetic_writer_roundtrip(emu):

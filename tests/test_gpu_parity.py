@@ -206,6 +206,7 @@ def test_lz_stages_dense_and_sparse(lib, monkeypatch):
     import nafcodec_amd
     todo = [c for c in cases.build_cases(scale=4) if c[0] in ("text_dense_chains", "dna_dense_chains", "dna_homopolymer", "dna_l3",
                                                               "dna_l3_big", "text_quality", "dna_repeats_l1", "fastq_flush_per_record")]
+    lib.c.nafgpu_test_hooks(1)
     for mode in ("dense", "sparse"):
         monkeypatch.setenv("NAFGPU_LZ_MODE", mode)
         for name, blob, opts in todo:
@@ -234,6 +235,15 @@ def test_block_range_sharding(lib):
     import cases
     cases.check_sharding(None, 40_000_001, True, worlds=(2, 8))
     cases.check_sharding(None, 3_000_001, False, worlds=(3,))
+
+
+def test_shard_protocol_on_sections_with_lz_sequences(lib):
+    """One archive WITH LZ sequences over 2 / 3 / 8 block ranges (the shard protocol, every rank in this process): the
+    statistics of a real genome, level-3 DNA (one frame, three frames), FASTQ-like reads at levels 1 and 3, dense chains;
+    the route the library picks and both routes forced."""
+    import cases
+    cases.check_lz_sharding(None, 8, worlds=(2, 3, 8))
+    cases.check_lz_sharding(None, 4, worlds=(3,), force_modes=("dense", "sparse"))
 
 
 GOLDEN_TEXT = [("LuxC", "LuxC.faa"), ("masked", "masked.fna"), ("phix", "phix.fastq")]

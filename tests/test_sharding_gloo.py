@@ -45,3 +45,62 @@ def test_offset_gather_two_and_three_ranks(tmp_path):
                            env=dict(os.environ, OMP_NUM_THREADS="1"))
         assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
         assert p.stdout.count("ok") == n
+
+
+PROTOCOL_WORKER = r"""
+import io, os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import torch, torch.distributed as dist
+import cases
+from nafcodec_amd import _ffi
+from nafcodec_amd.decoder import Decoder
+from nafcodec_amd.sharding import decode_sharded
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+emu = _ffi.Library(os.path.join(%r, "tests", "emu", "_build", "libnafgpu_emu.so"))
+for name, blob, want_seq, want_qual, lens in cases.lz_shard_archives(1):
+    if name not in ("real_genome_l1", "random_dna_l3_frames", "fastq_like_l1"):
+        continue
+    dec = Decoder(io.BytesIO(blob), shard_rank=r, shard_count=w, shard_protocol=True, _lib=emu)
+    for _ in range(2):                                     # (a second decode: the protocol starts over)
+        res = decode_sharded(dec, dist, torch, "cpu")
+    assert res.sharded == 1
+    got = dec.copy_to_host(res.d_sequence, res.n_bases)
+    assert got == want_seq[res.base_offset:res.base_offset + res.n_bases], (name, r, "sequence")
+    if want_qual is not None:
+        assert dec.copy_to_host(res.d_quality, res.n_quality) == want_qual[res.quality_offset:res.quality_offset + res.n_quality], (name, r)
+    # the shards tile the sections: sizes added up over the ranks
+    t = torch.tensor([res.n_bases, res.n_quality], dtype=torch.int64)
+    dist.all_reduce(t)
+    assert int(t[0]) == len(want_seq) and int(t[1]) == (len(want_qual) if want_qual is not None else 0), name
+    # ... in rank order
+    offs = torch.zeros(w, dtype=torch.int64)
+    offs[r] = res.base_offset
+    dist.all_reduce(offs)
+    assert list(offs) == sorted(offs) and int(offs[0]) == 0
+    dec.close()
+dist.barrier()
+dist.destroy_process_group()
+print("rank", r, "ok")
+"""
+
+
+def test_shard_protocol_over_gloo_two_and_three_ranks(tmp_path):
+    """The shard protocol's exchange (one all-gather of 64 bytes, then the windows point to point) between real
+    processes: gloo ranks driving the CPU harness decode archives WITH LZ sequences -- the statistics of a real genome,
+    level-3 DNA in three frames, FASTQ-like reads -- and every rank's share must be its part of the whole."""
+    import zstd_ref
+    import pytest
+    if not zstd_ref.available():
+        pytest.skip("libzstd not loadable (the archives are written with it)")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "nafcodec_amd", "csrc"), "emu"],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    script = tmp_path / "protocol_worker.py"
+    script.write_text(PROTOCOL_WORKER % (ROOT, ROOT, ROOT))
+    for n in (2, 3):
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+                            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
+                           capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, OMP_NUM_THREADS="1"))
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        assert p.stdout.count("ok") == n

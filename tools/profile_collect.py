@@ -42,24 +42,40 @@ if stats:
         if "k_huf_decode" in r["Name"]:
             avg_ms = float(r["AverageNs"]) / 1e6
             break
-# the timed launches alone (the stats file's average also counts the warm-up launches): last `steps` launches of the kernel trace
-timed_avg = None
-trace = first(os.path.join(G, "%s_headline" % tag, "**", "*kernel_trace.csv"))
-if trace:
-    rows = [r for r in csv.DictReader(open(trace)) if "k_huf_decode" in r["Kernel_Name"]]
-    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows][-5:]
-    if d:
-        timed_avg = sum(d) / len(d)
 bench_line = None
 log = os.path.join(G, "%s_headline.log" % tag)
 if os.path.exists(log):
     for l in open(log, errors="replace"):
         if l.startswith("{") and '"metric"' in l:
             bench_line = json.loads(l)
+# the timed launches alone (the stats file's average also counts the warm-up launches): the last `steps` launches of the
+# kernel trace, `steps` taken from the bench line that run printed
+timed_avg = None
+steps = int(bench_line["steps"]) if bench_line else 5
+trace = first(os.path.join(G, "%s_headline" % tag, "**", "*kernel_trace.csv"))
+if trace:
+    rows = [r for r in csv.DictReader(open(trace)) if "k_huf_decode" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows][-steps:]
+    if d:
+        timed_avg = sum(d) / len(d)
+# the PMC passes run the same workload: its size comes from the bench line of one of them
+pmc_line = None
+plog = os.path.join(G, "%s_pmc_fetch.log" % tag)
+if os.path.exists(plog):
+    for l in open(plog, errors="replace"):
+        if l.startswith("{") and '"metric"' in l:
+            pmc_line = json.loads(l)
+n_bases = None
+for line in (pmc_line, bench_line):
+    m = line and re.search(r"(\d+) bases", line["config"]["workload"])
+    if m:
+        n_bases = int(m.group(1))
+        break
 if fetch and write:
     out = {
-        "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu --no-verify --real-copies 0 (40e9 bases, 10.0 GB archive), one rocprofv3 --pmc pass per counter group (tools/profile_round.sh)",
+        "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu --no-verify --real-copies 0, one rocprofv3 --pmc pass per counter group (tools/profile_round.sh)",
+        "n_bases": n_bases,
         "kernel": "k_huf_decode<true, 0, false>",
         "launches_averaged": nf.get("FETCH_SIZE"),
         "FETCH_SIZE_raw_KB": fetch["FETCH_SIZE"], "WRITE_SIZE_raw_KB": write["WRITE_SIZE"],

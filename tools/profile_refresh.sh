@@ -10,4 +10,3 @@ for pair in "real tools/real_probe.py 3000" "fq tools/fastq_probe.py 10e6" "l3 t
 done
 python3 bench.py > gpurun_out/${tag}_bench_full.log 2>&1
 tail -1 gpurun_out/${tag}_bench_full.log | cut -c1-200
-python3 -m pytest tests -m gpu -x -q 2>&1 | tail -2

@@ -39,6 +39,7 @@ for level in (1,):
     libs = [None] + [x for x in os.environ.get("NAFGPU_PROBE_LIBS", "").split(",") if x]
     for path in libs:
         L = _ffi.default() if path is None else _ffi.Library(os.path.join(R, path))
+        L.c.nafgpu_test_hooks(1)
         if path is None: os.environ["NAFGPU_DEBUG_PLAN"] = "1"
         dec = nafcodec_amd.Decoder(io.BytesIO(arc), _lib=L)
         res = dec.decode_all_device()

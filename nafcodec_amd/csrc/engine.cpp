@@ -261,6 +261,9 @@ Failure SectionJob::load_tile(uint32_t t, hipStream_t stream) {
     n_tasks_ = plan_.tasks.size();
     n_copies_ = plan_.copies.size();
     n_seq_blocks_ = plan_.seq_blocks.size();
+    cells_cap_ = 0;
+    for (const SeqBlock &sb : plan_.seq_blocks)
+        cells_cap_ = std::max<uint32_t>(cells_cap_, (1u << sb.ll_al) + (1u << sb.of_al) + (1u << sb.ml_al));
     classes_ = plan_.classes;                              // launch classes of the Huffman tasks (plan.h: HufClass)
     // frames with a Content_Checksum: the pieces of them this tile holds (a frame begun in front of a shard's range
     // cannot be verified by this process)
@@ -419,7 +422,8 @@ void SectionJob::run_k2_ahead(hipStream_t st) {
     uint32_t *status = d_status_.as<uint32_t>();
     (void)hipMemsetAsync(status, 0, 64, st);
     launch_seq_decode(st, d_src_, d_seq_blocks_.as<SeqBlock>(), static_cast<uint32_t>(n_seq_blocks_), d_cells_.as<SeqCell>(),
-                      d_seqs_.as<Seq>(), d_meta_.as<SeqMeta>(), d_blk_size_.as<uint32_t>(), d_rep_final_.as<uint32_t>(), status);
+                      d_seqs_.as<Seq>(), d_meta_.as<SeqMeta>(), d_blk_size_.as<uint32_t>(), d_rep_final_.as<uint32_t>(), status,
+                      cells_cap_, static_cast<long long>(plan_.src_lo) - static_cast<long long>(kSrcFrontPad));
     k2_ahead_ = hip_ok(hipEventRecord(ev_k2_, st));
     if (!k2_ahead_) (void)hipStreamSynchronize(st);         // (cannot happen; run() then simply does it again)
 }
@@ -464,7 +468,7 @@ void SectionJob::run_front(hipStream_t stream, StageTimer *timer, hipStream_t au
         launch_seq_decode(stream, d_src_, d_seq_blocks_.as<SeqBlock>(), static_cast<uint32_t>(n_seq_blocks_),
                           d_cells_.as<SeqCell>(), d_seqs_.as<Seq>(), d_meta_.as<SeqMeta>(), d_blk_size_.as<uint32_t>(),
                           d_rep_final_.as<uint32_t>(),
-                          status);
+                          status, cells_cap_, static_cast<long long>(plan_.src_lo) - static_cast<long long>(kSrcFrontPad));
         if (timer) timer->end(stream);
     }
     *early_out = early;

@@ -196,7 +196,7 @@ private:
     uint64_t expect_ = 0, n_blocks_ = 0, n_streams_ = 0, n_tasks_ = 0, n_copies_ = 0, n_seq_blocks_ = 0;
     uint64_t master_blocks_ = 0, master_streams_ = 0, src_resident_ = 0;
     std::vector<HufClass> classes_;
-    uint32_t t_char_ = 0;
+    uint32_t t_char_ = 0, cells_cap_ = 0;
     bool sharded_ = false;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;   // K1 on two streams (created on first use, destroyed with the job)
     hipEvent_t ev_early_fork_ = nullptr, ev_early_join_ = nullptr;   // literal-buffer classes of K1 beside K2

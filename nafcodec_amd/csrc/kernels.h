@@ -24,8 +24,11 @@ struct ScanTotals {          // written by the scan kernels
 // cursor of every sequence) and k_seq_values (one wave per block: values, positions, repeat offsets).  Adds match bytes to
 // blk_size[].  `meta` is scratch here (the 8-byte state records): nothing else uses it before k_lz_literals.
 // rep_final: 3 u32 per block -- the repeat offsets the block ends with (concrete or kRepToken tokens)
+// cells_cap: most cells (LL + OF + ML tables together) any of the blocks has; src_min: lowest payload offset that may be read
+// (both for the variant of k_seq_states that keeps tables and bitstream in LDS; cells_cap = 0: never that one)
 void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *blocks, uint32_t n_blocks,
-                       const SeqCell *cells, Seq *seqs, SeqMeta *meta, uint32_t *blk_size, uint32_t *rep_final, uint32_t *status);
+                       const SeqCell *cells, Seq *seqs, SeqMeta *meta, uint32_t *blk_size, uint32_t *rep_final, uint32_t *status,
+                       uint32_t cells_cap = 0, long long src_min = 0);
 
 // K3: exclusive scan of u32 block sizes -> u64 bases (n+1 entries; the last is the total).
 // `tile_tmp` needs scan_tmp_bytes(n) bytes.  Flags status if the total differs from `expect_total`.

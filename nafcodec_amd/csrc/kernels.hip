@@ -934,6 +934,166 @@ __global__ __launch_bounds__(64) void k_seq_states(const uint8_t *__restrict__ s
     if (pos != 0) flag_error(status, kStSeqBadEnd, sb.blk);
 }
 
+// k_seq_states with the chain's memory in LDS: the first dword of every cell of the block's three tables, and the
+// bitstream through a 2 KiB ring per block -- no global load sits between two sequences any more: the dependent chain is
+// two LDS latencies (~64 cycles each: the three cells, then the two ring dwords they point at) plus ~35 instructions, instead of an L2
+// latency (~225) plus 55.  Every kSeqBatch sequences the wave tops the rings up together: a block whose cursor has left
+// the upper half of its ring gets the KiB below the ring in its place, from registers that were loaded a batch earlier
+// (one chunk per block is always on its way), so no wait sits in front of the top-up either.
+// Only for sections whose blocks are all resident at once (launch_seq_decode: LDS per block = cells + ring, 160 KiB per
+// CU): beyond that the blocks would run in batches, and two batches at half the time per sequence are no faster than
+// one batch out of L2.
+constexpr uint32_t kSeqRing = 2048;          // bytes of bitstream per block in LDS (+ a 16-byte guard: a dword pair never wraps)
+constexpr uint32_t kSeqBatch = 88;           // sequences between top-ups: 88 x 89 bits + a dword pair < 1020 bytes, what a ring always holds below its cursor
+constexpr uint32_t kSeqLdsLanes = 8;         // most blocks per wave
+
+__global__ __launch_bounds__(64) void k_seq_states_lds(const uint8_t *__restrict__ src, const SeqBlock *__restrict__ blocks,
+                                                       uint32_t n_blocks, const SeqCell *__restrict__ cells, SeqRec *recs,
+                                                       uint32_t lanes, uint32_t cells_cap, long long src_min, uint32_t *status) {
+    HIP_DYNAMIC_SHARED(uint32_t, s_seq)                   // per block: cells_cap cell dwords, then (kSeqRing + 16) / 4 ring dwords
+    __shared__ uint64_t s_at[kSeqLdsLanes];               // payload offset of the chunk a block wants loaded
+    __shared__ uint32_t s_cmd[kSeqLdsLanes], s_ro[kSeqLdsLanes];   // bit 0: write the chunk in flight at ring offset s_ro; bit 1: load the chunk at s_at
+    if (status[0] != 0) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b0 = blockIdx.x * lanes;
+    const uint32_t per = cells_cap + (kSeqRing + 16) / 4;
+    // ---- the tables of the wave's blocks: first dword of every cell (next_base | nb << 16 | extra_bits << 24)
+    for (uint32_t j = 0; j < lanes && b0 + j < n_blocks; j++) {
+        const SeqBlock bj = blocks[b0 + j];
+        uint32_t *t = s_seq + j * per;
+        const uint32_t nl = 1u << bj.ll_al, no = 1u << bj.of_al, nm = 1u << bj.ml_al;
+        for (uint32_t i = tid; i < nl; i += 64) t[i] = *reinterpret_cast<const uint32_t *>(cells + bj.ll_tbl + i);
+        for (uint32_t i = tid; i < no; i += 64) t[nl + i] = *reinterpret_cast<const uint32_t *>(cells + bj.of_tbl + i);
+        for (uint32_t i = tid; i < nm; i += 64) t[nl + no + i] = *reinterpret_cast<const uint32_t *>(cells + bj.ml_tbl + i);
+    }
+    const bool live = tid < lanes && b0 + tid < n_blocks;
+    SeqBlock sb{};
+    if (live) sb = blocks[b0 + tid];
+    // Ring geometry.  Payload byte x lives at ring offset (x - lo0) mod kSeqRing, lo0 = the lowest byte of the first
+    // fill (16-byte aligned; the stream's last byte in the ring's top 16 bytes).  The ring holds payload bytes
+    // [lo, lo + kSeqRing); lo moves down a KiB per top-up, so chunks never wrap and the one at ring offset 0 refreshes the guard.
+    const uint64_t end_off = sb.bits_off + sb.bits_len;                  // one past the stream's last byte
+    const uint64_t lo0 = ((end_off + 15) & ~uint64_t(15)) - kSeqRing;    // (wraps below zero for a stream near the payload's start: never dereferenced there)
+    uint64_t lo = lo0;
+    // ---- first fill: both halves of every block's ring; and the first chunk below goes on its way
+    if (live) s_at[tid] = lo0;
+    wave_sync();
+    uint4 fly[kSeqLdsLanes];                                             // the chunk in flight of every block (this thread's 16 bytes of it)
+    auto load16 = [&](uint64_t at) -> uint4 {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (static_cast<long long>(at) >= src_min) v = *reinterpret_cast<const uint4 *>(src + at);
+        return v;
+    };
+#pragma unroll
+    for (uint32_t j = 0; j < kSeqLdsLanes; j++) {
+        fly[j] = make_uint4(0, 0, 0, 0);
+        if (j < lanes && b0 + j < n_blocks) {
+            const uint64_t base = s_at[j];
+            uint32_t *rj = s_seq + j * per + cells_cap;
+            const uint4 h0 = load16(base + 16 * tid), h1 = load16(base + 1024 + 16 * tid);
+            *reinterpret_cast<uint4 *>(rj + 4 * tid) = h0;
+            *reinterpret_cast<uint4 *>(rj + 256 + 4 * tid) = h1;
+            if (tid == 0) *reinterpret_cast<uint4 *>(rj + kSeqRing / 4) = h0;     // the guard mirrors ring bytes 0..15
+            fly[j] = load16(base - 1024 + 16 * tid);
+        }
+    }
+    wave_sync();
+    const uint32_t *ring = s_seq + (tid < lanes ? tid : 0) * per + cells_cap;
+    // stream bit p (0 = lowest bit of the stream's first byte) is ring bit (bit0 + p) mod (8 kSeqRing)
+    const uint32_t bit0 = static_cast<uint32_t>((sb.bits_off - lo0) & (kSeqRing - 1)) * 8u;
+    // the <= 26-bit field whose lowest bit is stream bit p_low: two ring dwords (the guard takes the one past the ring's end),
+    // addressed once the cells have said where the field lies -- a second LDS latency on the chain, but no selects
+    auto field = [&](uint32_t p_low) -> uint32_t {
+        const uint32_t rb = (bit0 + p_low) & (kSeqRing * 8 - 1);
+        const uint32_t *w = ring + (rb >> 5);
+        return __builtin_amdgcn_alignbit(w[1], w[0], rb & 31u);
+    };
+    int32_t pos = -1;                                                    // unread bits below the cursor (as in k_seq_states)
+    uint32_t sl = 0, so = 0, sm = 0, n = 0;
+    SeqRec *dst = recs + sb.seq_first;
+    if (live) {
+        const uint32_t lastb = src[end_off - 1];                         // host checked: non-zero
+        pos = static_cast<int32_t>(sb.bits_len - 1) * 8 + (31 - __clz(static_cast<int>(lastb | 1u)));
+        n = sb.n_seq;
+        const int32_t p1 = pos - static_cast<int32_t>(sb.ll_al + sb.of_al + sb.ml_al);   // the three initial states: <= 26 bits below the end mark
+        if (p1 >= 0) {
+            const uint32_t f = field(static_cast<uint32_t>(p1));
+            sl = __builtin_amdgcn_ubfe(f, sb.of_al + sb.ml_al, sb.ll_al);
+            so = __builtin_amdgcn_ubfe(f, sb.ml_al, sb.of_al);
+            sm = __builtin_amdgcn_ubfe(f, 0, sb.ml_al);
+        }
+        pos = p1;
+    }
+#ifndef NAFGPU_EMU
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    const uint32_t *tl = s_seq + (tid < lanes ? tid : 0) * per, *tof = tl + (1u << sb.ll_al), *tm = tof + (1u << sb.of_al);
+    uint32_t i = 0;
+    bool pending = live;                                                 // a chunk is in flight for this block
+    for (;;) {
+        // ---- up to kSeqBatch sequences without a global load
+        const uint32_t stop = i + kSeqBatch;
+        for (; i < stop; i++) {
+            const bool on = live && i + 1 < n && pos >= 0;
+            if (!__any(on ? 1 : 0)) break;
+            if (!on) continue;
+            const uint32_t cl = tl[sl], co = tof[so], cm = tm[sm];
+            dst[i] = SeqRec{pos, sl | sm << 9 | so << 18};
+            const uint32_t nbl = (cl >> 16) & 0xFFu, nbm = (cm >> 16) & 0xFFu, nbo = (co >> 16) & 0xFFu;
+            const int32_t p1 = pos - static_cast<int32_t>((cl >> 24) + (co >> 24) + (cm >> 24) + nbl + nbm + nbo);
+            // (an overrun, p1 < 0, reads some dword of the ring: the states no longer matter, the block stops here and is flagged)
+            const uint32_t f = field(static_cast<uint32_t>(p1 < 0 ? 0 : p1));
+            sl = (cl & 0xFFFFu) + __builtin_amdgcn_ubfe(f, nbm + nbo, nbl);
+            sm = (cm & 0xFFFFu) + __builtin_amdgcn_ubfe(f, nbo, nbm);
+            so = (co & 0xFFFFu) + __builtin_amdgcn_ubfe(f, 0, nbo);
+            pos = p1;
+        }
+        const bool more = live && i + 1 < n && pos >= 0;
+        if (!__any(more ? 1 : 0)) break;
+        // ---- top up.  A block whose cursor has left the upper half of its ring (the five dwords that end at the cursor too)
+        // takes the chunk in flight in that half's place and sends for the next one.
+        if (tid < kSeqLdsLanes) s_cmd[tid] = 0;
+        wave_sync();
+        if (more) {
+            const uint64_t cur = sb.bits_off + (static_cast<uint32_t>(pos > 0 ? pos - 1 : 0) >> 3);   // payload offset of the byte the next bit read lies in
+            uint32_t cmd = 0;
+            if (pending && cur + 4 <= lo + kSeqRing / 2) {
+                lo -= kSeqRing / 2;
+                s_ro[tid] = static_cast<uint32_t>((lo - lo0) & (kSeqRing - 1));
+                cmd = 1;
+                pending = false;
+            }
+            if (!pending) {
+                s_at[tid] = lo - kSeqRing / 2;
+                cmd |= 2;
+                pending = true;
+            }
+            s_cmd[tid] = cmd;
+        }
+        wave_sync();
+#pragma unroll
+        for (uint32_t j = 0; j < kSeqLdsLanes; j++) {
+            const uint32_t cmd = s_cmd[j];                               // (uniform)
+            if (cmd & 1u) {
+                uint32_t *rj = s_seq + j * per + cells_cap;
+                const uint32_t ro = s_ro[j];
+                *reinterpret_cast<uint4 *>(rj + ro / 4 + 4 * tid) = fly[j];
+                if (ro == 0 && tid == 0) *reinterpret_cast<uint4 *>(rj + kSeqRing / 4) = fly[j];
+            }
+            if (cmd & 2u) fly[j] = load16(s_at[j] + 16 * tid);
+        }
+        wave_sync();
+    }
+    if (live) {
+        if (pos >= 0 && n > 0) {                                         // the last: no state update after it
+            const uint32_t cl = tl[sl], co = tof[so], cm = tm[sm];
+            dst[n - 1] = SeqRec{pos, sl | sm << 9 | so << 18};
+            pos -= static_cast<int32_t>((cl >> 24) + (co >> 24) + (cm >> 24));
+        }
+        if (pos != 0) flag_error(status, kStSeqBadEnd, sb.blk);
+    }
+}
+
 constexpr uint32_t kSeqPerLane = 4;
 
 __global__ __launch_bounds__(64) void k_seq_values(const uint8_t *__restrict__ src, const SeqBlock *__restrict__ blocks,
@@ -3050,16 +3210,41 @@ __global__ __launch_bounds__(256) void k_hash64(const uint8_t *__restrict__ p, u
 // launchers
 // ======================================================================================
 void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *blocks, uint32_t n_blocks,
-                       const SeqCell *cells, Seq *seqs, SeqMeta *meta, uint32_t *blk_size, uint32_t *rep_final, uint32_t *status) {
+                       const SeqCell *cells, Seq *seqs, SeqMeta *meta, uint32_t *blk_size, uint32_t *rep_final, uint32_t *status,
+                       uint32_t cells_cap, long long src_min) {
     if (!n_blocks) return;
-    const char *k2e = hook_env("NAFGPU_K2_LANES");        // measurements only (nafgpu_test_hooks)
-    const uint32_t forced = k2e ? static_cast<uint32_t>(std::atoi(k2e)) : 0u;
-    uint32_t lanes = forced ? forced : (n_blocks + 359u) / 360u;     // about one wave per CU ...
-    lanes = forced ? lanes : (lanes < 16 ? 16 : lanes);              // ... of at least 16 lanes (measured: see above)
-    lanes = lanes < 1 ? 1 : (lanes > 64 ? 64 : lanes);
     SeqRec *recs = reinterpret_cast<SeqRec *>(meta);      // (the SeqMeta records are written after these two kernels)
-    hipLaunchKernelGGL(k_seq_states, dim3((n_blocks + lanes - 1) / lanes), dim3(64), 0, stream, src, blocks, n_blocks, cells, recs,
-                       lanes, status);
+    // The chain out of LDS (k_seq_states_lds) when every block of the section is resident at once: tables + ring per block,
+    // 160 KiB per CU, one wave per SIMD.  NAFGPU_K2_LDS=0/1 (nafgpu_test_hooks) forces one or the other.
+    static const uint32_t n_cu = [] {
+        hipDeviceProp_t p;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        return hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? static_cast<uint32_t>(p.multiProcessorCount) : 1u;
+    }();
+    const uint32_t per_block = cells_cap * 4u + kSeqRing + 16u;
+    uint32_t per_cu = (160u * 1024u - 1024u) / per_block;             // blocks resident per CU
+    uint32_t lds_lanes = (per_cu + 3u) / 4u;                          // ... spread over four waves, at most kSeqLdsLanes each
+    if (lds_lanes > kSeqLdsLanes) lds_lanes = kSeqLdsLanes;
+    if (lds_lanes * per_block > 64u * 1024u) lds_lanes = (64u * 1024u) / per_block;
+    if (lds_lanes) per_cu = ((160u * 1024u - 1024u) / (lds_lanes * per_block + 256u)) * lds_lanes;
+    bool use_lds = cells_cap != 0 && lds_lanes != 0 && static_cast<uint64_t>(n_blocks) <= static_cast<uint64_t>(n_cu) * per_cu;
+    if (const char *e = hook_env("NAFGPU_K2_LDS")) use_lds = cells_cap != 0 && lds_lanes != 0 && e[0] == '1';
+    if (use_lds) {
+        // fewer lanes per wave than fit, when there are few blocks: every CU gets its share of the chains
+        uint32_t lanes = (n_blocks + 4u * n_cu - 1u) / (4u * n_cu);
+        lanes = lanes < 1 ? 1 : (lanes > lds_lanes ? lds_lanes : lanes);
+        hipLaunchKernelGGL(k_seq_states_lds, dim3((n_blocks + lanes - 1) / lanes), dim3(64), lanes * per_block, stream, src, blocks, n_blocks,
+                           cells, recs, lanes, cells_cap, src_min, status);
+    } else {
+        const char *k2e = hook_env("NAFGPU_K2_LANES");        // measurements only (nafgpu_test_hooks)
+        const uint32_t forced = k2e ? static_cast<uint32_t>(std::atoi(k2e)) : 0u;
+        uint32_t lanes = forced ? forced : (n_blocks + 359u) / 360u;     // about one wave per CU ...
+        lanes = forced ? lanes : (lanes < 16 ? 16 : lanes);              // ... of at least 16 lanes (measured: see above)
+        lanes = lanes < 1 ? 1 : (lanes > 64 ? 64 : lanes);
+        hipLaunchKernelGGL(k_seq_states, dim3((n_blocks + lanes - 1) / lanes), dim3(64), 0, stream, src, blocks, n_blocks, cells, recs,
+                           lanes, status);
+    }
     hipLaunchKernelGGL(k_seq_values, dim3(n_blocks), dim3(64), 0, stream, src, blocks, n_blocks, cells, recs, seqs, blk_size,
                        rep_final, status);
 }

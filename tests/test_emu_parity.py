@@ -80,6 +80,23 @@ def test_lz_stages_dense_and_sparse(emu, all_cases, monkeypatch):
                 assert emu.zstd_decompress(payload, len(data)) == data, (name, mode)
 
 
+def test_sequence_chains_out_of_lds_and_out_of_l2(emu, all_cases, monkeypatch):
+    """k_seq_states has two bodies -- tables and bitstream in LDS (sections whose blocks are all resident at once), or read
+    through L2 -- chosen by size; NAFGPU_K2_LDS forces either on the same inputs: blocks of thousands of sequences (the
+    bitstream ring is topped up many times), one-sequence blocks, RLE and predefined tables, corrupt streams."""
+    emu.c.nafgpu_test_hooks(1)
+    names = ("dna_l3_big", "text_quality", "fastq_flush_per_record", "text_repeat_offsets_l9", "dna_homopolymer", "truncated_mid",
+             "bitflip_sequence", "checksum_text_l3")
+    for force in ("1", "0"):
+        monkeypatch.setenv("NAFGPU_K2_LDS", force)
+        for name, blob, opts in all_cases:
+            if name in names:
+                assert cases.run_product(blob, opts, emu) == cases.run_oracle(blob, opts), (name, force)
+        for name, payload, data in cases.zstd_payload_cases(scale=1):
+            if name in ("multi_frame_l19_flush151", "equal_length_words_l3"):
+                assert emu.zstd_decompress(payload, len(data)) == data, (name, force)
+
+
 def test_pointer_jumping_distance_limit_falls_back_to_frame_order(emu, all_cases, monkeypatch):
     """D holds 32-bit distances: a chain longer than that cannot be jumped to its end.  With the limit lowered
     to a few elements (NAFGPU_PJ_MAX_DIST) distances stop growing while elements still point at pending ones;

@@ -222,6 +222,21 @@ def test_lz_stages_dense_and_sparse(lib, monkeypatch):
         assert cases.run_product(blob, opts) == cases.run_oracle(blob, opts), (name, "limit")
 
 
+def test_sequence_chains_out_of_lds_and_out_of_l2(lib, monkeypatch):
+    """Both bodies of k_seq_states (NAFGPU_K2_LDS forces one) on every archive case with LZ sequences and on the fuzz set."""
+    import cases
+    lib.c.nafgpu_test_hooks(1)
+    todo = [c for c in cases.build_cases(scale=4) if c[0].startswith(("dna_l", "text_", "fastq_", "dna_repeat", "dna_dense", "dna_homo", "protein",
+                                                                      "rna", "checksum", "truncated", "bitflip"))]
+    for force in ("1", "0"):
+        monkeypatch.setenv("NAFGPU_K2_LDS", force)
+        for name, blob, opts in todo:
+            assert cases.run_product(blob, opts) == cases.run_oracle(blob, opts), (name, force)
+        for name, payload, data in cases.zstd_payload_cases(scale=2):
+            assert lib.zstd_decompress(payload, len(data)) == data, (name, force)
+        assert cases.fuzz_disagreements(cases.fuzz_cases(seed=5, n=60)) == []
+
+
 def test_corrupted_archives_terminate_and_never_disagree_silently(lib):
     """The same corrupted inputs the CPU harness runs under AddressSanitizer: on the GPU they must
     come back as errors (or as the same records the oracle gives), never as a fault or a hang."""

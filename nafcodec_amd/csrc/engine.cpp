@@ -529,6 +529,11 @@ void SectionJob::fill_lz_args(LzArgs *out, uint32_t phase) {
             la.pj_list[0] = d_pj_list_[0].as<uint32_t>();
             la.pj_list[1] = d_pj_list_[1].as<uint32_t>();
         }
+        // Strip-wise sweeps where chains are shallow: text / qualities (their matches come from near by) with a tenth of the
+        // elements or more literals.  (Measured on the 10 M-read probe: level 1, 22 % literals, 44.6 -> 38.0 ms; level 3, 2 %
+        // literals -- chains forty links deep -- 90.8 -> 100 ms.)
+        la.strips = (!t_char_ && sec_known * 10 >= expect_) ? 1u : 0u;
+        if (const char *e = hook_env("NAFGPU_PJ_STRIPS")) la.strips = e[0] == '1' ? 1u : 0u;
         lz_dense_ = true;
     } else {
         // the pending lists are an accelerator: without memory for them every pass walks the blocks

@@ -11,6 +11,10 @@
 //   k_hash64           checksum used by full-size parity tests
 // Reference counterparts are cited per kernel.  Format: RFC 8878 / SURVEY.md Appendix B.
 #include <hip/hip_runtime.h>
+#ifdef NAFGPU_EMU
+#include <cstdio>
+#include <vector>
+#endif
 
 #include <cstdlib>
 #include <type_traits>
@@ -944,7 +948,7 @@ __global__ __launch_bounds__(64) void k_seq_states(const uint8_t *__restrict__ s
 // CU): beyond that the blocks would run in batches, and two batches at half the time per sequence are no faster than
 // one batch out of L2.
 constexpr uint32_t kSeqRing = 2048;          // bytes of bitstream per block in LDS (+ a 16-byte guard: a dword pair never wraps)
-constexpr uint32_t kSeqBatch = 88;           // sequences between top-ups: 88 x 89 bits + a dword pair < 1020 bytes, what a ring always holds below its cursor
+constexpr uint32_t kSeqBatch = 88;           // sequences between top-ups: 88 x 89 bits + a dword pair < 1008 bytes, what a ring always holds below its cursor
 constexpr uint32_t kSeqLdsLanes = 8;         // most blocks per wave
 
 __global__ __launch_bounds__(64) void k_seq_states_lds(const uint8_t *__restrict__ src, const SeqBlock *__restrict__ blocks,
@@ -1057,7 +1061,8 @@ __global__ __launch_bounds__(64) void k_seq_states_lds(const uint8_t *__restrict
         if (more) {
             const uint64_t cur = sb.bits_off + (static_cast<uint32_t>(pos > 0 ? pos - 1 : 0) >> 3);   // payload offset of the byte the next bit read lies in
             uint32_t cmd = 0;
-            if (pending && cur + 4 <= lo + kSeqRing / 2) {
+            // (a field's dword pair reaches up to eight bytes above the cursor's byte)
+            if (pending && static_cast<long long>(cur) + 16 <= static_cast<long long>(lo) + kSeqRing / 2) {   // (signed: lo goes below the payload's start)
                 lo -= kSeqRing / 2;
                 s_ro[tid] = static_cast<uint32_t>((lo - lo0) & (kSeqRing - 1));
                 cmd = 1;
@@ -2317,6 +2322,7 @@ constexpr uint32_t kPjWait = kPjFinal - 1u;  // an element of the window in fron
 __device__ inline bool pj_pending(uint32_t v) { return v - 1u < kPjWait - 1u; }   // 1 <= v < kPjWait: a distance
 constexpr uint32_t kPjShort = 16;            // k_pj_fill: matches up to this long are filled by the thread that looked at them
 constexpr uint32_t kPjLocal = 4;             // jumps inside the tile (LDS) before a sweep looks into memory
+constexpr uint32_t kPjWin = 3;               // tiles a strip-wise sweep keeps in LDS behind the current one (k_pj_sweep)
 constexpr uint32_t kPjFinishSweeps = 4;      // a shard's sweeps after the window in front of it has arrived
 constexpr uint32_t kPjSweeps = 24;           // a sweep at least halves every chain: 2^24 matches deep; what is left after them goes to the
                                              // frame-order walk (every launch that finds nothing left still costs its 4-5 us: 40 of them
@@ -2466,14 +2472,24 @@ __device__ inline void pj_list_flush(PjLister<N> *L, uint32_t *list_out, unsigne
     __syncthreads();
 }
 
-template <bool ASCII>
-__global__ __launch_bounds__(256, 6) void k_pj_sweep(uint32_t *D, uint8_t *out_bytes, uint32_t *tile_pending, unsigned long long *pcount,
+// WIN > 0 (text and quality sections whose chains are shallow: LzArgs.strips): the workgroup takes a STRIP of consecutive
+// tiles, front to back, and keeps the words of the last WIN tiles it swept (as it left them: final wherever they got
+// final) in LDS beside the current one; the next tile's words are on their way while this one's are worked on.  In a
+// strip everything in front of an element has been swept already -- as in a serial decoder -- so with a fifth of the
+// elements literals (level-1 quality strings: chains a few links long) nearly everything resolves in the first pass,
+// sources a few thousand elements back out of LDS, the others by the gathers below: 2 sweeps instead of 4-5.
+// Where chains are deep (level 3: 2 % literals, forty links) a pass resolves no more than one of the tile-wise sweeps
+// (WIN = 0: the tile alone, tiles dealt round robin, twice the workgroups per CU for the gathers) -- those keep them.
+template <bool ASCII, uint32_t WIN>
+__global__ __launch_bounds__(256, WIN ? 3 : 6) void k_pj_sweep(uint32_t *D, uint8_t *out_bytes, uint32_t *tile_pending, unsigned long long *pcount,
                                                   uint64_t n_elems, uint32_t sweep, uint32_t max_dist, uint32_t *list_out,
                                                   uint64_t list_cap, unsigned long long *lstate, const uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
+    constexpr uint32_t kSlots = WIN + 1;
     __shared__ uint32_t s_cnt[3];                          // pending elements of the tile, three counters in rotation
-    __shared__ uint32_t s_D[kPjTile];                      // the tile's words: the first few jumps of a sweep stay inside the tile
+    __shared__ uint32_t s_D[kSlots * kPjTile];             // the tile's words (and the WIN tiles before it): the first few jumps of a sweep stay in LDS
+    __shared__ uint64_t s_held[kSlots];                    // which tile each slot holds (~0: none)
     __shared__ PjLister<kPjBatch> s_list;                  // (a tile's survivors at most: flushed before a tile that would not fit)
     const uint32_t tid = threadIdx.x;
     // pcount[s % 3] = elements still pending after sweep s (pcount[0] != 0 before the first one)
@@ -2491,12 +2507,39 @@ __global__ __launch_bounds__(256, 6) void k_pj_sweep(uint32_t *D, uint8_t *out_b
     if (before == 0 || status[0] != 0) return;
     if (tid == 0) s_list.n = 0;
     if (tid < 3) s_cnt[tid] = 0;
+    if (tid < kSlots) s_held[tid] = ~0ull;
     __syncthreads();
     const uint64_t n_tiles = (n_elems + kPjTile - 1) / kPjTile;
+    // WIN: a strip of consecutive tiles per workgroup; else tiles dealt round robin
+    const uint64_t per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const uint64_t t_first = WIN ? blockIdx.x * per_wg : blockIdx.x;
+    const uint64_t t_last = WIN ? (t_first + per_wg < n_tiles ? t_first + per_wg : n_tiles) : n_tiles;
+    const uint64_t t_step = WIN ? 1 : gridDim.x;
     uint32_t flip = 0;
     unsigned long long wg_pending = 0;                     // (thread 0)
-    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        if (sweep > 1 && tile_pending[t] == 0) continue;    // (the same word for every thread: uniform)
+    auto load_words = [&](uint64_t at, uint32_t *x) {      // four words of D at element `at` (a multiple of four), zeros past the end
+        x[0] = x[1] = x[2] = x[3] = 0;
+        if (at >= n_elems) return;
+        if (n_elems - at >= 4) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(D + at);   // D is 16-byte aligned
+            x[0] = q.x;
+            x[1] = q.y;
+            x[2] = q.z;
+            x[3] = q.w;
+        } else {
+            for (uint32_t k = 0; k < static_cast<uint32_t>(n_elems - at); k++) x[k] = D[at + k];
+        }
+    };
+    uint32_t nxt[2][4];
+    bool have_next = false;
+    for (uint64_t t = t_first; t < t_last; t += t_step) {
+        if (sweep > 1 && tile_pending[t] == 0) {            // (the same word for every thread: uniform)
+            have_next = false;
+            continue;
+        }
+        const uint32_t slot = WIN ? static_cast<uint32_t>(t % kSlots) : 0u;
+        uint32_t *s_cur = s_D + slot * kPjTile;
+        const uint64_t tile0 = t * kPjTile;                // first element of the tile
         // Two runs of four consecutive elements per thread.  All the look-ups of a thread are issued before any of its
         // stores: a source read a moment too early is still a valid ancestor in the chain (its old distance points
         // further back), so the order inside a sweep does not matter -- but eight dependent round trips to memory do.
@@ -2505,24 +2548,26 @@ __global__ __launch_bounds__(256, 6) void k_pj_sweep(uint32_t *D, uint8_t *out_b
         Elem e[2][4];
 #pragma unroll
         for (uint32_t half = 0; half < 2; half++) {
-            p[half] = t * kPjTile + tid * 4 + half * (kPjTile / 2);
+            p[half] = tile0 + tid * 4 + half * (kPjTile / 2);
+            if (WIN && have_next) {                         // (the words loaded while the tile in front was worked on)
 #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) v[half][k] = 0;
-            if (p[half] >= n_elems) continue;
-            if (n_elems - p[half] >= 4) {
-                const uint4 x = *reinterpret_cast<const uint4 *>(D + p[half]);   // D is 16-byte aligned, p a multiple of 4
-                v[half][0] = x.x;
-                v[half][1] = x.y;
-                v[half][2] = x.z;
-                v[half][3] = x.w;
-            } else {
-                for (uint32_t k = 0; k < static_cast<uint32_t>(n_elems - p[half]); k++) v[half][k] = D[p[half] + k];
+                for (uint32_t k = 0; k < 4; k++) v[half][k] = nxt[half][k];
+                continue;
+            }
+            load_words(p[half], v[half]);
+        }
+        if (WIN) {                                         // the next tile's words set out now
+            have_next = t + 1 < t_last;
+            if (have_next) {
+                load_words(tile0 + kPjTile + tid * 4, nxt[0]);
+                load_words(tile0 + kPjTile + tid * 4 + kPjTile / 2, nxt[1]);
             }
         }
-        // Jumps whose source lies in the same tile are taken in LDS first, kPjLocal times over: quality strings and
-        // tandem repeats copy from a few hundred elements back, so a sweep advances a chain by up to 2^kPjLocal doublings for
-        // one pass over D in memory.  No barriers between the rounds: a thread writes its own eight words only, and a word
-        // read a moment early or late is a valid ancestor (or the final value) either way.
+        // Jumps whose source lies in the same tile (or, WIN, in one of the tiles of the strip still held) are taken in LDS
+        // first, kPjLocal times over: quality strings and tandem repeats copy from a few hundred elements back, so a sweep
+        // advances a chain by up to 2^kPjLocal doublings for one pass over D in memory.  No barriers between the rounds: a
+        // thread writes its own eight words only, and a word read a moment early or late is a valid ancestor (or the final
+        // value) either way.
         uint32_t v0[2][4];                                 // as loaded: what differs at the end is stored
 #pragma unroll
         for (uint32_t half = 0; half < 2; half++) {
@@ -2540,9 +2585,18 @@ __global__ __launch_bounds__(256, 6) void k_pj_sweep(uint32_t *D, uint8_t *out_b
                 for (uint32_t k = 0; k < 4; k++)
                     if (v[half][k] == 0 && p[half] + k < n_elems) v[half][k] = kPjFinal | el[k];
             }
-            *reinterpret_cast<uint4 *>(&s_D[tid * 4 + half * (kPjTile / 2)]) = make_uint4(v[half][0], v[half][1], v[half][2], v[half][3]);
+            *reinterpret_cast<uint4 *>(&s_cur[tid * 4 + half * (kPjTile / 2)]) = make_uint4(v[half][0], v[half][1], v[half][2], v[half][3]);
         }
+        if (WIN && tid == 0) s_held[slot] = t;
         __syncthreads();
+        // how far back LDS reaches: the held tiles directly in front of this one
+        uint32_t reach = 0;                                // elements in front of the tile that are in LDS
+        if (WIN) {
+            for (uint32_t k = 1; k <= WIN; k++) {
+                if (t < k || s_held[(t - k) % kSlots] != t - k) break;
+                reach = k * kPjTile;
+            }
+        }
 #pragma unroll 1
         for (uint32_t it = 0; it < kPjLocal; it++) {
 #pragma unroll
@@ -2550,14 +2604,15 @@ __global__ __launch_bounds__(256, 6) void k_pj_sweep(uint32_t *D, uint8_t *out_b
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) {
                     const uint32_t li = tid * 4 + half * (kPjTile / 2) + k, d = v[half][k];
-                    if (!pj_pending(d) || d > li) continue;                     // literal / final / source outside the tile
-                    const uint32_t ws = s_D[li - d];
+                    if (!pj_pending(d) || d > li + reach) continue;             // literal / final / source not in LDS
+                    // (element index of the source modulo what the slots hold: consecutive tiles sit in consecutive slots, cyclically)
+                    const uint32_t ws = WIN ? s_D[static_cast<uint32_t>((tile0 + li - d) % (kSlots * kPjTile))] : s_cur[li - d];
                     if (ws >= kPjFinal) {
                         v[half][k] = ws;                                        // (mark and element of the source: ours too)
-                        s_D[li] = ws;
+                        s_cur[li] = ws;
                     } else if (ws != 0 && static_cast<uint64_t>(d) + ws < max_dist) {
                         v[half][k] = d + ws;
-                        s_D[li] = d + ws;
+                        s_cur[li] = d + ws;
                     }                                                           // (a literal in the tile: its element is in the output -- below)
                 }
         }
@@ -2607,6 +2662,8 @@ __global__ __launch_bounds__(256, 6) void k_pj_sweep(uint32_t *D, uint8_t *out_b
                     for (uint32_t k = 0; k < static_cast<uint32_t>(n_elems - p[half]); k++) D[p[half] + k] = v[half][k];
                 }
             }
+            // (WIN) ... and into the slot, as the tiles behind this one will find them
+            if (WIN) *reinterpret_cast<uint4 *>(&s_cur[tid * 4 + half * (kPjTile / 2)]) = make_uint4(v[half][0], v[half][1], v[half][2], v[half][3]);
         }
         if (remaining) atomicAdd(&s_cnt[flip], remaining);
         __syncthreads();
@@ -2620,10 +2677,10 @@ __global__ __launch_bounds__(256, 6) void k_pj_sweep(uint32_t *D, uint8_t *out_b
             const uint32_t c = s_cnt[flip];                // (stable: thread 0 reset the OTHER counters only)
             pj_list_flush(&s_list, list_out, &lstate[sweep % 3u], list_cap, s_list.n + c > kPjBatch ? 1u : kPjBatch);
             if (remaining) {
-                uint32_t slot = atomicAdd(&s_list.n, remaining);
+                uint32_t slot_l = atomicAdd(&s_list.n, remaining);
 #pragma unroll
                 for (uint32_t j = 0; j < 8; j++)
-                    if (survivors & (1u << j)) s_list.buf[slot++] = static_cast<uint32_t>(p[j >> 2] + (j & 3u));
+                    if (survivors & (1u << j)) s_list.buf[slot_l++] = static_cast<uint32_t>(p[j >> 2] + (j & 3u));
             }
         }
         flip = (flip + 1u) % 3u;
@@ -3042,6 +3099,7 @@ __global__ __launch_bounds__(64) void k_xxh64_frames(const XxhSeg *__restrict__ 
     __shared__ XxhCarry s_c;
     __shared__ uint8_t s_inv[256];               // character -> 4-bit code
     const uint32_t lane = threadIdx.x;
+    if (status[0] != 0) return;                  // (a stage in front failed: block bases and output are not to be trusted)
     const XxhSeg seg = segs[blockIdx.x];
     uint64_t a = blk_base[seg.blk0];
     const uint64_t b = blk_base[seg.blk1];
@@ -3236,6 +3294,25 @@ void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *b
         lanes = lanes < 1 ? 1 : (lanes > lds_lanes ? lds_lanes : lanes);
         hipLaunchKernelGGL(k_seq_states_lds, dim3((n_blocks + lanes - 1) / lanes), dim3(64), lanes * per_block, stream, src, blocks, n_blocks,
                            cells, recs, lanes, cells_cap, src_min, status);
+#ifdef NAFGPU_EMU
+        if (std::getenv("NAFGPU_K2_CHECK")) {
+            uint64_t total = 0;
+            for (uint32_t b = 0; b < n_blocks; b++) total = std::max<uint64_t>(total, blocks[b].seq_first + blocks[b].n_seq);
+            std::vector<SeqRec> ref(total);
+            uint32_t st2[16] = {0};
+            hipLaunchKernelGGL(k_seq_states, dim3((n_blocks + 15) / 16), dim3(64), 0, stream, src, blocks, n_blocks, cells, ref.data(), 16u, st2);
+            std::fprintf(stderr, "K2 check: status lds %u ref %u\n", status[0], st2[0]);
+            for (uint32_t b = 0; b < n_blocks; b++)
+                for (uint32_t i = 0; i < blocks[b].n_seq; i++) {
+                    const SeqRec &x = recs[blocks[b].seq_first + i], &y = ref[blocks[b].seq_first + i];
+                    if (x.pos != y.pos || x.states != y.states) {
+                        std::fprintf(stderr, "K2 check: block %u (bits_off %llu len %u n_seq %u al %u %u %u) seq %u: lds pos %d states %x, ref pos %d states %x\n", b,
+                                     (unsigned long long)blocks[b].bits_off, blocks[b].bits_len, blocks[b].n_seq, blocks[b].ll_al, blocks[b].of_al, blocks[b].ml_al, i, x.pos, x.states, y.pos, y.states);
+                        break;
+                    }
+                }
+        }
+#endif
     } else {
         const char *k2e = hook_env("NAFGPU_K2_LANES");        // measurements only (nafgpu_test_hooks)
         const uint32_t forced = k2e ? static_cast<uint32_t>(std::atoi(k2e)) : 0u;
@@ -3397,6 +3474,9 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
         // is swept (see k_pj_sweep)
         const uint32_t max_dist = pj_max_dist();
         uint64_t tiles = (a.n_elems + kPjTile - 1) / kPjTile;
+        // strips: at least 32 tiles each where there are that many; three workgroups per CU, four rounds of them at most
+        uint64_t strips = tiles / 32 ? tiles / 32 : 1;
+        if (strips > 256u * 12u) strips = 256u * 12u;
         if (tiles > 256u * 16u) tiles = 256u * 16u;
         unsigned long long *pcount = a.counters + 4;       // [4..6]: pending elements, rotating (k_pj_sweep)
         unsigned long long *lstate = a.counters + 10;      // [10..12]: lengths of the pending lists, rotating; [13]: listing since sweep ...
@@ -3426,9 +3506,15 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
             sweep1 = kPjSweeps + kPjFinishSweeps;
         }
         for (uint32_t sweep = sweep0; sweep <= sweep1; sweep++) {
-            hipLaunchKernelGGL(k_pj_sweep<ASCII>, dim3(static_cast<uint32_t>(tiles)), dim3(256), 0, stream, a.pj_dist, a.out,
-                               a.pj_tiles, pcount, a.n_elems, sweep, max_dist, can_list ? lists[sweep & 1u] : nullptr, a.pj_list_cap,
-                               lstate, a.status);
+            // (shallow chains: strip-wise, see k_pj_sweep)
+            if (a.strips)
+                hipLaunchKernelGGL((k_pj_sweep<ASCII, kPjWin>), dim3(static_cast<uint32_t>(strips)), dim3(256), 0, stream, a.pj_dist, a.out,
+                                   a.pj_tiles, pcount, a.n_elems, sweep, max_dist, can_list ? lists[sweep & 1u] : nullptr, a.pj_list_cap, lstate,
+                                   a.status);
+            else
+                hipLaunchKernelGGL((k_pj_sweep<ASCII, 0u>), dim3(static_cast<uint32_t>(tiles)), dim3(256), 0, stream, a.pj_dist, a.out,
+                                   a.pj_tiles, pcount, a.n_elems, sweep, max_dist, can_list ? lists[sweep & 1u] : nullptr, a.pj_list_cap,
+                                   lstate, a.status);
             if (can_list && sweep >= 2)
                 hipLaunchKernelGGL(k_pj_list<ASCII>, dim3(list_grid), dim3(256), 0, stream, a.pj_dist, a.out, pcount,
                                    lists[(sweep & 1u) ^ 1u], lists[sweep & 1u], a.pj_list_cap, lstate, sweep, max_dist, finish ? 1u : 0u, a.status);

@@ -78,6 +78,13 @@ def test_lz_stages_dense_and_sparse(emu, all_cases, monkeypatch):
         for name, payload, data in cases.zstd_payload_cases(scale=1):
             if name in ("multi_frame_l3_flush97", "equal_length_words_l1"):    # (all of them, larger, in the GPU test of the same name)
                 assert emu.zstd_decompress(payload, len(data)) == data, (name, mode)
+    # the sweeps of dense sections tile-wise and strip-wise (NAFGPU_PJ_STRIPS forces either; the library picks by the share of literals)
+    monkeypatch.setenv("NAFGPU_LZ_MODE", "dense")
+    for strips in ("1", "0"):
+        monkeypatch.setenv("NAFGPU_PJ_STRIPS", strips)
+        for name, blob, opts in all_cases:
+            if name in ("text_dense_chains", "checksum_text_l3", "text_quality", "text_repeat_offsets_l1", "dna_l3_big"):
+                assert cases.run_product(blob, opts, emu) == cases.run_oracle(blob, opts), (name, "strips", strips)
 
 
 def test_sequence_chains_out_of_lds_and_out_of_l2(emu, all_cases, monkeypatch):

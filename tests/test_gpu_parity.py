@@ -217,6 +217,13 @@ def test_lz_stages_dense_and_sparse(lib, monkeypatch):
         for name, payload, data in cases.zstd_payload_cases(scale=2):
             assert lib.zstd_decompress(payload, len(data)) == data, (name, mode)
     monkeypatch.setenv("NAFGPU_LZ_MODE", "dense")
+    for strips in ("1", "0"):                               # the sweeps strip-wise and tile-wise (the library picks by the share of literals)
+        monkeypatch.setenv("NAFGPU_PJ_STRIPS", strips)
+        for name, blob, opts in todo:
+            assert cases.run_product(blob, opts) == cases.run_oracle(blob, opts), (name, "strips", strips)
+        for name, payload, data in cases.zstd_payload_cases(scale=2):
+            assert lib.zstd_decompress(payload, len(data)) == data, (name, "strips", strips)
+    monkeypatch.delenv("NAFGPU_PJ_STRIPS")
     monkeypatch.setenv("NAFGPU_PJ_MAX_DIST", "16")          # distances cannot grow: the frame-order walk finishes
     for name, blob, opts in todo[:3]:
         assert cases.run_product(blob, opts) == cases.run_oracle(blob, opts), (name, "limit")

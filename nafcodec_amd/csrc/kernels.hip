@@ -2322,7 +2322,8 @@ constexpr uint32_t kPjWait = kPjFinal - 1u;  // an element of the window in fron
 __device__ inline bool pj_pending(uint32_t v) { return v - 1u < kPjWait - 1u; }   // 1 <= v < kPjWait: a distance
 constexpr uint32_t kPjShort = 16;            // k_pj_fill: matches up to this long are filled by the thread that looked at them
 constexpr uint32_t kPjLocal = 4;             // jumps inside the tile (LDS) before a sweep looks into memory
-constexpr uint32_t kPjWin = 3;               // tiles a strip-wise sweep keeps in LDS behind the current one (k_pj_sweep)
+constexpr uint32_t kPjStripSweeps = 1;       // ... for the first this-many sweeps; what they leave is scattered: tile-wise from there
+constexpr uint32_t kPjWin = 1;               // tiles a strip-wise sweep keeps in LDS behind the current one (k_pj_sweep)
 constexpr uint32_t kPjFinishSweeps = 4;      // a shard's sweeps after the window in front of it has arrived
 constexpr uint32_t kPjSweeps = 24;           // a sweep at least halves every chain: 2^24 matches deep; what is left after them goes to the
                                              // frame-order walk (every launch that finds nothing left still costs its 4-5 us: 40 of them
@@ -2481,7 +2482,7 @@ __device__ inline void pj_list_flush(PjLister<N> *L, uint32_t *list_out, unsigne
 // Where chains are deep (level 3: 2 % literals, forty links) a pass resolves no more than one of the tile-wise sweeps
 // (WIN = 0: the tile alone, tiles dealt round robin, twice the workgroups per CU for the gathers) -- those keep them.
 template <bool ASCII, uint32_t WIN>
-__global__ __launch_bounds__(256, WIN ? 3 : 6) void k_pj_sweep(uint32_t *D, uint8_t *out_bytes, uint32_t *tile_pending, unsigned long long *pcount,
+__global__ __launch_bounds__(256, WIN ? 5 : 6) void k_pj_sweep(uint32_t *D, uint8_t *out_bytes, uint32_t *tile_pending, unsigned long long *pcount,
                                                   uint64_t n_elems, uint32_t sweep, uint32_t max_dist, uint32_t *list_out,
                                                   uint64_t list_cap, unsigned long long *lstate, const uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
@@ -3280,6 +3281,7 @@ void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *b
         (void)hipGetDevice(&dev);
         return hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? static_cast<uint32_t>(p.multiProcessorCount) : 1u;
     }();
+    cells_cap = (cells_cap + 3u) & ~3u;                               // (the ring behind the cells takes 16-byte stores)
     const uint32_t per_block = cells_cap * 4u + kSeqRing + 16u;
     uint32_t per_cu = (160u * 1024u - 1024u) / per_block;             // blocks resident per CU
     uint32_t lds_lanes = (per_cu + 3u) / 4u;                          // ... spread over four waves, at most kSeqLdsLanes each
@@ -3476,7 +3478,7 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
         uint64_t tiles = (a.n_elems + kPjTile - 1) / kPjTile;
         // strips: at least 32 tiles each where there are that many; three workgroups per CU, four rounds of them at most
         uint64_t strips = tiles / 32 ? tiles / 32 : 1;
-        if (strips > 256u * 12u) strips = 256u * 12u;
+        if (strips > 256u * 20u) strips = 256u * 20u;
         if (tiles > 256u * 16u) tiles = 256u * 16u;
         unsigned long long *pcount = a.counters + 4;       // [4..6]: pending elements, rotating (k_pj_sweep)
         unsigned long long *lstate = a.counters + 10;      // [10..12]: lengths of the pending lists, rotating; [13]: listing since sweep ...
@@ -3507,7 +3509,7 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
         }
         for (uint32_t sweep = sweep0; sweep <= sweep1; sweep++) {
             // (shallow chains: strip-wise, see k_pj_sweep)
-            if (a.strips)
+            if (a.strips && sweep <= kPjStripSweeps)
                 hipLaunchKernelGGL((k_pj_sweep<ASCII, kPjWin>), dim3(static_cast<uint32_t>(strips)), dim3(256), 0, stream, a.pj_dist, a.out,
                                    a.pj_tiles, pcount, a.n_elems, sweep, max_dist, can_list ? lists[sweep & 1u] : nullptr, a.pj_list_cap, lstate,
                                    a.status);

@@ -45,6 +45,11 @@ def parse_args():
     ap.add_argument("--real-copies", type=int, default=3000,
                     help="N=1 only: also time an archive shaped like a real genome (the reference's NZ_AAEN01000029 fixture tiled "
                          "this many times, libzstd level 1) and report it as path.real_genome; 0 skips it")
+    ap.add_argument("--small-real-copies", type=int, default=565,
+                    help="N=1 only: the same at the size of a human genome (x 565 = 3.1 Gbases), reported as path.real_genome_3g; 0 skips it")
+    ap.add_argument("--fastq-reads", type=float, default=10e6,
+                    help="N=1 only: a FASTQ-shaped archive of this many 151-base reads (bulk decode + the record iterator), path.fastq_like; 0 skips it")
+    ap.add_argument("--no-iterator", action="store_true", help="skip path.iterator (the headline archive through nafgpu_next)")
     ap.add_argument("--real-copies-per-gpu", type=int, default=1000,
                     help="N>1: the real-genome archive (WITH LZ sequences) holds this many tiles per GPU, ONE archive decoded through the "
                          "shard protocol and reported as path.real_genome; 0 skips it")
@@ -81,12 +86,12 @@ def cpu_baseline(lib, n_bases_target, mask, device):
     t0 = time.perf_counter()
     n = drain(blob, False).n_bases
     rate = n / (time.perf_counter() - t0)
-    sample = int(n_bases_target) if n_bases_target else int(min(max(rate * 8.0, probe_bases), 4e9))
+    sample = int(n_bases_target) if n_bases_target else int(min(max(rate * 4.0, probe_bases), 4e9))
     arc = lib.synth(sample, seed=0x4E4146, with_mask=mask)
     try:
         blob = ctypes.string_at(arc.bytes, arc.n)
         best = None
-        for _ in range(2):
+        for _ in range(5):
             t0 = time.perf_counter()
             r = drain(blob, False)
             dt = time.perf_counter() - t0
@@ -124,7 +129,7 @@ def cpu_baseline(lib, n_bases_target, mask, device):
     finally:
         lib.c.nafgpu_synth_free(ctypes.byref(arc))
     out = {"value": round(n / best / 1e9, 4), "unit": "Gbases/s", "cores": 1, "kind": "port",
-           "sample": "%d bases (%.1f MB archive) of the same synthetic workload; %s; best of 2; host has %d cores"
+           "sample": "%d bases (%.1f MB archive) of the same synthetic workload; %s; best of 5; host has %d cores"
                      % (n, len(blob) / 1e6,
                         "reference pipeline shape: streaming libzstd with 4 KiB buffers + per-nibble push + per-record strings (oracle/ref_shape.c)"
                         if shaped else "CPU oracle (oracle/*.c: scalar zstd + reader.rs restatement); libzstd.so.1 not loadable here",
@@ -235,6 +240,104 @@ def real_genome_leg(lib, device, copies):
                              "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": int(alg)}}
     finally:
         lib.c.nafgpu_close(h)
+
+
+def iterator_leg(path, device):
+    """The drop-in API itself (Decoder::from_path + Iterator::next, mod.rs:304-306, 356-399): nafcodec_amd/iter_bench -- plain C++
+    on the C-ABI, what a Rust / C++ shim does -- opens the archive at `path` and calls nafgpu_next until the end; every record's
+    sequence / quality comes to the host through the decoder's pinned window.  Seconds from open to the last record."""
+    import subprocess
+    tool = os.path.join(ROOT, "nafcodec_amd", "iter_bench")
+    if not os.path.exists(tool):
+        return None
+    p = subprocess.run([tool, path, str(device)], capture_output=True, text=True, timeout=900)
+    if p.returncode != 0:
+        raise RuntimeError("iter_bench failed: %s" % p.stderr[-500:])
+    j = json.loads(p.stdout.strip().splitlines()[-1])
+    it = max(j["iterate_s"], 1e-9)
+    return {"records": j["records"], "bases": j["bases"], "open_s": round(j["open_s"], 4), "first_next_s": round(j["first_next_s"], 4),
+            "iterate_s": round(j["iterate_s"], 4), "records_per_s": round(j["records"] / it), "Gbases_per_s": round(j["bases"] / it / 1e9, 3),
+            "end_to_end_Gbases_s": round(j["bases"] / max(j["total_s"], 1e-9) / 1e9, 3),
+            "note": "first next() to last through nafgpu_next (the first one decodes every section on the GPU); end_to_end from nafgpu_open_path: "
+                    "host walk + H2D + decode + every record's bytes D2H through the 64 MiB pinned window"}
+
+
+def fastq_like_leg(lib, device, n_reads, level=1):
+    """Third workload, FASTQ-shaped (configs[2] scaled up as SURVEY 8d allows): n_reads x 151 bases, iid ACGT + iid quality
+    strings from a skewed 32-entry alphabet, Length + Sequence + Quality sections written by the system libzstd at `level` --
+    every section holds LZ sequences (dense routes).  Bulk decode timed on the device, then the same archive through the
+    iterator.  Checked: quality and sequence checksums against what was written."""
+    import numpy as np
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import zstd_ref
+    if not zstd_ref.available():
+        return None
+    rng = np.random.default_rng(2)
+    L = 151
+    n_bases = n_reads * L
+    codes = np.array([1, 2, 4, 8], dtype=np.uint8)
+    nib = codes[rng.integers(0, 4, n_bases + (n_bases & 1))]
+    packed = (nib[0::2] | (nib[1::2] << 4)).astype(np.uint8)
+    qalpha = np.frombuffer(b"#8CGGGGGGGGGG<AFFFJJJJJJJJJJJJJJ", dtype=np.uint8)
+    qual = qalpha[rng.integers(0, len(qalpha), n_bases)].tobytes()
+    lens = np.full(n_reads, L, dtype="<u4").tobytes()
+
+    def varint(v):
+        out = [v & 0x7F]
+        v >>= 7
+        while v:
+            out.append(0x80 | (v & 0x7F))
+            v >>= 7
+        return bytes(reversed(out))
+
+    blob = bytearray([1, 0xF9, 0xEC, 1, 0x0B, 0x20]) + varint(L) + varint(n_reads)
+    comp = 0
+    for orig, data in ((len(lens), lens), (n_bases, packed.tobytes()), (len(qual), qual)):
+        payload = zstd_ref.compress_magicless(data, level, True)
+        comp += len(payload)
+        blob += varint(orig) + varint(len(payload)) + payload
+    lut = np.frombuffer(b"-TGKCYSBAWRDMHVN", dtype=np.uint8)
+    want = np.empty(2 * len(packed), dtype=np.uint8)
+    want[0::2] = lut[packed & 15]
+    want[1::2] = lut[packed >> 4]
+    want_seq = lib.c.nafgpu_hash64_host(want.tobytes()[:n_bases], n_bases)
+    want_qual = lib.c.nafgpu_hash64_host(qual, len(qual))
+    del want, nib, packed
+    blob = bytes(blob)
+    h, res = _decode_bulk(lib, device, blob)
+    try:
+        best = None
+        for _ in range(3):
+            if lib.c.nafgpu_decode_all_device(h, ctypes.byref(res)) != 0:
+                raise RuntimeError("decode failed")
+            if best is None or res.ms_total < best[0]:
+                best = (res.ms_total, res.ms_huf, res.ms_seq_lz, res.ms_other)
+        hs, hq = ctypes.c_uint64(), ctypes.c_uint64()
+        lib.c.nafgpu_hash64_device(h, res.d_sequence, res.n_bases, ctypes.byref(hs))
+        lib.c.nafgpu_hash64_device(h, res.d_quality, res.n_quality, ctypes.byref(hq))
+        if (int(res.n_bases), int(res.n_quality), hs.value, hq.value) != (n_bases, len(qual), want_seq, want_qual):
+            raise RuntimeError("FASTQ-like leg: GPU output differs from what was written")
+    finally:
+        lib.c.nafgpu_close(h)
+    alg = comp + n_bases + len(qual) + 4 * n_reads                     # compressed in, bases + qualities + record table out
+    out = {"workload": "%d reads x %d: iid ACGT + iid qualities (32-entry skewed alphabet), libzstd level %d, Length + Sequence + Quality "
+                       "sections all with LZ sequences; output checksums equal what was written" % (n_reads, L, level),
+           "bases": n_bases, "archive_bytes": len(blob), "ms_per_step": round(best[0], 3), "value": round(n_bases / best[0] / 1e6, 1), "unit": "Gbases/s",
+           "ms_huf": round(best[1], 3), "ms_seq_lz": round(best[2], 3),
+           "roofline": {"bound": "hbm", "achieved": round(alg / (best[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / (best[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": int(alg)}}
+    path = os.path.join("/dev/shm" if shutil.disk_usage("/dev/shm").free > 2 * len(blob) else tempfile.gettempdir(), "nafgpu_bench_fq_%d.naf" % os.getpid())
+    try:
+        with open(path, "wb") as f:
+            f.write(blob)
+        del blob
+        out["iterator"] = iterator_leg(path, device)
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+    return out
 
 
 def real_genome_sharded_leg(lib, dist, torch, tdev, device, rank, world, copies_per_gpu, steps=3, warmup=1):
@@ -525,7 +628,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "synthetic %.1f GB DNA-only .naf (seq+len%s%s), %d bases, %d records, "
-                                   "%d zstd blocks / %d Huffman streams in all, zstd-level-1 shape (L1), bit-exact check %s"
+                                   "%d zstd blocks / %d Huffman streams in all, zstd-level-1 shape (L1), full-size check against the WRITER's checksums of bases and record table %s"
                                    % (archive_bytes / 1e9, "+mask" if args.mask else "", ", %d permille IUPAC" % args.iupac if args.iupac else "",
                                       total_bases, res.n_records,
                                       res.n_zstd_blocks, res.n_huf_streams,
@@ -545,8 +648,27 @@ def main():
                      "host_plan_ms": round(res.ms_host_plan, 1), "h2d_ms": round(res.ms_h2d, 1),
                      "synth_s": round(t_gen, 1), "upload_s": round(t_upload, 2)},
         }
+        # first decode of a fresh archive, everything included: host walk + H2D (PCIe) + the device decode
+        e2e_s = (res.ms_host_plan + res.ms_h2d + dev_ms) * 1e-3
+        line["path"]["end_to_end_Gbases_s"] = round(total_bases / world / e2e_s / 1e9, 1) if e2e_s > 0 else None
         if args.real_copies and world == 1 and not args.rehearsal_lib:
             line["path"]["real_genome"] = real_genome_leg(lib, device, args.real_copies)
+        if args.small_real_copies and world == 1 and not args.rehearsal_lib:
+            line["path"]["real_genome_3g"] = real_genome_leg(lib, device, args.small_real_copies)
+        if args.fastq_reads and world == 1 and not args.rehearsal_lib:
+            line["path"]["fastq_like"] = fastq_like_leg(lib, device, int(args.fastq_reads))
+        if not args.no_iterator and world == 1 and not args.rehearsal_lib:
+            # the headline archive through the drop-in API: Decoder::from_path + Iterator::next (a file, as the reference reads one)
+            import shutil
+            import tempfile
+            ipath = os.path.join("/dev/shm" if shutil.disk_usage("/dev/shm").free > 2 * arc.n else tempfile.gettempdir(), "nafgpu_bench_%d.naf" % os.getpid())
+            try:
+                with open(ipath, "wb") as f:
+                    f.write((ctypes.c_char * arc.n).from_address(arc.bytes))
+                line["path"]["iterator"] = iterator_leg(ipath, device)
+            finally:
+                if os.path.exists(ipath):
+                    os.unlink(ipath)
         if real_sharded is not None:
             line["path"]["real_genome"] = real_sharded
         if not args.no_cpu and world == 1:       # reported baseline, rank 0 at N=1 only

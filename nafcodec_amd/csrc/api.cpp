@@ -44,6 +44,8 @@ public:
         window_ = window;
         lo_ = hi_ = 0;
     }
+    // bytes [start, start+len) are on the host already (a record in front of a tile that failed is still handed out)
+    bool holds(uint64_t start, uint64_t len) const { return start >= lo_ && start + len <= hi_ && hi_ > lo_; }
     // pointer to bytes [start, start+len) on the host; nullptr on failure
     const uint8_t *get(uint64_t start, uint64_t len, Failure *f) {
         if (len == 0) return reinterpret_cast<const uint8_t *>("");
@@ -76,7 +78,16 @@ public:
                 if (pos >= held1) {                        // off the end of the tile: the next one takes its place
                     if (sj.tiles_done() >= sj.n_tiles()) break;
                     *f = job_->advance_tile(section_);
-                    if (!f->ok()) return nullptr;
+                    if (!f->ok()) {
+                        // a tile BEHIND the record asked for failed while the window was being filled ahead: the record itself is
+                        // whole -- it is handed out, and the error comes with the first record that needs the bad tile (the
+                        // reference meets a corrupt block when its stream gets there, mod.rs:356-399)
+                        if (pos >= start + len && f->status != NAFGPU_E_DEVICE) {
+                            *f = Failure();
+                            break;
+                        }
+                        return nullptr;
+                    }
                     continue;
                 }
                 if (pos < held0) {
@@ -585,7 +596,8 @@ int nafgpu_next(nafgpu_decoder *d, nafgpu_record *rec) {
     if (rec->has_length) {                                                 // mod.rs:373
         const uint64_t l = rec->length;
         if (d->use[kSequence]) {
-            if (!d->job.section_failure(kSequence).ok()) return fail(d, d->job.section_failure(kSequence));
+            if (!d->job.section_failure(kSequence).ok() && !(d->tiled_output && d->seq_win.holds(start, l)))
+                return fail(d, d->job.section_failure(kSequence));
             if (end > d->job.n_sequence_bytes())
                 return fail(d, Failure::io(NAFGPU_IO_UNEXPECTED_EOF, "sequence section ends before the record does"));
             const uint8_t *p = d->seq_win.get(start, l, &f);
@@ -597,7 +609,8 @@ int nafgpu_next(nafgpu_decoder *d, nafgpu_record *rec) {
             rec->sequence.present = 1;
         }
         if (d->use[kQuality]) {
-            if (!d->job.section_failure(kQuality).ok()) return fail(d, d->job.section_failure(kQuality));
+            if (!d->job.section_failure(kQuality).ok() && !(d->tiled_output && d->qual_win.holds(start, l)))
+                return fail(d, d->job.section_failure(kQuality));
             if (end > d->job.section_size(kQuality))
                 return fail(d, Failure::io(NAFGPU_IO_UNEXPECTED_EOF, "quality section ends before the record does"));
             const uint8_t *p = d->qual_win.get(start, l, &f);

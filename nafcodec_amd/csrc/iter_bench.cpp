@@ -1,0 +1,59 @@
+// iter_bench.cpp -- times the API the reference exposes: Decoder::from_path + Iterator::next
+// (nafcodec/src/decoder/mod.rs:304-306, 356-399, 444-451) through the C-ABI, the way a Rust / C++ / Python shim drives
+// it: open by path, then nafgpu_next until NAFGPU_END, touching every field it is handed (length sums), first next() to
+// last.  Prints one JSON object.  Built by `make tools` into nafcodec_amd/iter_bench; bench.py runs it (path.iterator).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/nafgpu.h"
+
+static double now_s() {
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) {
+        std::fprintf(stderr, "usage: iter_bench ARCHIVE.naf [device]\n");
+        return 2;
+    }
+    nafgpu_opts opts;
+    nafgpu_opts_default(&opts);
+    opts.device = argc > 2 ? std::atoi(argv[2]) : 0;
+    nafgpu_decoder *dec = nullptr;
+    nafgpu_error err;
+    const double t_open = now_s();
+    if (nafgpu_open_path(argv[1], &opts, &dec, &err) != NAFGPU_OK) {
+        std::fprintf(stderr, "open failed: %s\n", err.message);
+        return 1;
+    }
+    nafgpu_record rec;
+    unsigned long long n = 0, bases = 0, qual = 0, names = 0, xsum = 0;
+    const double t0 = now_s();
+    double t_first = 0;
+    for (;;) {
+        const int rc = nafgpu_next(dec, &rec);
+        if (n == 0) t_first = now_s();
+        if (rc == NAFGPU_END) break;
+        if (rc != NAFGPU_OK) {
+            nafgpu_last_error(dec, &err);
+            std::fprintf(stderr, "next failed at record %llu: %s\n", n, err.message);
+            return 1;
+        }
+        n++;
+        bases += rec.sequence.len;
+        qual += rec.quality.len;
+        names += rec.id.len + rec.comment.len;
+        // (one byte of every field is read: the views must be on the host)
+        if (rec.sequence.len) xsum += rec.sequence.ptr[0] + rec.sequence.ptr[rec.sequence.len - 1];
+        if (rec.quality.len) xsum += rec.quality.ptr[rec.quality.len - 1];
+    }
+    const double t1 = now_s();
+    nafgpu_close(dec);
+    std::printf("{\"records\": %llu, \"bases\": %llu, \"quality_bytes\": %llu, \"name_bytes\": %llu, \"open_s\": %.6f, "
+                "\"first_next_s\": %.6f, \"iterate_s\": %.6f, \"total_s\": %.6f, \"xsum\": %llu}\n",
+                n, bases, qual, names, t0 - t_open, t_first - t0, t1 - t0, t1 - t_open, xsum);
+    return 0;
+}

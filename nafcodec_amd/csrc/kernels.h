@@ -135,10 +135,6 @@ void launch_rep_map(hipStream_t stream, const SeqBlock *blocks, uint32_t n_block
                     uint32_t continues, uint32_t *map_out, uint32_t *status);
 void launch_lz_execute(hipStream_t stream, const LzArgs &args, bool ascii);
 
-// K5: 4-bit -> IUPAC ASCII; t_char = 'T' (DNA) or 'U' (RNA)
-void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed, uint8_t *ascii, uint64_t n_bases,
-                    uint32_t t_char, uint32_t *status);
-
 // soft-mask: lower-case the masked runs (odd-numbered runs of mask_ends) honouring record ends.
 // `ascii` is addressed by global base index; only bases [lo_clamp, hi_clamp) are touched (a shard).
 void launch_mask_apply(hipStream_t stream, uint8_t *ascii, uint64_t n_bases, uint64_t lo_clamp, uint64_t hi_clamp,

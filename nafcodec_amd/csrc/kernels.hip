@@ -6,7 +6,6 @@
 //   k_scan_*       K3/K6  tile scans: block bases, record ends, mask run ends
 //   k_copy_fill        Raw / RLE blocks and literal sections
 //   k_rep_partial/scan/apply, k_lz_literals, k_lz_index, k_lz_match_pass, k_lz_matches_ordered   K4
-//   k_unpack4      K5  4-bit -> IUPAC ASCII (reader.rs:121-172)
 //   k_mask_apply       soft-mask lower-casing incl. the record-end rule (mod.rs:402-441)
 //   k_hash64           checksum used by full-size parity tests
 // Reference counterparts are cited per kernel.  Format: RFC 8878 / SURVEY.md Appendix B.
@@ -2894,46 +2893,6 @@ __global__ __launch_bounds__(256) void k_lz_matches_ordered(const SeqBlock *__re
 }
 
 // ======================================================================================
-// K5  4-bit -> IUPAC ASCII (SequenceReader::read_nucleotide / decode, reader.rs:121-172)
-// ======================================================================================
-// Byte b of the packed stream yields LUT[b & 15] then LUT[b >> 4]; records are contiguous in
-// nibble space, so record k is bases [end[k-1], end[k]) of this one flat array -- the odd-nibble
-// `cache` of reader.rs:92-94,138-143 is just an odd offset here.
-__global__ __launch_bounds__(256) void k_unpack4(const uint8_t *__restrict__ packed, uint64_t n_packed,
-                                                 uint8_t *__restrict__ ascii, uint64_t n_bases, uint32_t t_char,
-                                                 const uint32_t *status) {
-    if (status[0] != 0) return;
-    // "-TGKCYSBAWRDMHVN" with index 1 = 'T' (DNA) or 'U' (RNA)
-    const uint32_t t0 = 0x4B47002Du | (t_char << 8);  // '-' T 'G' 'K'
-    const uint32_t t1 = 0x42535943u;                  // 'C' 'Y' 'S' 'B'
-    const uint32_t t2 = 0x44525741u;                  // 'A' 'W' 'R' 'D'
-    const uint32_t t3 = 0x4E56484Du;                  // 'M' 'H' 'V' 'N'
-    const uint64_t n_vec = n_bases / 32;              // whole 16-byte input groups that are fully in range
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
-        const uint4 in = *reinterpret_cast<const uint4 *>(packed + 16 * i);
-        uint4 a, b;
-        unpack_dword(in.x, t0, t1, t2, t3, &a.x, &a.y);
-        unpack_dword(in.y, t0, t1, t2, t3, &a.z, &a.w);
-        unpack_dword(in.z, t0, t1, t2, t3, &b.x, &b.y);
-        unpack_dword(in.w, t0, t1, t2, t3, &b.z, &b.w);
-        uint4 *o = reinterpret_cast<uint4 *>(ascii + 32 * i);
-        o[0] = a;
-        o[1] = b;
-    }
-    // tail (< 32 bases): one thread, byte by byte
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint32_t tt[4] = {t0, t1, t2, t3};
-        for (uint64_t k = n_vec * 32; k < n_bases; k++) {
-            const uint64_t byte = k >> 1;
-            if (byte >= n_packed) break;
-            const uint32_t nib = (k & 1) ? packed[byte] >> 4 : packed[byte] & 15u;
-            ascii[k] = static_cast<uint8_t>(tt[nib >> 2] >> (8 * (nib & 3)));
-        }
-    }
-}
-
-// ======================================================================================
 // soft mask (MaskReader + Decoder::mask_sequence, reader.rs:198-231, mod.rs:402-441)
 // ======================================================================================
 // Runs alternate unmasked / masked starting unmasked; run k covers [ends[k-1], ends[k]).
@@ -3601,17 +3560,6 @@ void launch_lz_execute(hipStream_t stream, const LzArgs &a, bool ascii) {
         lz_execute<true>(stream, a);
     else
         lz_execute<false>(stream, a);
-}
-
-void launch_unpack4(hipStream_t stream, const uint8_t *packed, uint64_t n_packed, uint8_t *ascii, uint64_t n_bases,
-                    uint32_t t_char, uint32_t *status) {
-    if (!n_bases) return;
-    const uint64_t n_vec = n_bases / 32;
-    uint64_t blocks = (n_vec + 255) / 256;
-    if (blocks > 256u * 16u) blocks = 256u * 16u;      // grid-stride: 16 workgroups per CU
-    if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(k_unpack4, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, packed, n_packed, ascii,
-                       n_bases, t_char, status);
 }
 
 void launch_mask_apply(hipStream_t stream, uint8_t *ascii, uint64_t n_bases, uint64_t lo_clamp, uint64_t hi_clamp,

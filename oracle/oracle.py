@@ -77,6 +77,7 @@ def lib():
         L.no_drain.argtypes = [c_void_p, c_int, POINTER(DrainResult)]
         L.rs_available.restype = c_int
         L.rs_drain.argtypes = [c_char_p, c_size_t, c_int, POINTER(DrainResult)]
+        L.rs_drain_limit.argtypes = [c_char_p, c_size_t, c_int, c_uint64, POINTER(DrainResult)]
         L.rs_drain_parallel.restype = c_uint64
         L.rs_drain_parallel.argtypes = [c_char_p, c_size_t, c_int]
         _lib = L
@@ -135,6 +136,15 @@ def ref_shape_drain(data: bytes, want_hash=True):
     if rc != 0:
         raise OracleError(rc)
     return out
+
+
+def ref_shape_stream(data: bytes, limit=(1 << 64) - 1, want_hash=True):
+    """The same, as far as it gets: -> (rc, DrainResult) where rc is 0 or the error the STREAMING pipeline meets, and the
+    result counts and hashes the records it had handed out before that (or before `limit` records).  This is the
+    reference's error timing: records in front of a corrupt block are yielded, then Err (mod.rs:356-399)."""
+    out = DrainResult()
+    rc = lib().rs_drain_limit(data, len(data), int(want_hash), limit, byref(out))
+    return rc, out
 
 
 def ref_shape_drain_parallel(data: bytes, threads: int) -> int:

@@ -302,7 +302,16 @@ static int mask_sequence(rs_decoder *d, uint8_t *seq, uint64_t len) /* mod.rs:40
 }
 
 /* Drains the whole archive as `for record in Decoder::new(..)` does; returns 0, or a negative code on any error. */
+int rs_drain_limit(const uint8_t *bytes, size_t n, int want_hash, uint64_t limit, no_drain_result *out);
 int rs_drain(const uint8_t *bytes, size_t n, int want_hash, no_drain_result *out)
+{
+    return rs_drain_limit(bytes, n, want_hash, UINT64_MAX, out);
+}
+
+/* ... at most `limit` records of it: what the reference has handed out by then (it streams: a corrupt block in the
+ * middle of a section is met after the records in front of it, decoder/mod.rs:356-399 over :221-223).  *out counts and
+ * hashes the records yielded before the error or the limit, whichever comes first. */
+int rs_drain_limit(const uint8_t *bytes, size_t n, int want_hash, uint64_t limit, no_drain_result *out)
 {
     static const uint8_t FLAG[6] = {0x20, 0x10, 0x08, 0x04, 0x02, 0x01};
     memset(out, 0, sizeof *out);
@@ -348,7 +357,7 @@ int rs_drain(const uint8_t *bytes, size_t n, int want_hash, no_drain_result *out
     hacc hs = {0, 0, 0}, hq = {0, 0, 0}, he = {0, 0, 0}, hi = {0, 0, 0}, hc = {0, 0, 0};
     uint64_t end = 0;
     int rc = 0;
-    for (d->n = 0; d->n < d->h.number_of_sequences; d->n++) { /* Iterator::next, mod.rs:444-451 */
+    for (d->n = 0; d->n < d->h.number_of_sequences && d->n < limit; d->n++) { /* Iterator::next, mod.rs:444-451 */
         rstring id = {0, 0, 0}, com = {0, 0, 0}, seq = {0, 0, 0}, qual = {0, 0, 0};
         int have_len = 0;
         uint64_t l = 0;

@@ -293,12 +293,57 @@ def fuzz_cases(seed=1, n=120):
 
 
 def fuzz_disagreements(cases_list, lib=None):
+    """Names of the cases on which product and checker disagree: both succeed with different records, or both fail with
+    errors of different kinds (where only one of them fails the detection differs in strictness, which is allowed; what
+    either hands out before failing must still be a prefix of what the other does)."""
     bad = []
     for name, blob, opts in cases_list:
         got, want = run_product(blob, opts, lib), run_oracle(blob, opts)
-        if got[1] is None and want[1] is None and got != want:
-            bad.append(name)
+        if got[1] is None and want[1] is None:
+            if got != want:
+                bad.append(name)
+        elif got[1] is not None and want[1] is not None:
+            # Both fail: the same records in front of the error, and the same KIND of error -- except that an archive which
+            # is both cut short and corrupt may be Io(UnexpectedEof) to one and Io(InvalidData) to the other (the product's
+            # host walk sees every block header before the device decodes a byte; the checker decodes front to back).
+            kinds = {got[1], want[1]}
+            if got[0] != want[0] or (len(kinds) > 1 and kinds != {"io:eof", "io:invalid"}):
+                bad.append("%s: %s after %d records, checker %s after %d" % (name, got[1], len(got[0]), want[1], len(want[0])))
+        else:
+            a, b = (got[0], want[0]) if got[1] is not None else (want[0], got[0])    # a: from the side that failed
+            if a != b[:len(a)]:
+                bad.append(name + ": records before the error differ")
     return bad
+
+
+def error_timing(blob, opts, lib=None, eager=True, slack=0):
+    """An archive that is malformed somewhere inside a section, three ways:
+      * the reference's timing (oracle/ref_shape.c, streaming like mod.rs:356-399 over :221-223): k records, then the error;
+      * the product through the record iterator: it decodes a section whole (or tile by tile) when the first record needs
+        it, so the error comes at that record -- DESIGN.md section 8 -- i.e. after j <= k records, and those j are the
+        streaming pipeline's first j;
+      * the eager checker (oracle/naf_oracle.c), which the product equals exactly.
+    Returns (k, streaming rc, j, product error kind)."""
+    from nafcodec_amd import _ffi
+    from oracle import oracle
+    L = lib or _ffi.default()
+    rc, st = oracle.ref_shape_stream(blob)
+    got, err = run_product(blob, opts, lib)
+    if eager:                                              # (decoded in tiles, the product gets further than the eager checker)
+        assert (got, err) == run_oracle(blob, opts)
+    assert (rc != 0) == (err is not None), (rc, err)
+    # (slack: libzstd's streaming decoder meets the bad block while it fills the 4 KiB request that ENDS the block in front of
+    #  it, and the reference loses that request's bytes with the error -- a record that ends in those 4 KiB is one this
+    #  library, which fails tile by tile, still hands out)
+    assert len(got) <= st.n_records + slack, (len(got), st.n_records)
+    # what was handed out is the streaming pipeline's first records (its checksums over exactly that many)
+    m = min(len(got), st.n_records)
+    rc2, first = oracle.ref_shape_stream(blob, limit=m)
+    seq = "".join(r[2] or "" for r in got[:m]).encode()
+    qual = "".join(r[3] or "" for r in got[:m]).encode()
+    assert first.n_records == m and first.n_bases == len(seq)
+    assert first.seq_hash == L.c.nafgpu_hash64_host(seq, len(seq)) and first.qual_hash == L.c.nafgpu_hash64_host(qual, len(qual))
+    return st.n_records, rc, len(got), err
 
 
 def check_sharding(lib, n_bases, mask, worlds=(2, 3, 5), seed=5):

@@ -117,6 +117,38 @@ def test_pointer_jumping_distance_limit_falls_back_to_frame_order(emu, all_cases
                 assert cases.run_product(blob, opts, emu) == cases.run_oracle(blob, opts), (name, limit)
 
 
+def test_error_timing_against_the_streaming_reference(emu, all_cases, monkeypatch):
+    """Malformed in the middle of a section: the reference has streamed k records by the time it meets the bad block;
+    this library decodes a section when the first record needs it, so its error comes at record j <= k (DESIGN section 8:
+    the documented deviation) and what it handed out before are the reference's first j records.  With the section cut
+    into tiles the error comes with the tile that holds it: records of the tiles in front are handed out."""
+    from oracle import oracle
+    if not oracle.ref_shape_available():
+        pytest.skip("libzstd not loadable")
+    todo = {name: (blob, opts) for name, blob, opts in all_cases if name in ("truncated_mid", "bitflip_sequence", "checksum_wrong", "truncated_tail")}
+    seen = {}
+    for name, (blob, opts) in todo.items():
+        seen[name] = cases.error_timing(blob, opts, emu)
+        # (a flipped bit inside Huffman-coded literals decodes to other symbols without any error: both pipelines then agree on them)
+        if name != "bitflip_sequence":
+            assert seen[name][1] != 0 and seen[name][3] in ("io:invalid", "io:eof"), (name, seen[name])
+    # (checksum_wrong: everything decodes, the frame's last four bytes disagree)
+    assert seen["checksum_wrong"][2] == 0 and seen["checksum_wrong"][3] == "io:invalid"
+    # a larger archive, corrupt three quarters in, decoded in tiles: the tiles in front of the damage hand out their records
+    import naf_writer as nw
+    import numpy as np
+    rng = np.random.default_rng(8)
+    recs = cases.make_records(rng, [20000] * 60, iupac=0.01)
+    good = bytearray(nw.write_naf(recs, level=1))
+    at = len(good) * 3 // 4
+    good[at:at + 300] = bytes(300)                          # (a zeroed stretch: the Huffman streams it crosses no longer end where they must)
+    emu.c.nafgpu_test_hooks(1)
+    k, rc, j_whole, _ = cases.error_timing(bytes(good), {}, emu)
+    monkeypatch.setenv("NAFGPU_TILE_KIB", "256")
+    k2, rc2, j_tiled, _ = cases.error_timing(bytes(good), {}, emu, eager=False, slack=1)
+    assert rc != 0 and (k, rc) == (k2, rc2) and j_whole == 0 and k - 7 <= j_tiled <= k + 1, (k, j_whole, j_tiled)
+
+
 def test_block_range_sharding(emu):
     cases.check_sharding(emu, 3_000_001, True)
     cases.check_sharding(emu, 1_500_000, False, worlds=(2, 8))

@@ -244,6 +244,31 @@ def test_sequence_chains_out_of_lds_and_out_of_l2(lib, monkeypatch):
         assert cases.fuzz_disagreements(cases.fuzz_cases(seed=5, n=60)) == []
 
 
+def test_error_timing_against_the_streaming_reference(lib, monkeypatch):
+    """Malformed inside a section: the reference (oracle/ref_shape.c: streaming, as mod.rs:356-399) has handed out k records
+    when it meets the damage; this library fails at the first record that needs the section -- or, decoded in tiles, the
+    tile that holds the damage -- and what it handed out before are the reference's first records."""
+    import cases
+    import naf_writer as nw
+    import numpy as np
+    from oracle import oracle
+    if not oracle.ref_shape_available():
+        pytest.skip("libzstd not loadable")
+    for name, blob, opts in cases.build_cases(scale=2):
+        if name in ("truncated_mid", "truncated_tail", "checksum_wrong", "bitflip_sequence"):
+            k, rc, j, err = cases.error_timing(blob, opts)
+            assert name == "bitflip_sequence" or (rc != 0 and j == 0), (name, k, rc, j, err)
+    rng = np.random.default_rng(8)
+    good = bytearray(nw.write_naf(cases.make_records(rng, [20000] * 300, iupac=0.01), level=1))
+    at = len(good) * 3 // 4
+    good[at:at + 300] = bytes(300)
+    lib.c.nafgpu_test_hooks(1)
+    k, rc, j_whole, _ = cases.error_timing(bytes(good), {})
+    monkeypatch.setenv("NAFGPU_TILE_KIB", "1024")
+    k2, rc2, j_tiled, _ = cases.error_timing(bytes(good), {}, eager=False, slack=1)
+    assert rc != 0 and (k, rc) == (k2, rc2) and j_whole == 0 and k - 27 <= j_tiled <= k + 1, (k, j_whole, j_tiled)
+
+
 def test_corrupted_archives_terminate_and_never_disagree_silently(lib):
     """The same corrupted inputs the CPU harness runs under AddressSanitizer: on the GPU they must
     come back as errors (or as the same records the oracle gives), never as a fault or a hang."""

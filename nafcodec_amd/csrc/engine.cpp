@@ -52,6 +52,20 @@ bool DevBuf::alloc(size_t bytes) {
     if (ptr_ && bytes <= size_) return true;
     release();
     void *p = nullptr;
+#ifndef NAFGPU_EMU
+    // Experiment (nafgpu_test_hooks + NAFGPU_ALLOC_CONTIGUOUS=1, tools/placement_probe.sh): large buffers physically
+    // contiguous.  K1 runs 8 % slower for some placements of its 50 GB of buffers -- measured: this
+    // flag does not change that (10.7-11.9 ms over eight decoders either way), so it stays off.
+    const char *ce = hook_env("NAFGPU_ALLOC_CONTIGUOUS");
+    const bool contiguous = ce && ce[0] == '1';
+    if (contiguous && bytes >= (size_t(64) << 20) && hip_ok(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocContiguous)) && p) {
+        ptr_ = p;
+        size_ = bytes;
+        return true;
+    }
+    (void)hipGetLastError();
+    p = nullptr;
+#endif
     if (!hip_ok(hipMalloc(&p, bytes ? bytes : 16))) return false;
     ptr_ = p;
     size_ = bytes ? bytes : 16;
@@ -150,8 +164,12 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
     expect_ = expect_size;
     master_blocks_ = master_.blk_size.size();
     master_streams_ = master_.streams.size();
-    if ((master_.seq_blocks.empty() && master_.known_out != expect_size) ||
-        expect_size > static_cast<uint64_t>(master_.blk_size.size()) * kBlockMax)     // untrusted: no block decodes to more than 128 KiB
+    // The size the archive announces is not something the reference checks (its zstd reader is never told it; a section that
+    // decodes to less fails at the record that needs the missing bytes, mod.rs:373-385 over reader.rs:104-119): without LZ
+    // sequences the walk knows what the section decodes to, and that is what is decoded; with sequences the announced size
+    // bounds the output, less is found out on the device (check()), more is an error.
+    if (master_.seq_blocks.empty()) expect_size = expect_ = master_.known_out;
+    if (expect_size > static_cast<uint64_t>(master_.blk_size.size()) * kBlockMax)     // untrusted: no block decodes to more than 128 KiB
         return Failure::io(NAFGPU_IO_INVALID_DATA, "zstd: decoded size differs from the size recorded in the archive");
     // ---- this process's block range: a shard of a section without LZ sequences -- or, when the ranks run the shard
     // protocol, of any section -- else everything
@@ -390,8 +408,8 @@ Failure SectionJob::decode_tile(uint32_t t, hipStream_t stream, StageTimer *time
         carry_frame_ = plan_.last_seq_frame;
     }
     tiles_done_ = t + 1;
-    if (tile_pos0_ + tile_len_ > out1_ || (tiles_done_ == tiles_.size() && tile_pos0_ + tile_len_ != out1_))
-        return Failure::io(NAFGPU_IO_INVALID_DATA, status_text(kStSizeMismatch));
+    if (tile_pos0_ + tile_len_ > out1_) return Failure::io(NAFGPU_IO_INVALID_DATA, status_text(kStSizeMismatch));
+    if (tiles_done_ == tiles_.size()) out1_ = tile_pos0_ + tile_len_;                  // (less than announced: see prepare)
     return Failure();
 }
 
@@ -725,7 +743,7 @@ Failure SectionJob::shard_place(const ShardSummary *all, uint32_t n_ranks, hipSt
         if (r < me) before += all[r].decoded;
         sum += all[r].decoded;
     }
-    if (sum != expect_) return Failure::io(NAFGPU_IO_INVALID_DATA, status_text(kStSizeMismatch));
+    if (sum > expect_) return Failure::io(NAFGPU_IO_INVALID_DATA, status_text(kStSizeMismatch));   // (less: see prepare)
     out0_ = before;
     out1_ = before + decoded_;
     tile_pos0_ = out0_;
@@ -809,6 +827,13 @@ Failure SectionJob::check(hipStream_t stream) {
     if (!hip_ok(hipMemcpyAsync(st, d_status_.bytes(), sizeof st, hipMemcpyDeviceToHost, stream)) ||
         !hip_ok(hipStreamSynchronize(stream)))
         return Failure::make(NAFGPU_E_DEVICE, "device status read-back failed");
+    // a section with LZ sequences may decode to less than the archive announces (prepare): what there is, is what counts
+    if (has_lz_ && tiles_.size() == 1 && !sharded_ && st[0] == 0) {
+        uint64_t total = 0;
+        if (hip_ok(hipMemcpyAsync(&total, d_blk_base_.as<uint64_t>() + n_blocks_, sizeof total, hipMemcpyDeviceToHost, stream)) &&
+            hip_ok(hipStreamSynchronize(stream)) && total <= expect_)
+            out1_ = out0_ + total;
+    }
     lz_residue_ = 0;
     if (n_seq_blocks_) {                                       // statistics: matches the launched passes did not finish
         unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -1430,7 +1430,10 @@ __global__ void k_scan_finish_blocks(uint64_t *blk_base, uint64_t n, const ScanT
                                      uint32_t *status) {
     if (status[0] != 0) return;
     blk_base[n] = totals->sum;
-    if (expect != ~0ull && totals->sum != expect) flag_error(status, kStSizeMismatch, 0xFFFFFFFFu);   // (~0: a tile of a section with sequences -- the host adds the tiles up)
+    // More than the archive announces would not fit the output; LESS is not an error in the reference -- its zstd reader is
+    // never told the size, the record that needs the missing bytes fails (Io(UnexpectedEof)) -- and so not here: the host
+    // reads the total back (SectionJob::check).  (~0: a tile of a section with sequences -- the host adds the tiles up)
+    if (expect != ~0ull && totals->sum > expect) flag_error(status, kStSizeMismatch, 0xFFFFFFFFu);
 }
 
 // ======================================================================================

@@ -8,6 +8,7 @@ from nafcodec_amd import _ffi
 n, ip = int(float(sys.argv[1])), int(sys.argv[2])
 mask = len(sys.argv) > 3 and sys.argv[3] == "1"
 base = _ffi.default()
+base.c.nafgpu_test_hooks(1)
 arc = base.synth(n, seed=0x4E4146, with_mask=mask, iupac_permille=ip)
 # (the archive goes through a file in /dev/shm and nafgpu_open_path: ctypes cannot hand a 10 GB buffer to a file-like)
 path_arc = "/dev/shm/nafgpu_probe_%d.naf" % os.getpid()

@@ -2322,7 +2322,6 @@ constexpr uint32_t kPjFinal = 0xFFFF0000u;   // D >= kPjFinal: final, and the lo
 constexpr uint32_t kPjWait = kPjFinal - 1u;  // an element of the window in front of a shard whose value has not arrived yet (shard protocol):
                                              // not pending, not final -- whoever copies from it stays pending, and no distance reaches this value
 __device__ inline bool pj_pending(uint32_t v) { return v - 1u < kPjWait - 1u; }   // 1 <= v < kPjWait: a distance
-constexpr uint32_t kPjShort = 16;            // k_pj_fill: matches up to this long are filled by the thread that looked at them
 constexpr uint32_t kPjLocal = 4;             // jumps inside the tile (LDS) before a sweep looks into memory
 constexpr uint32_t kPjStripSweeps = 1;       // ... for the first this-many sweeps; what they leave is scattered: tile-wise from there
 constexpr uint32_t kPjWin = 1;               // tiles a strip-wise sweep keeps in LDS behind the current one (k_pj_sweep)
@@ -2331,116 +2330,135 @@ constexpr uint32_t kPjSweeps = 24;           // a sweep at least halves every ch
                                              // frame-order walk (every launch that finds nothing left still costs its 4-5 us: 40 of them
                                              // plus as many k_pj_list were 0.4 ms per section)
 
+// Output-ordered (round 3): the threads of a workgroup take CONSECUTIVE elements of the block's output, four each, find the
+// sequence an element belongs to with one binary search over the batch's output positions (LDS) and write its word of D --
+// a literal: the FINAL word, its value taken from the literal buffer (the output itself gets it from k_pj_emit, in order,
+// with everything else); an element of a match: the distance.  Every word of the block's range is written, in 16-byte
+// stores: no memset of D in front, no scattered runs (the first version wrote 4-byte runs at every match and the literal
+// runs into the output: 2.5 GB of write granules for 0.5 GB of words on level-3 DNA), and the sweeps' first look at a
+// literal source finds its value in the same word.  Blocks whose literals k_huf_decode put in place (sb.direct) write 0
+// for them ("literal, value in the output").  What lies between the blocks with sequences (raw / RLE / literal-only
+// blocks, the window in front of a tile) gets zeros from the block behind it; the last block also zeroes the tail up to
+// n_elems.  skip_lo: leading elements that are somebody else's (a shard's window that has not arrived: kPjWait).
 template <bool ASCII>
 __global__ __launch_bounds__(256) void k_pj_fill(const SeqBlock *__restrict__ blocks, uint32_t n_blocks, const Seq *__restrict__ seqs,
                                                  const uint32_t *__restrict__ rep_init, const uint64_t *__restrict__ blk_base,
                                                  uint32_t *D, const uint8_t *__restrict__ lit, uint32_t *blk_pending,
-                                                 uint8_t *out_bytes, uint32_t t_char, uint32_t *status) {
-    // Also what k_lz_literals does for the other sections (every literal run to its place in the output), in the same walk:
-    // one read of the 20-byte sequence records instead of two (7 GB for the qualities of 10 M reads).
-    using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
-    __shared__ uint64_t s_pos[256];
-    __shared__ uint32_t s_off[256];
-    __shared__ uint32_t s_pre[2][257];                     // element-count prefix sums (ping-pong for the scan)
-    __shared__ uint32_t s_abort, s_long[2];                // s_long[round & 1]: some match of the round is long
-    __shared__ uint32_t s_lit[256], s_nlit[2];             // the round's literal runs too long for their own thread
+                                                 uint32_t t_char, uint32_t n_sel_blocks, uint64_t n_elems, uint64_t skip_lo, uint32_t *status) {
+    __shared__ uint32_t s_opos[257], s_ll[256], s_off[256], s_lpos[256];
+    __shared__ uint32_t s_abort;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) {
-        s_abort = status[0];
-        s_long[0] = s_long[1] = 0;
-        s_nlit[0] = s_nlit[1] = 0;
-    }
+    if (tid == 0) s_abort = status[0];
     __syncthreads();
     if (s_abort) return;
-    auto put = [&](Elem *d, uint8_t c) { *d = ASCII ? static_cast<Elem>(byte_chars(c, t_char)) : static_cast<Elem>(c); };
-    uint32_t round = 0;
+    auto zero_range = [&](uint64_t lo, uint64_t hi) {      // D[lo, hi) = 0, by the whole workgroup (lo, hi uniform)
+        if (lo < skip_lo) lo = skip_lo;
+        if (hi <= lo) return;
+        const uint64_t a0 = (lo + 3) & ~uint64_t(3), a1 = hi & ~uint64_t(3);
+        if (a0 >= a1) {
+            for (uint64_t e = lo + tid; e < hi; e += 256) D[e] = 0;
+            return;
+        }
+        for (uint64_t e = lo + tid; e < a0; e += 256) D[e] = 0;
+        for (uint64_t e = a0 + 4ull * tid; e < a1; e += 1024) *reinterpret_cast<uint4 *>(D + e) = make_uint4(0, 0, 0, 0);
+        for (uint64_t e = a1 + tid; e < hi; e += 256) D[e] = 0;
+    };
+    auto lit_word = [&](uint8_t c) -> uint32_t { return kPjFinal | (ASCII ? byte_chars(c, t_char) : static_cast<uint32_t>(c)); };
     for (uint32_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
         const SeqBlock sb = blocks[b];
         const uint64_t obase = blk_base[sb.blk], fstart = blk_base[sb.frame_first_blk];
         const uint32_t init[3] = {rep_init[3 * b], rep_init[3 * b + 1], rep_init[3 * b + 2]};
-        Elem *out = reinterpret_cast<Elem *>(out_bytes) + obase;
         const uint8_t *blit = lit + sb.lit_off;
-        const Seq *sq = seqs + sb.seq_first;
-        const bool do_lit = !sb.direct;                    // (else k_huf_decode put the literals in place)
+        const bool has_lit = !sb.direct;                   // (else k_huf_decode put the literals in place: their words are 0)
         if (tid == 0) blk_pending[b] = sb.n_seq;           // (for the frame-order walk, should it have to run)
+        // what lies between the block with sequences in front of this one (or the start) and this block
+        zero_range(b ? blk_base[blocks[b - 1].blk + 1] : 0, obase);
+        uint32_t out_end = 0;                              // elements of the block written so far
         for (uint32_t s0 = 0; s0 < sb.n_seq; s0 += 256) {
-            uint32_t ml = 0;
+            __syncthreads();                               // the batch before is done with the arrays
+            uint32_t span_end = 0;
             if (s0 + tid < sb.n_seq) {
                 const Seq q = seqs[sb.seq_first + s0 + tid];
-                if (do_lit) {
-                    if (q.ll <= kLzShort)
-                        for (uint32_t k = 0; k < q.ll; k++) put(out + q.opos + k, blit[q.lpos + k]);
-                    else
-                        s_lit[atomicAdd(&s_nlit[round & 1u], 1u)] = s0 + tid;
-                }
                 bool bad = false;
-                const uint32_t off = rep_resolve(q.off, init, &bad);
+                uint32_t off = rep_resolve(q.off, init, &bad);
                 const uint64_t mpos = obase + q.opos + q.ll;
-                if (bad || off > mpos - fstart || off >= kPjWait) {    // reaches before the frame (corrupt) / beyond any legal window
+                if (bad || off > mpos - fstart || off >= kPjWait) {   // reaches before the frame (corrupt) / beyond any legal window
                     flag_error(status, kStBadOffset, sb.blk);
-                } else if (q.ml <= kPjShort) {              // a short match (the usual kind in quality strings): its own thread
-                    for (uint32_t k = 0; k < q.ml; k++) D[mpos + k] = k < off ? off : off * (k / off + 1u);
+                    off = 1;
+                }
+                s_opos[tid] = q.opos;
+                s_ll[tid] = q.ll;
+                s_off[tid] = off;
+                s_lpos[tid] = q.lpos;
+                span_end = q.opos + q.ll + q.ml;
+            }
+            const uint32_t n_here = sb.n_seq - s0 < 256 ? sb.n_seq - s0 : 256;
+            if (tid == n_here - 1) s_opos[n_here] = span_end;   // one past the batch's last element
+            __syncthreads();
+            const uint32_t e0 = s_opos[0], e1 = s_opos[n_here];
+            if (e1 > kBlockMax || e0 != out_end) {         // (k_seq_values checked the sums: cannot happen)
+                flag_error(status, kStSizeMismatch, sb.blk);
+                break;
+            }
+            // four consecutive elements per thread, aligned to 16 bytes of D where the range allows
+            const uint64_t g0 = obase + e0, g1 = obase + e1;
+            const uint64_t a0 = (g0 + 3) & ~uint64_t(3);
+            for (uint64_t g = (g0 & ~uint64_t(3)) + 4ull * tid; g < g1; g += 1024) {
+                uint32_t w[4];
+                uint32_t lo = 0;
+                const uint64_t first = g < g0 ? g0 : g;
+                {   // the sequence that holds the first of the four: largest j with opos[j] <= e
+                    const uint32_t e = static_cast<uint32_t>(first - obase);
+                    uint32_t hi = n_here;
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (s_opos[mid] <= e)
+                            lo = mid;
+                        else
+                            hi = mid;
+                    }
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint64_t ge = g + k;
+                    w[k] = 0;
+                    if (ge < g0 || ge >= g1) continue;
+                    const uint32_t e = static_cast<uint32_t>(ge - obase);
+                    while (lo + 1 < n_here && s_opos[lo + 1] <= e) lo++;   // (sequences without output are stepped over)
+                    const uint32_t r = e - s_opos[lo], ll = s_ll[lo];
+                    if (r < ll) {
+                        w[k] = has_lit ? lit_word(blit[s_lpos[lo] + r]) : 0u;
+                    } else {
+                        const uint32_t kk = r - ll, off = s_off[lo];
+                        // element kk of a match at distance off copies element kk - off; where the match reaches into itself
+                        // (off <= kk: a run) that is an element of the same match, and so on down to the `off` elements in
+                        // front of it -- point there at once instead of leaving kk / off hops to the sweeps
+                        w[k] = kk < off ? off : off * (kk / off + 1u);
+                    }
+                }
+                if (g >= a0 && g + 4 <= g1) {
+                    *reinterpret_cast<uint4 *>(D + g) = make_uint4(w[0], w[1], w[2], w[3]);
                 } else {
-                    ml = q.ml;
-                    s_pos[tid] = mpos;
-                    s_off[tid] = off;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++)
+                        if (g + k >= g0 && g + k < g1) D[g + k] = w[k];
                 }
             }
-            __syncthreads();                               // previous round's readers are done (first round: nothing to wait for)
-            s_pre[0][tid + 1] = ml;
-            if (ml) s_long[round & 1u] = 1;
-            {   // the long literal runs of the round, by the whole workgroup
-                const uint32_t nl = s_nlit[round & 1u];
-                for (uint32_t j = 0; j < nl; j++) {
-                    const Seq q = sq[s_lit[j]];
-                    if (q.ll >= kLzWide)
-                        lz_copy_wide<ASCII>(out + q.opos, blit + q.lpos, q.ll, tid, t_char);
-                    else
-                        for (uint32_t k = tid; k < q.ll; k += 256) put(out + q.opos + k, blit[q.lpos + k]);
-                }
-            }
-            if (tid == 0) {
-                s_pre[0][0] = s_pre[1][0] = 0;
-                s_long[(round + 1u) & 1u] = 0;             // (the next round's flag and counter: nobody touches them before the next barrier)
-                s_nlit[(round + 1u) & 1u] = 0;
-            }
-            __syncthreads();
-            const bool any_long = s_long[round & 1u] != 0;
-            round++;
-            if (!any_long) continue;                       // (uniform) short matches only: nothing left to do for this round
-            uint32_t cur = 0;
-            for (uint32_t d = 1; d < 256; d <<= 1) {       // inclusive scan of entries 1..256
-                const uint32_t v = s_pre[cur][tid + 1] + (tid >= d ? s_pre[cur][tid + 1 - d] : 0);
-                s_pre[cur ^ 1][tid + 1] = v;
-                cur ^= 1;
-                __syncthreads();
-            }
-            const uint32_t *pre = s_pre[cur];
-            const uint32_t total = pre[256];
-            for (uint32_t e = tid; e < total; e += 256) {  // consecutive threads on consecutive elements, whatever the match lengths
-                uint32_t lo = 0, hi = 256;                 // largest j with pre[j] <= e
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (pre[mid] <= e)
-                        lo = mid;
-                    else
-                        hi = mid;
-                }
-                // element k of a match at distance off copies element k - off; where the match reaches into itself
-                // (off < ml: a run) that is an element of the same match, and so on down to the `off` elements in front of
-                // it -- point there at once instead of leaving k / off hops to the sweeps
-                const uint32_t k = e - pre[lo], off = s_off[lo];
-                D[s_pos[lo] + k] = k < off ? off : off * (k / off + 1u);
-            }
-            __syncthreads();
+            out_end = e1;
         }
-        if (do_lit) {                                      // literals after the last sequence run to the end of the block
-            const Seq last = sq[sb.n_seq - 1];
+        __syncthreads();
+        // literals after the last sequence run to the end of the block
+        {
+            const Seq last = seqs[sb.seq_first + sb.n_seq - 1];
             const uint32_t lused = last.lpos + last.ll, oend = last.opos + last.ll + last.ml;
-            if (sb.lit_size - lused >= kLzWide)
-                lz_copy_wide<ASCII>(out + oend, blit + lused, sb.lit_size - lused, tid, t_char);
-            else
-                for (uint32_t k = tid; k < sb.lit_size - lused; k += 256) put(out + oend + k, blit[lused + k]);
+            const uint32_t n_tail = sb.lit_size > lused ? sb.lit_size - lused : 0;
+            if (has_lit) {
+                for (uint32_t k = tid; k < n_tail; k += 256) D[obase + oend + k] = lit_word(blit[lused + k]);
+            } else {
+                zero_range(obase + oend, obase + oend + n_tail);
+            }
+            // ... and behind the last block with sequences: the rest of the selection, and of D
+            if (b + 1 == n_blocks) zero_range(obase + oend + n_tail, n_elems);
         }
     }
 }
@@ -3453,12 +3471,12 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
         if (eg == 0) eg = 1;
         uint32_t sweep0 = 1, sweep1 = kPjSweeps;
         if (!finish) {
-            (void)hipMemsetAsync(a.pj_dist, 0, static_cast<size_t>(a.n_elems) * sizeof(uint32_t), stream);
             if (wait)
                 hipLaunchKernelGGL(k_fill_u32, dim3(static_cast<uint32_t>(std::min<uint64_t>((a.halo_wait + 255) / 256, 2048))), dim3(256), 0, stream,
                                    a.pj_dist, a.halo_wait, kPjWait);
+            // (every word of D is written by k_pj_fill: no memset in front)
             hipLaunchKernelGGL(k_pj_fill<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.rep_init, a.blk_base,
-                               a.pj_dist, a.lit, a.blk_pending, a.out, a.t_char, a.status);
+                               a.pj_dist, a.lit, a.blk_pending, a.t_char, a.n_sel_blocks, a.n_elems, wait ? a.halo_wait : uint64_t(0), a.status);
             (void)hipMemsetAsync(lstate, 0, 4 * sizeof(unsigned long long), stream);
         } else {
             // the window is in the output buffer now: its elements become final words, and a few more sweeps -- chains were

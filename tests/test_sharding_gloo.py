@@ -59,7 +59,7 @@ dist.init_process_group("gloo")
 r, w = dist.get_rank(), dist.get_world_size()
 emu = _ffi.Library(os.path.join(%r, "tests", "emu", "_build", "libnafgpu_emu.so"))
 for name, blob, want_seq, want_qual, lens in cases.lz_shard_archives(1):
-    if name not in ("real_genome_l1", "random_dna_l3_frames", "fastq_like_l1"):
+    if name not in ("real_genome_l1", "fastq_like_l1"):
         continue
     dec = Decoder(io.BytesIO(blob), shard_rank=r, shard_count=w, shard_protocol=True, _lib=emu)
     for _ in range(2):                                     # (a second decode: the protocol starts over)
@@ -88,7 +88,7 @@ print("rank", r, "ok")
 def test_shard_protocol_over_gloo_two_and_three_ranks(tmp_path):
     """The shard protocol's exchange (one all-gather of 64 bytes, then the windows point to point) between real
     processes: gloo ranks driving the CPU harness decode archives WITH LZ sequences -- the statistics of a real genome,
-    level-3 DNA in three frames, FASTQ-like reads -- and every rank's share must be its part of the whole."""
+    FASTQ-like reads (Sequence and Quality both swept) -- and every rank's share must be its part of the whole."""
     import zstd_ref
     import pytest
     if not zstd_ref.available():

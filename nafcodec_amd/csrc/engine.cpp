@@ -7,7 +7,6 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
-#include <thread>
 
 namespace nafgpu {
 
@@ -142,55 +141,6 @@ StageTimes StageTimer::collect() {
     }
     if (t0_ && t1_) (void)hipEventElapsedTime(&t.total, t0_, t1_);
     return t;
-}
-
-// Compressed bytes to the device.  The source is pageable host memory -- a file mapping, or the caller's buffer -- and
-// one hipMemcpyAsync of it is staged by the runtime through a single bounce buffer (measured: 10 GB in 1.2 s).  Large
-// payloads go through staging of our own instead: a few worker threads, each with two pinned buffers and a stream of
-// its own, take alternate 16 MiB chunks -- the page faults of a fresh mapping are taken by all of them at once -- and
-// DMA them at the bus rate.  Returns when the bytes are on the device.
-static bool upload_payload(uint8_t *dst, const uint8_t *src, size_t n, hipStream_t stream) {
-    constexpr size_t kChunk = size_t(16) << 20;
-    const size_t n_chunks = (n + kChunk - 1) / kChunk;
-    unsigned hw = std::thread::hardware_concurrency();
-    unsigned workers = hw >= 16 ? 8u : (hw >= 8 ? 4u : 2u);
-    if (n_chunks < 8 || hw < 4) return hip_ok(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream));
-    if (workers > n_chunks / 2) workers = static_cast<unsigned>(n_chunks / 2);
-    int device = 0;
-    (void)hipGetDevice(&device);
-    std::atomic<size_t> next{0};
-    std::atomic<bool> good{true};
-    auto work = [&]() {
-        (void)hipSetDevice(device);
-        hipStream_t st = nullptr;
-        void *buf[2] = {nullptr, nullptr};
-        hipEvent_t ev[2] = {nullptr, nullptr};
-        bool ok = hip_ok(hipStreamCreate(&st)) && hip_ok(hipHostMalloc(&buf[0], kChunk)) && hip_ok(hipHostMalloc(&buf[1], kChunk)) &&
-                  hip_ok(hipEventCreate(&ev[0])) && hip_ok(hipEventCreate(&ev[1]));
-        for (unsigned k = 0; ok; k++) {
-            const size_t c = next.fetch_add(1);
-            if (c >= n_chunks) break;
-            const unsigned b = k & 1u;
-            const size_t off = c * kChunk, len = std::min(kChunk, n - off);
-            if (k >= 2) ok = hip_ok(hipEventSynchronize(ev[b]));             // the DMA out of this buffer two chunks ago
-            if (!ok) break;
-            std::memcpy(buf[b], src + off, len);
-            ok = hip_ok(hipMemcpyAsync(dst + off, buf[b], len, hipMemcpyHostToDevice, st)) && hip_ok(hipEventRecord(ev[b], st));
-        }
-        if (st) ok = hip_ok(hipStreamSynchronize(st)) && ok;
-        if (!ok) good.store(false);
-        for (int b = 0; b < 2; b++) {
-            if (ev[b]) (void)hipEventDestroy(ev[b]);
-            if (buf[b]) (void)hipHostFree(buf[b]);
-        }
-        if (st) (void)hipStreamDestroy(st);
-    };
-    std::vector<std::thread> pool;
-    for (unsigned w = 0; w < workers; w++) pool.emplace_back(work);
-    for (std::thread &t : pool) t.join();
-    if (good.load()) return true;
-    (void)hipGetLastError();                                                 // (staging failed: out of pinned memory, say -- the plain copy still works)
-    return hip_ok(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, stream));
 }
 
 // ------------------------------------------------------------------ SectionJob
@@ -366,7 +316,7 @@ Failure SectionJob::load_tile(uint32_t t, hipStream_t stream) {
     if (ok) {
         (void)hipMemsetAsync(d_src_buf_.bytes(), 0, kSrcFrontPad, stream);
         (void)hipMemsetAsync(d_src_buf_.bytes() + kSrcFrontPad + src_n, 0, kSrcBackPad, stream);
-        if (src_n) ok = upload_payload(d_src_buf_.bytes() + kSrcFrontPad, host_payload_ + plan_.src_lo, static_cast<size_t>(src_n), stream);
+        if (src_n) ok = hip_ok(hipMemcpyAsync(d_src_buf_.bytes() + kSrcFrontPad, host_payload_ + plan_.src_lo, src_n, hipMemcpyHostToDevice, stream));
         d_src_ = d_src_buf_.bytes() + kSrcFrontPad - plan_.src_lo;     // kernels address the payload by its offsets
     }
     ok = ok && d_blk_size_.upload(plan_.blk_size.data(), n_blocks_ * sizeof(uint32_t), stream) &&

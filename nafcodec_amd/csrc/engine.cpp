@@ -307,7 +307,9 @@ Failure SectionJob::load_tile(uint32_t t, hipStream_t stream) {
                      static_cast<unsigned long long>(plan_.lit_bytes), static_cast<unsigned long long>(plan_.src_hi - plan_.src_lo));
         for (const HufClass &c : classes_)
             std::fprintf(stderr, " {%u tasks, tbl %u, %s%s, lds %u B}", c.n_tasks, c.tbl, c.to_lit ? "lit" : "out", c.seg ? "+seg" : "", c.lds_bytes);
-        std::fprintf(stderr, "\n");
+        uint64_t cells = 0;
+        for (const SeqBlock &sb : plan_.seq_blocks) cells += (1u << sb.ll_al) + (1u << sb.of_al) + (1u << sb.ml_al);
+        std::fprintf(stderr, "; FSE cells per block: %llu on average, %u at most\n", static_cast<unsigned long long>(n_seq_blocks_ ? cells / n_seq_blocks_ : 0), cells_cap_);
     }
     // ---- the compressed bytes the tile's tasks read, with the padding k_huf_decode's whole-line loads may touch
     const uint64_t src_n = plan_.src_hi - plan_.src_lo;

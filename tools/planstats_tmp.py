@@ -10,5 +10,10 @@ qalpha = np.frombuffer(b"#8CGGGGGGGGGG<AFFFJJJJJJJJJJJJJJ", dtype=np.uint8)
 qual = qalpha[rng.integers(0, len(qalpha), n_bases)].tobytes()
 for level in (1, 3):
     blob = nw.write_naf([{"id": "q", "sequence": qual.decode()}], sequence_type="text", level=level)
-    print("level", level, len(blob), flush=True)
+    print("qual level", level, len(blob), flush=True)
+    d = nafcodec_amd.Decoder(io.BytesIO(blob)); d.decode_all_device(); d.close()
+seq = "".join(rng.choice(list("ACGT"), 20_000_000))
+for level in (1, 3):
+    blob = nw.write_naf([{"id": "q", "sequence": seq}], level=level)
+    print("dna level", level, len(blob), flush=True)
     d = nafcodec_amd.Decoder(io.BytesIO(blob)); d.decode_all_device(); d.close()

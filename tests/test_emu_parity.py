@@ -157,7 +157,8 @@ def test_shard_protocol_on_sections_with_lz_sequences(emu):
     """SURVEY 8e for archives as found in the wild: sections WITH LZ sequences over 2 / 3 / 8 block ranges through the
     shard protocol (nafgpu_shard_*) -- real-genome statistics, level-3 DNA in one and in three frames, FASTQ-like reads
     (Sequence and Quality both sharded), dense chains in two frames; both match routes where the archive is small."""
-    cases.check_lz_sharding(emu, 1, worlds=(2, 3, 8), names=("real_genome_l1", "random_dna_l3_frames", "text_dense_chains_frames"))
+    cases.check_lz_sharding(emu, 1, worlds=(2, 3, 8), names=("real_genome_l1",))
+    cases.check_lz_sharding(emu, 1, worlds=(3, 8), names=("random_dna_l3_frames", "text_dense_chains_frames"))
     cases.check_lz_sharding(emu, 1, worlds=(3,), names=("fastq_like_l1",))            # (all of them, larger, in the GPU test of the same name)
     cases.check_lz_sharding(emu, 1, worlds=(2,), names=("random_dna_l3_frames",), force_modes=("dense", "sparse"))
 
@@ -204,7 +205,8 @@ from conftest import golden_bytes
 from nafcodec_amd import _ffi
 lib = _ffi.Library(%r)
 heavy = ("dna_skewed_blocks_dict_seg", "dna_multi_tree_compact", "text_multi_tree_dict", "checksum_dna_blocks", "checksum_wrong",
-         "checksum_text_l3", "fastq_flush_per_record")    # (run without the sanitizer by the other tests)
+         "checksum_text_l3", "fastq_flush_per_record", "text_repeat_offsets_l1", "text_repeat_offsets_l9", "dna_repeat_offsets",
+         "mask_compact_tables", "mask_raw_rle_blocks")    # (run without the sanitizer by the other tests)
 part, parts = int(sys.argv[1]), int(sys.argv[2])         # (the cases are dealt over `parts` processes running side by side)
 todo = [c for c in cases.build_cases(1) if not c[0].endswith("_big") and c[0] not in heavy]
 todo += [(n, golden_bytes(n + ".naf"), {}) for n in ("phix", "masked", "CP040672")]

@@ -55,8 +55,8 @@ def test_tiles_on_the_cpu_harness(monkeypatch):
     from nafcodec_amd import _ffi
     # (a subset: the CPU harness runs one fibre per work-item)
     check(_ffi.Library(os.path.join(EMU_DIR, "libnafgpu_emu.so")), 1, 300, monkeypatch,
-          names=("dna_l3_big", "text_dense_chains", "dna_skewed_blocks_dict_seg", "dna_multi_tree_compact", "mask_run_gt_65535",
-                 "checksum_dna_blocks", "checksum_text_l3", "checksum_wrong"), fixtures=("phix",))
+          names=("dna_l3_big", "text_dense_chains", "dna_skewed_blocks_dict_seg", "mask_run_gt_65535",
+                 "checksum_dna_blocks", "checksum_wrong"), fixtures=("phix",))
     # block ranges of one archive, each decoded in tiles (decode_all_device per range, and the shard protocol)
     cases.check_sharding(_ffi.Library(os.path.join(EMU_DIR, "libnafgpu_emu.so")), 2_000_001, True, worlds=(2,))
 

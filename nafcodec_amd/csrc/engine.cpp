@@ -309,7 +309,15 @@ Failure SectionJob::load_tile(uint32_t t, hipStream_t stream) {
             std::fprintf(stderr, " {%u tasks, tbl %u, %s%s, lds %u B}", c.n_tasks, c.tbl, c.to_lit ? "lit" : "out", c.seg ? "+seg" : "", c.lds_bytes);
         uint64_t cells = 0;
         for (const SeqBlock &sb : plan_.seq_blocks) cells += (1u << sb.ll_al) + (1u << sb.of_al) + (1u << sb.ml_al);
-        std::fprintf(stderr, "; FSE cells per block: %llu on average, %u at most\n", static_cast<unsigned long long>(n_seq_blocks_ ? cells / n_seq_blocks_ : 0), cells_cap_);
+        uint64_t fresh = 0;                                    // tables that are not the block in front's (Repeat_Mode)
+        for (size_t k = 0; k < plan_.seq_blocks.size(); k++) {
+            const SeqBlock &sb = plan_.seq_blocks[k];
+            if (k == 0 || sb.ll_tbl != plan_.seq_blocks[k - 1].ll_tbl) fresh++;
+            if (k == 0 || sb.of_tbl != plan_.seq_blocks[k - 1].of_tbl) fresh++;
+            if (k == 0 || sb.ml_tbl != plan_.seq_blocks[k - 1].ml_tbl) fresh++;
+        }
+        std::fprintf(stderr, "; FSE cells per block: %llu on average, %u at most; %llu of %zu tables differ from the block in front's\n",
+                     static_cast<unsigned long long>(n_seq_blocks_ ? cells / n_seq_blocks_ : 0), cells_cap_, static_cast<unsigned long long>(fresh), 3 * plan_.seq_blocks.size());
     }
     // ---- the compressed bytes the tile's tasks read, with the padding k_huf_decode's whole-line loads may touch
     const uint64_t src_n = plan_.src_hi - plan_.src_lo;

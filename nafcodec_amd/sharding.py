@@ -64,7 +64,8 @@ def gather_placement(dist, torch, bases, packed_bytes, first_record, carry, tota
 #   1. every rank entropy-decodes its range (Huffman literals, FSE sequences) and puts together its block sizes and its
 #      repeat-offset map;
 #   2. ONE all-gather of 64 bytes per rank (RCCL over xGMI): decoded sizes and maps -- every rank now knows where its
-#      range begins, which repeat offsets it inherits and how large the window in front of it is;
+#      range begins, which repeat offsets it inherits and how large the window in front of it is (and, behind step 3, a
+#      1-element all-reduce of an error flag, so that a rank that failed leaves nobody waiting for its window);
 #   3. every rank places its literals and resolves every match that does not reach -- directly or through other
 #      matches -- into that window;
 #   4. the windows travel down the line, point to point (ncclSend / ncclRecv, at most window_size bytes each): a rank
@@ -73,16 +74,37 @@ def gather_placement(dist, torch, bases, packed_bytes, first_record, carry, tota
 SUMMARY_BYTES = 64
 
 
-def decode_sharded(dec, dist, torch, device, buffers=None):
+def decode_sharded(dec, dist, torch, device):
     """One sharded decode of `dec` (a Decoder opened with shard_rank / shard_count / shard_protocol=True) over the
-    process group: returns the nafgpu_device_result of this rank's share.  `device`: "cuda" (RCCL) or "cpu" (gloo)."""
+    process group: returns the nafgpu_device_result of this rank's share.  `device`: "cuda" (RCCL) or "cpu" (gloo).
+    A rank that fails (a corrupt block in its range, say) still takes part in every exchange -- nobody is left waiting in
+    a receive -- and every rank raises: the ranks agree on one flag (a 1-element all-reduce) after the placement step, and
+    skip the window exchange together when any of them has failed by then, and on one more at the end."""
     rank, world = dist.get_rank(), dist.get_world_size()
-    mine = torch.frombuffer(bytearray(dec.shard_begin()), dtype=torch.uint8).to(device)
+    error = None
+    try:
+        summary = dec.shard_begin()
+    except Exception as e:                                 # noqa: BLE001 -- carried past the collectives, raised below
+        error = e
+        summary = bytes(56) + b"\x01\x01" + bytes(6)        # nafgpu_shard_summary with failed[0] = failed[1] = 1
+    mine = torch.frombuffer(bytearray(summary), dtype=torch.uint8).to(device)
     everyone = torch.empty(SUMMARY_BYTES * world, dtype=torch.uint8, device=device)
     dist.all_gather_into_tensor(everyone, mine)
-    dec.shard_place(everyone.cpu().numpy().tobytes())
+    halo = [(0, 0, True), (0, 0, True)]
+    if error is None:
+        try:
+            dec.shard_place(everyone.cpu().numpy().tobytes())
+            halo = [dec.shard_halo(0), dec.shard_halo(1)]  # (synchronises: what the placement step found wrong is known here)
+        except Exception as e:                             # noqa: BLE001
+            error = e
+    flag = torch.tensor([0 if error is None else 1], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()) != 0:
+        if error is not None:
+            raise error
+        raise OSError(0, "zstd: another rank could not decode its part of the archive")
     for section in (0, 1):
-        recv_n, send_n, ready = dec.shard_halo(section)
+        recv_n, send_n, ready = halo[section]
         pending = None
         sbuf = rbuf = None
         if send_n and rank + 1 < world:
@@ -95,13 +117,31 @@ def decode_sharded(dec, dist, torch, device, buffers=None):
             dist.recv(rbuf, rank - 1)
             if device != "cpu":
                 torch.cuda.current_stream().synchronize()
-            dec.shard_import_halo(section, rbuf.data_ptr(), recv_n)
+            try:
+                dec.shard_import_halo(section, rbuf.data_ptr(), recv_n)
+            except Exception as e:                         # noqa: BLE001 -- the ranks behind still get their window (of a failed decode)
+                error = error or e
         if send_n and rank + 1 < world and not ready:
-            dec.shard_export_tail(section, sbuf.data_ptr(), send_n)
+            try:
+                dec.shard_export_tail(section, sbuf.data_ptr(), send_n)
+            except Exception as e:                         # noqa: BLE001
+                error = error or e
             pending = dist.isend(sbuf, rank + 1)
         if pending is not None:
             pending.wait()
-    return dec.shard_finish()
+    res = None
+    if error is None:
+        try:
+            res = dec.shard_finish()                       # (synchronises: a corrupt block in this rank's range is known here at the latest)
+        except Exception as e:                             # noqa: BLE001
+            error = e
+    flag = torch.tensor([0 if error is None else 1], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)            # one archive, one verdict: every rank raises when any of them failed
+    if error is not None:
+        raise error
+    if int(flag.item()) != 0:
+        raise OSError(0, "zstd: another rank could not decode its part of the archive")
+    return res
 
 
 def decode_sharded_local(decoders):

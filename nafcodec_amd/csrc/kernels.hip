@@ -2340,6 +2340,7 @@ constexpr uint32_t kPjSweeps = 24;           // a sweep at least halves every ch
 // for them ("literal, value in the output").  What lies between the blocks with sequences (raw / RLE / literal-only
 // blocks, the window in front of a tile) gets zeros from the block behind it; the last block also zeroes the tail up to
 // n_elems.  skip_lo: leading elements that are somebody else's (a shard's window that has not arrived: kPjWait).
+constexpr uint32_t kFillPer = 8;              // elements a thread of k_pj_fill takes per step
 template <bool ASCII>
 __global__ __launch_bounds__(256) void k_pj_fill(const SeqBlock *__restrict__ blocks, uint32_t n_blocks, const Seq *__restrict__ seqs,
                                                  const uint32_t *__restrict__ rep_init, const uint64_t *__restrict__ blk_base,
@@ -2400,14 +2401,17 @@ __global__ __launch_bounds__(256) void k_pj_fill(const SeqBlock *__restrict__ bl
                 flag_error(status, kStSizeMismatch, sb.blk);
                 break;
             }
-            // four consecutive elements per thread, aligned to 16 bytes of D where the range allows
+            // kFillPer consecutive elements per thread and step, aligned to 16 bytes of D where the range allows.  The kernel is
+            // bound by latency (PMC: waves wait 71 % of their cycles; every step is search -> addresses -> literal bytes ->
+            // store), so a step carries as much independent work as registers allow: ONE binary search for the first
+            // element, the next sequences' boundaries and fields fetched together, then all literal bytes at once.
             const uint64_t g0 = obase + e0, g1 = obase + e1;
             const uint64_t a0 = (g0 + 3) & ~uint64_t(3);
-            for (uint64_t g = (g0 & ~uint64_t(3)) + 4ull * tid; g < g1; g += 1024) {
-                uint32_t w[4];
+            for (uint64_t g = (g0 & ~uint64_t(kFillPer - 1)) + static_cast<uint64_t>(kFillPer) * tid; g < g1; g += static_cast<uint64_t>(kFillPer) * 256) {
+                uint32_t w[kFillPer];
                 uint32_t lo = 0;
-                const uint64_t first = g < g0 ? g0 : g;
-                {   // the sequence that holds the first of the four: largest j with opos[j] <= e
+                const uint64_t first = g < g0 ? g0 : g, last = g + kFillPer < g1 ? g + kFillPer : g1;
+                {   // the sequence that holds the first element: largest j with opos[j] <= e
                     const uint32_t e = static_cast<uint32_t>(first - obase);
                     uint32_t hi = n_here;
                     while (hi - lo > 1) {
@@ -2418,30 +2422,71 @@ __global__ __launch_bounds__(256) void k_pj_fill(const SeqBlock *__restrict__ bl
                             hi = mid;
                     }
                 }
+                // that sequence and the three behind it, in registers (indices past the batch repeat its last sequence: the
+                // boundary in front of them is the batch's end, which no element of the step reaches)
+                uint32_t so[4], sl[4], sf[4], sp[4], nb[4];
 #pragma unroll
-                for (uint32_t k = 0; k < 4; k++) {
+                for (uint32_t i = 0; i < 4; i++) {
+                    const uint32_t j = lo + i < n_here ? lo + i : n_here - 1;
+                    so[i] = s_opos[j];
+                    sl[i] = s_ll[j];
+                    sf[i] = s_off[j];
+                    sp[i] = s_lpos[j];
+                    nb[i] = s_opos[lo + i + 1 < n_here ? lo + i + 1 : n_here];
+                }
+                const bool simple = static_cast<uint32_t>(last - 1 - obase) < nb[3] || lo + 4 >= n_here;   // the step's elements lie in those four
+                uint32_t litpos[kFillPer];                                                                 // literal-buffer index of an element, ~0: not a literal
+#pragma unroll
+                for (uint32_t k = 0; k < kFillPer; k++) {
                     const uint64_t ge = g + k;
                     w[k] = 0;
-                    if (ge < g0 || ge >= g1) continue;
+                    litpos[k] = 0xFFFFFFFFu;
+                    if (ge < first || ge >= last) continue;
                     const uint32_t e = static_cast<uint32_t>(ge - obase);
-                    while (lo + 1 < n_here && s_opos[lo + 1] <= e) lo++;   // (sequences without output are stepped over)
-                    const uint32_t r = e - s_opos[lo], ll = s_ll[lo];
+                    uint32_t o, ll, off, lp;
+                    if (simple) {
+                        const uint32_t i = (e >= nb[0] ? 1u : 0u) + (e >= nb[1] ? 1u : 0u) + (e >= nb[2] ? 1u : 0u);
+                        o = i == 0 ? so[0] : (i == 1 ? so[1] : (i == 2 ? so[2] : so[3]));
+                        ll = i == 0 ? sl[0] : (i == 1 ? sl[1] : (i == 2 ? sl[2] : sl[3]));
+                        off = i == 0 ? sf[0] : (i == 1 ? sf[1] : (i == 2 ? sf[2] : sf[3]));
+                        lp = i == 0 ? sp[0] : (i == 1 ? sp[1] : (i == 2 ? sp[2] : sp[3]));
+                    } else {                               // (more than four sequences in the step: very short ones)
+                        while (lo + 1 < n_here && s_opos[lo + 1] <= e) lo++;
+                        o = s_opos[lo];
+                        ll = s_ll[lo];
+                        off = s_off[lo];
+                        lp = s_lpos[lo];
+                    }
+                    const uint32_t r = e - o;
                     if (r < ll) {
-                        w[k] = has_lit ? lit_word(blit[s_lpos[lo] + r]) : 0u;
+                        litpos[k] = lp + r;
                     } else {
-                        const uint32_t kk = r - ll, off = s_off[lo];
+                        const uint32_t kk = r - ll;
                         // element kk of a match at distance off copies element kk - off; where the match reaches into itself
                         // (off <= kk: a run) that is an element of the same match, and so on down to the `off` elements in
                         // front of it -- point there at once instead of leaving kk / off hops to the sweeps
-                        w[k] = kk < off ? off : off * (kk / off + 1u);
+                        w[k] = off;
+                        if (kk >= off) w[k] = off * (kk / off + 1u);
                     }
                 }
-                if (g >= a0 && g + 4 <= g1) {
-                    *reinterpret_cast<uint4 *>(D + g) = make_uint4(w[0], w[1], w[2], w[3]);
-                } else {
+                if (has_lit) {                             // all literal bytes of the step on their way together
+                    uint8_t c[kFillPer];
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; k++)
-                        if (g + k >= g0 && g + k < g1) D[g + k] = w[k];
+                    for (uint32_t k = 0; k < kFillPer; k++) c[k] = litpos[k] != 0xFFFFFFFFu ? blit[litpos[k]] : 0;
+#pragma unroll
+                    for (uint32_t k = 0; k < kFillPer; k++)
+                        if (litpos[k] != 0xFFFFFFFFu) w[k] = lit_word(c[k]);
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < kFillPer / 4; q++) {
+                    const uint64_t gq = g + 4 * q;
+                    if (gq >= a0 && gq + 4 <= g1) {
+                        *reinterpret_cast<uint4 *>(D + gq) = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+                    } else {
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++)
+                            if (gq + k >= g0 && gq + k < g1) D[gq + k] = w[4 * q + k];
+                    }
                 }
             }
             out_end = e1;

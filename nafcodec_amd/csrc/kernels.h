@@ -125,7 +125,8 @@ struct LzArgs {
     uint32_t n_sel_blocks;       // blocks of the loaded selection (blk_base[n_sel_blocks] = its elements)
     uint64_t halo_wait;          // phase 1 / 2: elements of the pseudo block in front
     uint64_t tail_elems;         // phase 1: the next shard waits for the last this-many elements
-    uint32_t strips;             // dense: the sweeps go strip-wise (k_pj_sweep<., kPjWin>): shallow chains
+    uint32_t strips;             // dense: the sweeps go strip-wise (k_pj_sweep<., kPjWin>): shallow chains, matches from near by
+    uint32_t shallow;            // dense: chains are shallow (a tenth of the elements or more are literals): the FIRST sweep already lists what it leaves pending
 };
 uint64_t lz_pj_tiles(uint64_t n_elems);
 // The repeat-offset map of a whole run of blocks (shard protocol): what the three offsets behind the last block are in

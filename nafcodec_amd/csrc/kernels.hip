@@ -2522,12 +2522,19 @@ struct PjLister {                                          // (LDS state of one 
 };
 // hands the gathered entries to the list when there are `limit` of them or more (limit 1: whatever there is)
 template <uint32_t N>
-__device__ inline void pj_list_flush(PjLister<N> *L, uint32_t *list_out, unsigned long long *len, uint64_t cap, uint32_t limit) {
+__device__ inline void pj_list_flush(PjLister<N> *L, uint32_t *list_out, unsigned long long *len, uint64_t cap, uint32_t limit,
+                                     unsigned long long *overflow = nullptr) {
     // called by every thread of the workgroup with uniform arguments, at a point where L->n is stable
+    // (overflow: set when the list does not hold what is handed to it -- a list begun by the FIRST sweep, which cannot know
+    //  how much it will leave pending; whoever reads the list afterwards then goes on sweeping instead)
     __syncthreads();
     const uint32_t n = L->n;
     if (n >= limit && n) {
-        if (threadIdx.x == 0) L->base = static_cast<uint32_t>(atomicAdd(len, static_cast<unsigned long long>(n)));
+        if (threadIdx.x == 0) {
+            const unsigned long long at = atomicAdd(len, static_cast<unsigned long long>(n));
+            L->base = static_cast<uint32_t>(at);
+            if (overflow && at + n > cap) *overflow = 1;
+        }
         __syncthreads();
         const uint64_t base = L->base;
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
@@ -2549,7 +2556,7 @@ __device__ inline void pj_list_flush(PjLister<N> *L, uint32_t *list_out, unsigne
 template <bool ASCII, uint32_t WIN>
 __global__ __launch_bounds__(256, WIN ? 5 : 6) void k_pj_sweep(uint32_t *D, uint8_t *out_bytes, uint32_t *tile_pending, unsigned long long *pcount,
                                                   uint64_t n_elems, uint32_t sweep, uint32_t max_dist, uint32_t *list_out,
-                                                  uint64_t list_cap, unsigned long long *lstate, const uint32_t *status) {
+                                                  uint64_t list_cap, unsigned long long *lstate, uint32_t first_list, const uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
     constexpr uint32_t kSlots = WIN + 1;
@@ -2560,17 +2567,29 @@ __global__ __launch_bounds__(256, WIN ? 5 : 6) void k_pj_sweep(uint32_t *D, uint
     const uint32_t tid = threadIdx.x;
     // pcount[s % 3] = elements still pending after sweep s (pcount[0] != 0 before the first one)
     const unsigned long long before = pcount[(sweep + 2u) % 3u];
-    const unsigned long long listing = lstate[3];
+    // lstate[3]: listing since sweep ...; lstate[4]: that list overflowed (it was begun by the first sweep) -- then nobody
+    // lists, the sweeps go on, and a later one begins a new list once it knows that what is pending fits
+    const unsigned long long listing = lstate[4] != 0 ? 0ull : lstate[3];
     if (listing != 0 && listing < sweep) return;           // k_pj_list's turn (it keeps the counters from here on)
-    // (listing == sweep: workgroup 0 of THIS launch has set it already.  Sweep 1 starts from a placeholder count.)
-    const bool build = list_out != nullptr && sweep >= 2 && before != 0 && before * 3 < n_elems && before <= list_cap && status[0] == 0;
+    // (listing == sweep: workgroup 0 of THIS launch has set it already.  Sweep 1 starts from a placeholder count: it
+    //  lists only when the host expects little to be left -- first_list -- and the overflow flag covers the rest.)
+    const bool build = list_out != nullptr && status[0] == 0 &&
+                       (sweep >= 2 ? (before != 0 && before * 3 < n_elems && before <= list_cap) : first_list != 0);
     if (blockIdx.x == 0 && tid == 0) {
         pcount[(sweep + 1u) % 3u] = 0;
         lstate[(sweep + 1u) % 3u] = 0;
         if (before == 0 || status[0] != 0) pcount[sweep % 3u] = 0;
+        if (lstate[4] != 0) {                              // (the order matters to the workgroups that read both words meanwhile)
+            lstate[3] = 0;
+            __threadfence();
+            lstate[4] = 0;
+        }
         if (build) lstate[3] = sweep;                      // (read by the kernels launched after this one)
     }
     if (before == 0 || status[0] != 0) return;
+    // (a list begun by the first sweep is worth having only when it is short -- an eighth of the elements: a pass over a list
+    //  is two gathers per entry, a tile-wise sweep reads its tiles in order -- beyond that it counts as overflowed)
+    const uint64_t cap_now = sweep >= 2 ? list_cap : (n_elems / 8 < list_cap ? n_elems / 8 : list_cap);
     if (tid == 0) s_list.n = 0;
     if (tid < 3) s_cnt[tid] = 0;
     if (tid < kSlots) s_held[tid] = ~0ull;
@@ -2741,7 +2760,7 @@ __global__ __launch_bounds__(256, WIN ? 5 : 6) void k_pj_sweep(uint32_t *D, uint
         }
         if (build) {                                       // (uniform) the tile's survivors join the list
             const uint32_t c = s_cnt[flip];                // (stable: thread 0 reset the OTHER counters only)
-            pj_list_flush(&s_list, list_out, &lstate[sweep % 3u], list_cap, s_list.n + c > kPjBatch ? 1u : kPjBatch);
+            pj_list_flush(&s_list, list_out, &lstate[sweep % 3u], cap_now, s_list.n + c > kPjBatch ? 1u : kPjBatch, &lstate[4]);
             if (remaining) {
                 uint32_t slot_l = atomicAdd(&s_list.n, remaining);
 #pragma unroll
@@ -2751,7 +2770,7 @@ __global__ __launch_bounds__(256, WIN ? 5 : 6) void k_pj_sweep(uint32_t *D, uint
         }
         flip = (flip + 1u) % 3u;
     }
-    if (build) pj_list_flush(&s_list, list_out, &lstate[sweep % 3u], list_cap, 1u);
+    if (build) pj_list_flush(&s_list, list_out, &lstate[sweep % 3u], cap_now, 1u, &lstate[4]);
     // (one addition per workgroup, not per tile: 700 k additions to one word serialise)
     if (tid == 0 && wg_pending) atomicAdd(&pcount[sweep % 3u], wg_pending);
 }
@@ -2765,8 +2784,8 @@ __global__ __launch_bounds__(256) void k_pj_list(uint32_t *D, uint8_t *out_bytes
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
     __shared__ PjLister<kPjBatch + 256> s_list;
     const uint32_t tid = threadIdx.x;
-    const unsigned long long listing = lstate[3];
-    if (listing == 0 || sweep <= listing) return;          // still sweeping / the sweep that made the first list
+    const unsigned long long listing = lstate[4] != 0 ? 0ull : lstate[3];
+    if (listing == 0 || sweep <= listing) return;          // still sweeping (or the list overflowed) / the sweep that made the first list
     const unsigned long long before = pcount[(sweep + 2u) % 3u];
     unsigned long long n_in = lstate[(sweep + 2u) % 3u];
     if (n_in > list_cap) n_in = list_cap;
@@ -2821,7 +2840,7 @@ __global__ __launch_bounds__(256) void k_pj_emit(const uint32_t *__restrict__ D,
     if (status[0] != 0) return;
     // (a shard's finishing passes: when they all ran from the list -- list mode since a sweep <= skip_max, before they began --
     //  they wrote the output themselves)
-    if (skip_if && *skip_if != 0 && *skip_if <= skip_max) return;
+    if (skip_if && skip_if[0] != 0 && skip_if[1] == 0 && skip_if[0] <= skip_max) return;   // ([1]: that list overflowed -- nobody used it)
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256 * 4;
     for (uint64_t p = (static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x) * 4; p < n_elems; p += stride) {
         if (n_elems - p >= 4) {
@@ -2873,7 +2892,7 @@ __global__ __launch_bounds__(256) void k_pj_tail_check(const uint32_t *list, con
     if (pcount[last_sweep % 3u] == 0) return;              // nothing pending at all
     bool hit = false;
     const uint64_t me = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x, stride = static_cast<uint64_t>(gridDim.x) * 256;
-    if (lstate[3] != 0) {
+    if (lstate[3] != 0 && lstate[4] == 0) {
         unsigned long long n = lstate[last_sweep % 3u];
         if (n > list_cap) n = list_cap;
         for (uint64_t i = me; i < n; i += stride) hit = hit || list[i] >= tail_lo;
@@ -3522,7 +3541,7 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
             // (every word of D is written by k_pj_fill: no memset in front)
             hipLaunchKernelGGL(k_pj_fill<ASCII>, dim3(grid), dim3(256), 0, stream, a.blocks, a.n_blocks, a.seqs, a.rep_init, a.blk_base,
                                a.pj_dist, a.lit, a.blk_pending, a.t_char, a.n_sel_blocks, a.n_elems, wait ? a.halo_wait : uint64_t(0), a.status);
-            (void)hipMemsetAsync(lstate, 0, 4 * sizeof(unsigned long long), stream);
+            (void)hipMemsetAsync(lstate, 0, 5 * sizeof(unsigned long long), stream);
         } else {
             // the window is in the output buffer now: its elements become final words, and a few more sweeps -- chains were
             // jumped down to their first element inside the window while it was away -- finish what waited for them
@@ -3537,11 +3556,11 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
             if (a.strips && sweep <= kPjStripSweeps)
                 hipLaunchKernelGGL((k_pj_sweep<ASCII, kPjWin>), dim3(static_cast<uint32_t>(strips)), dim3(256), 0, stream, a.pj_dist, a.out,
                                    a.pj_tiles, pcount, a.n_elems, sweep, max_dist, can_list ? lists[sweep & 1u] : nullptr, a.pj_list_cap, lstate,
-                                   a.status);
+                                   a.shallow, a.status);
             else
                 hipLaunchKernelGGL((k_pj_sweep<ASCII, 0u>), dim3(static_cast<uint32_t>(tiles)), dim3(256), 0, stream, a.pj_dist, a.out,
                                    a.pj_tiles, pcount, a.n_elems, sweep, max_dist, can_list ? lists[sweep & 1u] : nullptr, a.pj_list_cap,
-                                   lstate, a.status);
+                                   lstate, a.shallow, a.status);
             if (can_list && sweep >= 2)
                 hipLaunchKernelGGL(k_pj_list<ASCII>, dim3(list_grid), dim3(256), 0, stream, a.pj_dist, a.out, pcount,
                                    lists[(sweep & 1u) ^ 1u], lists[sweep & 1u], a.pj_list_cap, lstate, sweep, max_dist, finish ? 1u : 0u, a.status);

@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument("--real-copies-per-gpu", type=int, default=1000,
                     help="N>1: the real-genome archive (WITH LZ sequences) holds this many tiles per GPU, ONE archive decoded through the "
                          "shard protocol and reported as path.real_genome; 0 skips it")
+    ap.add_argument("--sharded-leg-limit", type=int, default=300,
+                    help="N>1: seconds the path.real_genome leg may take before the line is printed without it")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--rehearsal-one-gpu", action="store_true",
                     help="tests only: several ranks (gloo) share GPU 0 -- the sharded flow with the real library on a one-GPU box; "
@@ -608,9 +610,7 @@ def main():
         if not ok:
             raise RuntimeError("rank %d: decoded bases / offsets differ from the writer's checksums" % rank)
 
-    real_sharded = None
-    if world > 1 and args.real_copies_per_gpu:               # sections WITH LZ sequences over the same ranks (every rank takes part)
-        real_sharded = real_genome_sharded_leg(lib, dist, torch, tdev, device, rank, world, args.real_copies_per_gpu)
+    line = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = total_bases * args.steps / elapsed / 1e9
@@ -669,8 +669,6 @@ def main():
             finally:
                 if os.path.exists(ipath):
                     os.unlink(ipath)
-        if real_sharded is not None:
-            line["path"]["real_genome"] = real_sharded
         if not args.no_cpu and world == 1:       # reported baseline, rank 0 at N=1 only
             line["cpu_baseline"], checked = cpu_baseline(lib, args.cpu_sample_bases, args.mask, device)
             line["config"]["oracle_checked_bases"] = checked
@@ -680,6 +678,37 @@ def main():
         if args.rehearsal_lib:                   # control-flow rehearsal on the CPU harness: never a measurement
             line.update({"metric": "REHEARSAL on %s -- not a measurement" % os.path.basename(args.rehearsal_lib),
                          "value": None, "roofline": None})
+
+    def cleanup_shared():
+        if rank == 0 and world > 1 and shared_path and os.path.exists(shared_path):
+            os.unlink(shared_path)
+
+    if world > 1 and args.real_copies_per_gpu:
+        # sections WITH LZ sequences over the same ranks (every rank takes part).  The headline above is already measured: a
+        # rank that fails or stalls in this leg must not take the line with it, so the leg runs under a per-rank time limit,
+        # after which rank 0 prints the line with the failure named in it and every rank leaves.
+        import threading
+
+        def leave(reason):
+            if rank == 0:
+                line["path"]["real_genome"] = {"error": reason}
+                print(json.dumps(line), flush=True)
+            cleanup_shared()
+            os._exit(0)
+
+        limit = threading.Timer(args.sharded_leg_limit, leave, ["sharded real-genome leg not finished after %d s" % args.sharded_leg_limit])
+        limit.daemon = True
+        limit.start()
+        try:
+            real_sharded = real_genome_sharded_leg(lib, dist, torch, tdev, device, rank, world, args.real_copies_per_gpu)
+            dist.barrier()
+        except Exception as e:                         # the other ranks leave when their own limit runs out
+            limit.cancel()
+            leave("rank %d: %s: %s" % (rank, type(e).__name__, e))
+        limit.cancel()
+        if rank == 0:
+            line["path"]["real_genome"] = real_sharded
+    if rank == 0:
         print(json.dumps(line), flush=True)
 
     lib.c.nafgpu_close(h)
@@ -687,8 +716,7 @@ def main():
         lib.c.nafgpu_synth_free(ctypes.byref(arc))
     if world > 1:
         dist.barrier()
-        if rank == 0 and shared_path and os.path.exists(shared_path):
-            os.unlink(shared_path)
+        cleanup_shared()
         dist.destroy_process_group()
 
 

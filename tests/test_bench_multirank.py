@@ -57,6 +57,26 @@ def test_bench_contract(world):
     assert "passed" in j["config"]["workload"]  # the full-size checksum check ran and held on every rank
 
 
+def test_headline_line_survives_a_sharded_leg_that_does_not_finish():
+    """The second workload of the multi-rank run has a time limit of its own: when it runs out every rank leaves, and rank 0
+    still prints the one line -- with the headline in it and the failure named where the leg's numbers would be."""
+    if not zstd_ref.available():
+        pytest.skip("libzstd not loadable")
+    csrc = os.path.join(ROOT, "nafcodec_amd", "csrc")
+    subprocess.check_call(["make", "-s", "-C", csrc, "emu"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--bases", "300001", "--real-copies-per-gpu", "1", "--sharded-leg-limit", "0",
+           "--rehearsal-lib", os.path.join(ROOT, "tests", "emu", "_build", "libnafgpu_emu.so")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and "passed" in j["config"]["workload"]
+    assert "not finished" in j["path"]["real_genome"]["error"]
+
+
 def test_real_genome_leg_runs_and_checks_itself():
     """bench.py's second workload (path.real_genome): the reference's NZ_AAEN01000029 fixture tiled and recompressed by
     libzstd, decoded by the library it is given (here the CPU harness), compared with the tiled fixture."""

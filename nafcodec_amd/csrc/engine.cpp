@@ -48,24 +48,82 @@ bool DevBuf::alloc_items(uint64_t count, uint64_t item_bytes, uint64_t extra_byt
     return alloc(static_cast<size_t>(count * item_bytes + extra_bytes));
 }
 
+#ifndef NAFGPU_EMU
+namespace {
+// Large buffers come from the virtual-memory API: an address range backed by hipMemCreate chunks of up to 1 GiB.  Why: memory
+// from one large hipMalloc writes at 4.9-6.7 TB/s depending on the allocation (the same virtual address after a hipFree can
+// land on either side; tools/frontbench4.hip, profiles/r03_frontbench4.log -- a plain streaming fill shows it as well as
+// K1's 610 k write fronts), which is what made K1 take 10.7-11.9 ms on the same archive.  Chunked backing gave 6.7 TB/s in
+// nine allocations out of nine, whatever the chunk size (2 MiB, 64 MiB, 1 GiB).
+constexpr size_t kVmmMinBytes = size_t(32) << 20, kVmmChunk = size_t(1) << 30;
+
+bool vmm_usable(int dev, size_t *gran) {
+    int ok = 0;
+    if (!hip_ok(hipDeviceGetAttribute(&ok, hipDeviceAttributeVirtualMemoryManagementSupported, dev)) || !ok) return false;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    return hip_ok(hipMemGetAllocationGranularity(gran, &prop, hipMemAllocationGranularityRecommended)) && *gran &&
+           kVmmChunk % *gran == 0;
+}
+}  // namespace
+
+bool DevBuf::alloc_mapped(size_t bytes) {
+    int dev = 0;
+    size_t gran = 0;
+    if (!hip_ok(hipGetDevice(&dev)) || !vmm_usable(dev, &gran)) return false;
+    const size_t total = (bytes + gran - 1) / gran * gran;
+    void *va = nullptr;
+    if (!hip_ok(hipMemAddressReserve(&va, total, gran, nullptr, 0)) || !va) return false;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t mapped = 0;
+    bool ok = true;
+    for (size_t off = 0; off < total && ok; off += kVmmChunk) {
+        const size_t n = total - off < kVmmChunk ? total - off : kVmmChunk;
+        hipMemGenericAllocationHandle_t h;
+        if (!hip_ok(hipMemCreate(&h, n, &prop, 0))) { ok = false; break; }
+        if (!hip_ok(hipMemMap(static_cast<char *>(va) + off, n, 0, h, 0))) {
+            (void)hipMemRelease(h);
+            ok = false;
+            break;
+        }
+        chunks_.push_back(h);
+        mapped = off + n;
+    }
+    if (ok) {
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        ok = hip_ok(hipMemSetAccess(va, total, &acc, 1));
+    }
+    if (!ok) {                                   // e.g. out of device memory: undo, the caller reports the failure of hipMalloc
+        if (mapped) (void)hipMemUnmap(va, mapped);
+        for (auto h : chunks_) (void)hipMemRelease(h);
+        chunks_.clear();
+        (void)hipMemAddressFree(va, total);
+        (void)hipGetLastError();
+        return false;
+    }
+    ptr_ = va;
+    size_ = bytes;
+    reserved_ = total;
+    return true;
+}
+#endif
+
 bool DevBuf::alloc(size_t bytes) {
     if (ptr_ && bytes <= size_) return true;
     release();
-    void *p = nullptr;
 #ifndef NAFGPU_EMU
-    // Experiment (nafgpu_test_hooks + NAFGPU_ALLOC_CONTIGUOUS=1, tools/placement_probe.sh): large buffers physically
-    // contiguous.  K1 runs 8 % slower for some placements of its 50 GB of buffers -- measured: this
-    // flag does not change that (10.7-11.9 ms over eight decoders either way), so it stays off.
-    const char *ce = hook_env("NAFGPU_ALLOC_CONTIGUOUS");
-    const bool contiguous = ce && ce[0] == '1';
-    if (contiguous && bytes >= (size_t(64) << 20) && hip_ok(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocContiguous)) && p) {
-        ptr_ = p;
-        size_ = bytes;
-        return true;
-    }
-    (void)hipGetLastError();
-    p = nullptr;
+    // (nafgpu_test_hooks + NAFGPU_ALLOC_PLAIN=1: everything from hipMalloc, for A/B runs -- tools/placement_probe.sh)
+    const char *plain = hook_env("NAFGPU_ALLOC_PLAIN");
+    if (bytes >= kVmmMinBytes && !(plain && plain[0] == '1') && alloc_mapped(bytes)) return true;
 #endif
+    void *p = nullptr;
     if (!hip_ok(hipMalloc(&p, bytes ? bytes : 16))) return false;
     ptr_ = p;
     size_ = bytes ? bytes : 16;
@@ -79,9 +137,18 @@ bool DevBuf::upload(const void *host, size_t bytes, hipStream_t stream) {
 }
 
 void DevBuf::release() {
+#ifndef NAFGPU_EMU
+    if (ptr_ && reserved_) {
+        (void)hipMemUnmap(ptr_, reserved_);
+        for (auto h : chunks_) (void)hipMemRelease(h);
+        chunks_.clear();
+        (void)hipMemAddressFree(ptr_, reserved_);
+        ptr_ = nullptr;
+    }
+#endif
     if (ptr_) (void)hipFree(ptr_);
     ptr_ = nullptr;
-    size_ = 0;
+    size_ = reserved_ = 0;
 }
 
 // ------------------------------------------------------------------ StageTimer

@@ -1,6 +1,6 @@
 // engine.h -- device-side orchestration: buffers in HBM, kernel sequence per section, timing.
 //
-// Data layout in HBM (all hipMalloc'ed, 256-byte aligned, sized for a 288 GB device):
+// Data layout in HBM (hipMalloc'ed, from 32 MiB on address ranges backed by hipMemCreate chunks; 256-byte aligned, sized for a 288 GB device):
 //   archive   [256 B pad][archive bytes][64 B pad]      compressed input, uploaded once
 //   per zstd section:
 //     out       decoded bytes (packed 4-bit for DNA/RNA sequence, text otherwise)
@@ -41,8 +41,12 @@ public:
     size_t size() const { return size_; }
 
 private:
+    bool alloc_mapped(size_t bytes);          // an address range backed by hipMemCreate chunks (engine.cpp: why)
     void *ptr_ = nullptr;
-    size_t size_ = 0;
+    size_t size_ = 0, reserved_ = 0;          // reserved_ != 0: ptr_ is such a range
+#ifndef NAFGPU_EMU
+    std::vector<hipMemGenericAllocationHandle_t> chunks_;
+#endif
 };
 
 struct StageTimes {          // milliseconds, summed over launches of the last run

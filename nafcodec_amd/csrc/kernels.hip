@@ -285,6 +285,7 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     // one table look-up on the next bits of the stream; rare long codes take a second, sub-table look-up
     // (tasks none of whose trees is deeper than W bits -- the common case -- run a copy of the loop without the test)
     const bool task_esc = __any(esc_bits != 0 ? 1 : 0) != 0;
+    const bool narrow_task = !__any((have && W > 8u) ? 1 : 0);     // no look-up of the task takes more than 8 bits (pack_tasks: W is 6 .. 8)
     auto lookup = [&](auto esc) -> HufLook {
         const uint32_t peek = __builtin_amdgcn_alignbit(L.hi, L.lo, L.s);
         if (TBL == kTblBaked) {
@@ -592,7 +593,36 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         // (wave-wide votes stay outside divergent code: every lane of the wave takes part)
         const bool dword_round = ASCII && TBL == kTblBaked && all_pairs &&
                                  !__any((pos < end_abs && (static_cast<uint32_t>(wa - orow) & 2u)) ? 1 : 0);
-        if (pos + 32 * kOutB <= end_abs) {                 // 16 look-ups cannot overrun the stream (segment)
+        if (pos + 32 * kOutB <= end_abs && !decltype(esc)::value && narrow_task) {
+            // Four look-ups off ONE peek.  The 32 bits under the cursor serve four look-ups of <= 8 bits each: the next
+            // index is the peek shifted left by what the entry consumed, and the bit window moves once per group, by the
+            // sum -- a borrow still means "one word on" (the sum is <= 32).  Per look-up: a shift, an address, the table
+            // read, the store and a quarter of an advance -- 6 vector instructions where a look-up with its own advance
+            // takes 13, and the chain from one table read to the next is two instructions long instead of ten.
+            auto group4 = [&](auto dword) {
+                uint32_t p = __builtin_amdgcn_alignbit(L.hi, L.lo, L.s), tot = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint2 e = tbl[p >> sh];
+                    if (decltype(dword)::value) {
+                        *reinterpret_cast<uint32_t *>(wa) = e.x;
+                        wa += 4;
+                    } else {
+                        put_adv(e.x, 1u + ((e.y >> 24) & 1u));
+                    }
+                    p <<= (e.y & 31u);
+                    tot += e.y;                            // (the fields above the low byte do not reach into it)
+                }
+                huf_advance(L, s_ring, tot & 0xFFu);
+            };
+            if (dword_round) {
+#pragma unroll
+                for (uint32_t g = 0; g < 4; g++) group4(std::true_type{});
+            } else {
+#pragma unroll
+                for (uint32_t g = 0; g < 4; g++) group4(std::false_type{});
+            }
+        } else if (pos + 32 * kOutB <= end_abs) {          // 16 look-ups cannot overrun the stream (segment)
             if (dword_round) {
                 // every entry of the task's table holds two symbols (codes of 4 bits or less: uniform ACGT) and every
                 // lane stands on a dword boundary: each look-up is one aligned 4-byte store, nothing to carry
@@ -694,10 +724,35 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
             const uint32_t x = (kAblate & 32u) ? c : (*a1 | (*a2 << 16));
             put_adv(x, c & 3u);
         };
+        // ... off ONE peek where no look-up takes more than 8 bits (see group4 above): the index of the next entry is the peek
+        // shifted left by what this one consumed, the bit window moves once per group
+        auto gstep = [&](uint32_t &p, uint32_t &tot, bool fetch) {
+            const uint32_t c = r;
+            const uint32_t *a1 = reinterpret_cast<const uint32_t *>(dict_bytes + (c & 0xFCu));
+            const uint32_t *a2 = reinterpret_cast<const uint32_t *>(dict_bytes + ((c >> 6) & 0x3Cu));
+            p <<= ((c >> 12) & 31u);
+            tot += c >> 12;
+            if (fetch) r = tbl2[p >> sh];
+            put_adv(*a1 | (*a2 << 16), c & 3u);
+        };
 #pragma unroll
         for (uint32_t g = 0; g < 4; g++) {
             const uint32_t pos = rbase + static_cast<uint32_t>(wa - orow);
-            if (pos + 8 * kOutB <= end_abs) {              // four look-ups cannot overrun the stream (segment)
+            if (pos + 8 * kOutB <= end_abs && narrow_task) {
+                uint32_t p, tot = 0;
+                if (task_esc && (r & 3u) == 0) {           // (an escape entry: 0 bits -- the lane stood still on it since it met it)
+                    resolve_escape();
+                    p = __builtin_amdgcn_alignbit(L.hi, L.lo, L.s);
+                } else {
+                    p = __builtin_amdgcn_alignbit(L.hi, L.lo, L.s);
+                    gstep(p, tot, true);
+                }
+                gstep(p, tot, true);
+                gstep(p, tot, true);
+                gstep(p, tot, false);
+                huf_advance(L, s_ring, tot);
+                r = dict_fetch();
+            } else if (pos + 8 * kOutB <= end_abs) {       // four look-ups cannot overrun the stream (segment)
                 if (task_esc && (r & 3u) == 0)
                     resolve_escape();
                 else

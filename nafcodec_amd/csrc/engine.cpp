@@ -74,6 +74,11 @@ bool DevBuf::alloc_mapped(size_t bytes) {
     size_t gran = 0;
     if (!hip_ok(hipGetDevice(&dev)) || !vmm_usable(dev, &gran)) return false;
     const size_t total = (bytes + gran - 1) / gran * gran;
+    size_t chunk = kVmmChunk;
+    if (const char *ce = hook_env("NAFGPU_VMM_CHUNK_MIB")) {        // (experiments: tools/placement_probe.sh)
+        const size_t want = static_cast<size_t>(std::strtoull(ce, nullptr, 10)) << 20;
+        if (want >= gran && want % gran == 0) chunk = want;
+    }
     void *va = nullptr;
     if (!hip_ok(hipMemAddressReserve(&va, total, gran, nullptr, 0)) || !va) return false;
     hipMemAllocationProp prop = {};
@@ -82,8 +87,8 @@ bool DevBuf::alloc_mapped(size_t bytes) {
     prop.location.id = dev;
     size_t mapped = 0;
     bool ok = true;
-    for (size_t off = 0; off < total && ok; off += kVmmChunk) {
-        const size_t n = total - off < kVmmChunk ? total - off : kVmmChunk;
+    for (size_t off = 0; off < total && ok; off += chunk) {
+        const size_t n = total - off < chunk ? total - off : chunk;
         hipMemGenericAllocationHandle_t h;
         if (!hip_ok(hipMemCreate(&h, n, &prop, 0))) { ok = false; break; }
         if (!hip_ok(hipMemMap(static_cast<char *>(va) + off, n, 0, h, 0))) {

@@ -149,6 +149,33 @@ def test_synthetic_archive(lib, n_bases, mask, iupac):
         lib.c.nafgpu_synth_free(ctypes.byref(arc))
 
 
+def test_large_buffers_from_plain_hipmalloc_and_from_mapped_chunks(lib, monkeypatch):
+    """DevBuf takes buffers of 32 MiB and more from the virtual-memory API (an address range backed by hipMemCreate chunks, engine.cpp);
+    NAFGPU_ALLOC_PLAIN=1 keeps everything on hipMalloc, NAFGPU_VMM_CHUNK_MIB changes the chunk size: the same archive decodes to
+    the same checksums on all of them, twice per decoder (the second call reuses the buffers), and the buffers go away with the
+    decoder (a loop of decoders would run out of device memory otherwise)."""
+    import nafcodec_amd
+    lib.c.nafgpu_test_hooks(1)
+    arc = lib.synth(400_000_001, seed=77, with_mask=True, iupac_permille=0)     # 100 MB of input, 400 MB of output
+    try:
+        blob = ctypes.string_at(arc.bytes, arc.n)
+        for env in ({"NAFGPU_ALLOC_PLAIN": "1"}, {}, {"NAFGPU_VMM_CHUNK_MIB": "2"}, {"NAFGPU_VMM_CHUNK_MIB": "64"}):
+            for k in ("NAFGPU_ALLOC_PLAIN", "NAFGPU_VMM_CHUNK_MIB"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            for _ in range(3):
+                dec = nafcodec_amd.Decoder(io.BytesIO(blob))
+                for _ in range(2):
+                    res = dec.decode_all_device()
+                    assert (res.n_bases, res.n_records) == (arc.n_bases, arc.n_records), env
+                    assert dec.hash_device(res.d_sequence, res.n_bases) == arc.seq_hash, env
+                    assert dec.hash_device(res.d_record_end, 8 * res.n_records) == arc.offsets_hash, env
+                dec.close()
+    finally:
+        lib.c.nafgpu_synth_free(ctypes.byref(arc))
+
+
 def test_gigabase_archive_against_the_oracle(lib):
     """Full-size parity pinned on the ORACLE, not on the writer: a 1.2 Gbase synthetic archive (with a Mask
     section) is drained by the CPU oracle in C, which accumulates the position-keyed checksum of the

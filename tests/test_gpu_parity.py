@@ -4,13 +4,15 @@
 Bar: bit-exact (integer / byte work only on this path)."""
 import ctypes
 import io
+import os
+import sys
 
 import numpy as np
 import pytest
 
 import cases
 import zstd_ref
-from conftest import golden_bytes
+from conftest import ROOT, golden_bytes
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -174,6 +176,24 @@ def test_large_buffers_from_plain_hipmalloc_and_from_mapped_chunks(lib, monkeypa
                 dec.close()
     finally:
         lib.c.nafgpu_synth_free(ctypes.byref(arc))
+
+
+def test_real_genome_archive_with_a_few_plain_tasks_beside_many_segmented_ones(lib, capfd, monkeypatch):
+    """The reference fixture's sequence tiled 40 times and recompressed by libzstd (bench.py's path.real_genome in small): 838 blocks
+    with a Huffman tree each, most with a few LZ sequences -- about fifty K1 tasks whose streams are cut into segments by their
+    blocks' sequences and a task or two without.  pack_tasks lets those join the segment-aware class (zplan.cpp); the output must
+    still be the tiled fixture, and the plan must show no class of the dictionary format that writes the output without segments."""
+    if not zstd_ref.available():
+        pytest.skip("libzstd not loadable")
+    sys.path.insert(0, ROOT)
+    import bench
+    lib.c.nafgpu_test_hooks(1)
+    monkeypatch.setenv("NAFGPU_DEBUG_PLAN", "1")
+    leg = bench.real_genome_leg(lib, 0, 40)
+    assert leg["bases"] == 40 * 5488676 and "output checksum equals the tiled fixture" in leg["workload"]
+    plans = [l for l in capfd.readouterr().err.splitlines() if "task classes" in l and "out+seg" in l]
+    assert plans, "no plan with a segment-aware class was printed"
+    assert all("tbl 2, out, " not in l for l in plans), plans[-1]
 
 
 def test_gigabase_archive_against_the_oracle(lib):

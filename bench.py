@@ -264,6 +264,27 @@ def iterator_leg(path, device):
                     "host walk + H2D + decode + every record's bytes D2H through the 64 MiB pinned window"}
 
 
+def fixtures_leg(device):
+    """The reference's own small archives (tests/golden = /root/reference/data: configs[0] LuxC.naf, configs[2] phix.naf, and the
+    5.5-Mbase NZ_AAEN01000029.naf) through the drop-in API in a warm process: open, every record, close -- the best of ten cycles in
+    ms per archive (nafcodec_amd/iter_bench).  Files this small measure fixed costs, not kernels."""
+    import subprocess
+    tool = os.path.join(ROOT, "nafcodec_amd", "iter_bench")
+    out = {}
+    for name in ("LuxC.naf", "phix.naf", "NZ_AAEN01000029.naf"):
+        path = os.path.join(ROOT, "tests", "golden", name)
+        if not (os.path.exists(tool) and os.path.exists(path)):
+            continue
+        p = subprocess.run([tool, path, str(device), "11"], capture_output=True, text=True, timeout=300)
+        if p.returncode != 0:
+            out[name] = {"error": p.stderr[-200:]}
+            continue
+        j = json.loads(p.stdout.strip().splitlines()[-1])
+        out[name] = {"records": j["records"], "bases": j["bases"], "ms_per_archive": round(j["best_cycle_ms"], 3),
+                     "first_in_process_ms": round(j["first_cycle_ms"], 1)}
+    return out or None
+
+
 def fastq_like_leg(lib, device, n_reads, level=1):
     """Third workload, FASTQ-shaped (configs[2] scaled up as SURVEY 8d allows): n_reads x 151 bases, iid ACGT + iid quality
     strings from a skewed 32-entry alphabet, Length + Sequence + Quality sections written by the system libzstd at `level` --
@@ -658,6 +679,7 @@ def main():
         if args.fastq_reads and world == 1 and not args.rehearsal_lib:
             line["path"]["fastq_like"] = fastq_like_leg(lib, device, int(args.fastq_reads))
         if not args.no_iterator and world == 1 and not args.rehearsal_lib:
+            line["path"]["fixtures"] = fixtures_leg(device)
             # the headline archive through the drop-in API: Decoder::from_path + Iterator::next (a file, as the reference reads one)
             import shutil
             import tempfile

@@ -5,6 +5,8 @@
 #include <cstdlib>
 
 #include <atomic>
+#include <map>
+#include <mutex>
 #include <chrono>
 #include <cstring>
 
@@ -120,8 +122,15 @@ bool DevBuf::alloc_mapped(size_t bytes) {
 }
 #endif
 
+void DevBuf::view(void *p, size_t bytes) {
+    release();
+    ptr_ = p;
+    size_ = bytes;
+    view_ = true;
+}
+
 bool DevBuf::alloc(size_t bytes) {
-    if (ptr_ && bytes <= size_) return true;
+    if (ptr_ && !view_ && bytes <= size_) return true;
     release();
 #ifndef NAFGPU_EMU
     // (nafgpu_test_hooks + NAFGPU_ALLOC_PLAIN=1: everything from hipMalloc, for A/B runs -- tools/placement_probe.sh)
@@ -142,6 +151,12 @@ bool DevBuf::upload(const void *host, size_t bytes, hipStream_t stream) {
 }
 
 void DevBuf::release() {
+    if (view_) {
+        ptr_ = nullptr;
+        size_ = 0;
+        view_ = false;
+        return;
+    }
 #ifndef NAFGPU_EMU
     if (ptr_ && reserved_) {
         (void)hipMemUnmap(ptr_, reserved_);
@@ -394,30 +409,73 @@ Failure SectionJob::load_tile(uint32_t t, hipStream_t stream) {
     // ---- the compressed bytes the tile's tasks read, with the padding k_huf_decode's whole-line loads may touch
     const uint64_t src_n = plan_.src_hi - plan_.src_lo;
     src_resident_ = src_n;
-    bool ok = d_src_buf_.alloc(kSrcFrontPad + static_cast<size_t>(src_n) + kSrcBackPad);
-    if (ok) {
-        (void)hipMemsetAsync(d_src_buf_.bytes(), 0, kSrcFrontPad, stream);
-        (void)hipMemsetAsync(d_src_buf_.bytes() + kSrcFrontPad + src_n, 0, kSrcBackPad, stream);
-        if (src_n) ok = hip_ok(hipMemcpyAsync(d_src_buf_.bytes() + kSrcFrontPad, host_payload_ + plan_.src_lo, src_n, hipMemcpyHostToDevice, stream));
-        d_src_ = d_src_buf_.bytes() + kSrcFrontPad - plan_.src_lo;     // kernels address the payload by its offsets
+    // Small tiles (the reference's own fixtures, the text sections of most archives): the source bytes and the ten task lists
+    // travel as ONE buffer in ONE copy -- a dozen copies of a few hundred bytes each cost 24 us of host time apiece, a third of
+    // what a small archive took.  The lists are pieces of d_pack_ then (DevBuf::view).
+    struct Piece {
+        DevBuf *buf;
+        const void *src;
+        size_t n, front, back, off;
+    };
+    Piece pieces[] = {
+        {&d_src_buf_, host_payload_ + plan_.src_lo, static_cast<size_t>(src_n), kSrcFrontPad, kSrcBackPad, 0},
+        {&d_blk_size_, plan_.blk_size.data(), n_blocks_ * sizeof(uint32_t), 0, 0, 0},
+        {&d_streams_, plan_.streams.data(), n_streams_ * sizeof(HufStream), 0, 0, 0},
+        {&d_tasks_, plan_.tasks.data(), n_tasks_ * sizeof(HufTask), 0, 0, 0},
+        {&d_tbl_copies_, plan_.tbl_copies.data(), plan_.tbl_copies.size() * sizeof(HufTblCopy), 0, 0, 0},
+        {&d_pool_, plan_.huf_pool.data(), plan_.huf_pool.size() * sizeof(uint16_t), 0, 0, 0},
+        {&d_dicts_, plan_.dict_pool.data(), plan_.dict_pool.size(), 0, 0, 0},
+        {&d_copies_, plan_.copies.data(), n_copies_ * sizeof(CopyTask), 0, 0, 0},
+        {&d_seq_blocks_, plan_.seq_blocks.data(), n_seq_blocks_ * sizeof(SeqBlock), 0, 0, 0},
+        {&d_cells_, plan_.fse_pool.data(), plan_.fse_pool.size() * sizeof(SeqCell), 0, 0, 0},
+        {&d_xxh_segs_, xxh_segs_.data(), xxh_segs_.size() * sizeof(XxhSeg), 0, 0, 0},
+    };
+    size_t pack_total = 0;
+    for (Piece &pc : pieces) {
+        pc.off = pack_total;
+        pack_total += (pc.front + pc.n + pc.back + 16 + 255) & ~size_t(255);
     }
-    ok = ok && d_blk_size_.upload(plan_.blk_size.data(), n_blocks_ * sizeof(uint32_t), stream) &&
-         d_blk_base_.alloc((n_blocks_ + 1) * sizeof(uint64_t)) && d_scan_tmp_.alloc(scan_tmp_bytes(n_blocks_)) &&
-         d_streams_.upload(plan_.streams.data(), n_streams_ * sizeof(HufStream), stream) &&
-         d_tasks_.upload(plan_.tasks.data(), n_tasks_ * sizeof(HufTask), stream) &&
-         d_tbl_copies_.upload(plan_.tbl_copies.data(), plan_.tbl_copies.size() * sizeof(HufTblCopy), stream) &&
-         d_pool_.upload(plan_.huf_pool.data(), plan_.huf_pool.size() * sizeof(uint16_t), stream) &&
-         d_dicts_.upload(plan_.dict_pool.data(), plan_.dict_pool.size(), stream) &&
-         d_copies_.upload(plan_.copies.data(), n_copies_ * sizeof(CopyTask), stream) &&
-         d_seq_blocks_.upload(plan_.seq_blocks.data(), n_seq_blocks_ * sizeof(SeqBlock), stream) &&
-         d_cells_.upload(plan_.fse_pool.data(), plan_.fse_pool.size() * sizeof(SeqCell), stream) &&
+    // (up to 256 KiB: a larger copy out of ordinary heap memory takes the runtime's pin-the-pages path -- 17 ms for 1.4 MB measured --
+    // where the same bytes straight from the file mapping took 0.4)
+    constexpr size_t kPackMax = size_t(256) << 10;
+    bool ok = true;
+    if (pack_total <= kPackMax) {
+        pack_host_.assign(pack_total, 0);                      // (the padding around the source bytes is part of it)
+        for (const Piece &pc : pieces)
+            if (pc.n) std::memcpy(pack_host_.data() + pc.off + pc.front, pc.src, pc.n);
+        ok = d_pack_.alloc(pack_total) &&
+             hip_ok(hipMemcpyAsync(d_pack_.bytes(), pack_host_.data(), pack_total, hipMemcpyHostToDevice, stream));
+        if (ok)
+            for (const Piece &pc : pieces) pc.buf->view(d_pack_.bytes() + pc.off, pc.front + pc.n + pc.back);
+        d_src_ = d_src_buf_.bytes() + kSrcFrontPad - plan_.src_lo;         // kernels address the payload by its offsets
+        ok = ok && d_blk_base_.alloc((n_blocks_ + 1) * sizeof(uint64_t)) && d_scan_tmp_.alloc(scan_tmp_bytes(n_blocks_));
+    } else {
+        ok = d_src_buf_.alloc(kSrcFrontPad + static_cast<size_t>(src_n) + kSrcBackPad);
+        if (ok) {
+            (void)hipMemsetAsync(d_src_buf_.bytes(), 0, kSrcFrontPad, stream);
+            (void)hipMemsetAsync(d_src_buf_.bytes() + kSrcFrontPad + src_n, 0, kSrcBackPad, stream);
+            if (src_n) ok = hip_ok(hipMemcpyAsync(d_src_buf_.bytes() + kSrcFrontPad, host_payload_ + plan_.src_lo, src_n, hipMemcpyHostToDevice, stream));
+            d_src_ = d_src_buf_.bytes() + kSrcFrontPad - plan_.src_lo;     // kernels address the payload by its offsets
+        }
+        ok = ok && d_blk_size_.upload(plan_.blk_size.data(), n_blocks_ * sizeof(uint32_t), stream) &&
+             d_blk_base_.alloc((n_blocks_ + 1) * sizeof(uint64_t)) && d_scan_tmp_.alloc(scan_tmp_bytes(n_blocks_)) &&
+             d_streams_.upload(plan_.streams.data(), n_streams_ * sizeof(HufStream), stream) &&
+             d_tasks_.upload(plan_.tasks.data(), n_tasks_ * sizeof(HufTask), stream) &&
+             d_tbl_copies_.upload(plan_.tbl_copies.data(), plan_.tbl_copies.size() * sizeof(HufTblCopy), stream) &&
+             d_pool_.upload(plan_.huf_pool.data(), plan_.huf_pool.size() * sizeof(uint16_t), stream) &&
+             d_dicts_.upload(plan_.dict_pool.data(), plan_.dict_pool.size(), stream) &&
+             d_copies_.upload(plan_.copies.data(), n_copies_ * sizeof(CopyTask), stream) &&
+             d_seq_blocks_.upload(plan_.seq_blocks.data(), n_seq_blocks_ * sizeof(SeqBlock), stream) &&
+             d_cells_.upload(plan_.fse_pool.data(), plan_.fse_pool.size() * sizeof(SeqCell), stream) &&
+             d_xxh_segs_.upload(xxh_segs_.data(), xxh_segs_.size() * sizeof(XxhSeg), stream);
+    }
+    ok = ok &&
          d_lit_.alloc(static_cast<size_t>(plan_.lit_bytes) + 64) &&
          d_seqs_.alloc_items(plan_.n_sequences, sizeof(Seq), 16) &&
          d_meta_.alloc_items(plan_.n_sequences, sizeof(SeqMeta), 16) &&
          d_rep_final_.alloc(n_seq_blocks_ * 12 + 16) && d_rep_init_.alloc(n_seq_blocks_ * 12 + 16) &&
          d_rep_scratch_.alloc((n_seq_blocks_ / 64 + 1) * 24 + 16) &&
          d_blk_pending_.alloc(n_seq_blocks_ * 4 + 16) &&
-         d_xxh_segs_.upload(xxh_segs_.data(), xxh_segs_.size() * sizeof(XxhSeg), stream) &&
          (xxh_segs_.empty() || d_xxh_carry_.alloc(2 * sizeof(XxhCarry)));
     if (!ok) return Failure::make(NAFGPU_E_DEVICE, "out of device memory while preparing a section");
     // the host vectors were consumed by asynchronous copies: keep them until the stream drains
@@ -939,12 +997,60 @@ Failure SectionJob::check(hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------ ArchiveJob
+namespace {
+// Streams outlive decoders.  hipStreamCreate takes 2.7 ms and hipStreamDestroy 2.4 ms on this stack (rocprofv3 --hip-trace of
+// tools/small_probe.py: 80 % of the 14-18 ms that opening, decoding and closing ONE of the reference's fixtures took, whatever
+// its size -- a decoder owns three streams), so a closed decoder hands its streams to the next one on the same device.  A
+// stream is idle when it comes back (synchronised), a few per device are kept, and the pool is never torn down: at process
+// exit the runtime may be gone before a static destructor runs.
+class StreamPool {
+public:
+    static StreamPool &instance() {
+        static StreamPool *pool = new StreamPool;
+        return *pool;
+    }
+    hipStream_t get(int device) {                          // the current device is `device`
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            std::vector<hipStream_t> &v = idle_[device];
+            if (!v.empty()) {
+                hipStream_t s = v.back();
+                v.pop_back();
+                return s;
+            }
+        }
+        hipStream_t s = nullptr;
+        if (!hip_ok(hipStreamCreate(&s))) return nullptr;
+        return s;
+    }
+    void put(int device, hipStream_t s) {
+        if (!s) return;
+        (void)hipStreamSynchronize(s);
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            std::vector<hipStream_t> &v = idle_[device];
+            if (v.size() < kKeep) {
+                v.push_back(s);
+                return;
+            }
+        }
+        (void)hipStreamDestroy(s);
+    }
+
+private:
+    static constexpr size_t kKeep = 12;
+    std::mutex mu_;
+    std::map<int, std::vector<hipStream_t>> idle_;
+};
+}  // namespace
+
 ArchiveJob::~ArchiveJob() {
+    if (stream_ || aux_stream_ || k2_stream_) (void)hipSetDevice(device_);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
-    if (aux_stream_) (void)hipStreamDestroy(aux_stream_);
-    if (k2_stream_) (void)hipStreamDestroy(k2_stream_);
-    if (stream_) (void)hipStreamDestroy(stream_);
+    StreamPool::instance().put(device_, aux_stream_);
+    StreamPool::instance().put(device_, k2_stream_);
+    StreamPool::instance().put(device_, stream_);
 }
 
 Failure ArchiveJob::init(int device) {
@@ -961,10 +1067,10 @@ Failure ArchiveJob::init(int device) {
     if (!hip_ok(e)) return dev_fail("hipSetDevice", e);
     device_ = device;
     if (!stream_) {
-        e = hipStreamCreate(&stream_);
-        if (!hip_ok(e)) return dev_fail("hipStreamCreate", e);
-        if (!hip_ok(hipStreamCreate(&aux_stream_))) aux_stream_ = nullptr;   // optional: K1 then stays on one stream
-        if (!hip_ok(hipStreamCreate(&k2_stream_))) k2_stream_ = nullptr;     // optional: K2 of a section beside the section before
+        stream_ = StreamPool::instance().get(device);
+        if (!stream_) return dev_fail("hipStreamCreate", hipGetLastError());
+        aux_stream_ = StreamPool::instance().get(device);   // optional: K1 then stays on one stream
+        k2_stream_ = StreamPool::instance().get(device);    // optional: K2 of a section beside the section before
     }
     return Failure();
 }

@@ -35,6 +35,7 @@ public:
     bool alloc_items(uint64_t count, uint64_t item_bytes, uint64_t extra_bytes = 0);   // count * item_bytes + extra_bytes, overflow-checked
     bool upload(const void *host, size_t bytes, hipStream_t stream);   // alloc + async H2D
     void release();
+    void view(void *p, size_t bytes);         // a piece of another buffer: not owned, release() only forgets it
     template <class T>
     T *as() const { return static_cast<T *>(ptr_); }
     uint8_t *bytes() const { return static_cast<uint8_t *>(ptr_); }
@@ -44,6 +45,7 @@ private:
     bool alloc_mapped(size_t bytes);          // an address range backed by hipMemCreate chunks (engine.cpp: why)
     void *ptr_ = nullptr;
     size_t size_ = 0, reserved_ = 0;          // reserved_ != 0: ptr_ is such a range
+    bool view_ = false;
 #ifndef NAFGPU_EMU
     std::vector<hipMemGenericAllocationHandle_t> chunks_;
 #endif
@@ -210,6 +212,8 @@ private:
     float plan_ms_ = 0;
     bool ready_ = false;
     DevBuf d_src_buf_, d_out_, d_lit_, d_seqs_, d_blk_size_, d_blk_base_, d_scan_tmp_, d_status_;
+    DevBuf d_pack_;                                // small tiles: the source bytes and every task list in ONE buffer, one copy (load_tile)
+    std::vector<uint8_t> pack_host_;
     DevBuf d_meta_, d_rep_final_, d_rep_init_, d_rep_scratch_, d_lz_index_, d_blk_pending_, d_roff_, d_counters_;
     DevBuf d_lz_list_[2];
     DevBuf d_halo_tmp_;

@@ -14,11 +14,51 @@ static double now_s() {
     return duration<double>(steady_clock::now().time_since_epoch()).count();
 }
 
+// iter_bench ARCHIVE.naf DEVICE REPEAT: open, every record, close -- REPEAT times in this process; the best cycle in ms (small
+// archives: what a caller that walks a directory of them pays per file once the process is warm).
+static int repeat_mode(const char *path, int device, int repeat) {
+    double best = 1e30, first = 0;
+    unsigned long long n = 0, bases = 0;
+    for (int rep = 0; rep < repeat; rep++) {
+        nafgpu_opts opts;
+        nafgpu_opts_default(&opts);
+        opts.device = device;
+        nafgpu_decoder *dec = nullptr;
+        nafgpu_error err;
+        const double t0 = now_s();
+        if (nafgpu_open_path(path, &opts, &dec, &err) != NAFGPU_OK) {
+            std::fprintf(stderr, "open failed: %s\n", err.message);
+            return 1;
+        }
+        nafgpu_record rec;
+        n = bases = 0;
+        for (;;) {
+            const int rc = nafgpu_next(dec, &rec);
+            if (rc == NAFGPU_END) break;
+            if (rc != NAFGPU_OK) {
+                nafgpu_last_error(dec, &err);
+                std::fprintf(stderr, "next failed at record %llu: %s\n", n, err.message);
+                return 1;
+            }
+            n++;
+            bases += rec.sequence.len;
+        }
+        nafgpu_close(dec);
+        const double dt = now_s() - t0;
+        if (rep == 0) first = dt;
+        if (rep > 0 && dt < best) best = dt;
+    }
+    std::printf("{\"records\": %llu, \"bases\": %llu, \"cycles\": %d, \"best_cycle_ms\": %.4f, \"first_cycle_ms\": %.3f}\n", n, bases, repeat,
+                1e3 * best, 1e3 * first);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) {
-        std::fprintf(stderr, "usage: iter_bench ARCHIVE.naf [device]\n");
+        std::fprintf(stderr, "usage: iter_bench ARCHIVE.naf [device [repeat]]\n");
         return 2;
     }
+    if (argc > 3 && std::atoi(argv[3]) > 1) return repeat_mode(argv[1], std::atoi(argv[2]), std::atoi(argv[3]));
     nafgpu_opts opts;
     nafgpu_opts_default(&opts);
     opts.device = argc > 2 ? std::atoi(argv[2]) : 0;

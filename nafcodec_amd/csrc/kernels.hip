@@ -1790,6 +1790,7 @@ __device__ inline void unpack_dword(uint32_t w, uint32_t t0, uint32_t t1, uint32
 constexpr uint32_t kCtrLeft = 16, kCtrWhich = 17, kCtrPass = 18;   // sparse: survivors of the last pass -- how many, in which list, the next pass number
 constexpr uint32_t kCtrTail = 19;                                  // 1: something still pending lies in the tail the next shard waits for
 constexpr uint32_t kLzShort = 48;        // runs up to this many elements are copied by their own thread
+constexpr uint32_t kLzFewSequences = 8192;   // sections with no more sequences than this: two launched passes, then k_lz_finish_small
 constexpr uint32_t kLzPasses = 24;       // launched passes: the first walks every block, the others the list of what is still pending;
                                          // what they leave goes to ONE workgroup (k_lz_finish_small), then to the frame-order walk
 
@@ -3657,11 +3658,14 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
                                a.blk_pending, a.roff, a.counters, a.rep_init, a.blk_base, a.out, 1u, a.plist[0], lcount + 2u, halo_end, a.status);
             uint64_t lgrid = (a.n_sequences + 255) / 256;
             if (lgrid > 256u * 8u) lgrid = 256u * 8u;
-            for (uint32_t pass = 2; pass <= kLzPasses; pass++)   // pass k reads list k & 1 (its length in lcount[k % 3]): pass 1 wrote list 0 / lcount[2]
+            // a section of a few thousand sequences goes to the one-workgroup stage after the second pass: launches that find
+            // nothing to do still cost 5 us each, and they were a third of the 350 launches a small FASTQ archive takes
+            const uint32_t passes = (!wait && a.n_sequences <= kLzFewSequences) ? 2u : kLzPasses;
+            for (uint32_t pass = 2; pass <= passes; pass++)   // pass k reads list k & 1 (its length in lcount[k % 3]): pass 1 wrote list 0 / lcount[2]
                 hipLaunchKernelGGL(k_lz_match_list<ASCII>, dim3(static_cast<uint32_t>(lgrid)), dim3(256), 0, stream, a.plist[pass & 1u],
                                    a.plist[(pass & 1u) ^ 1u], lcount, a.seqs, a.meta, a.cidx, a.blk_pending, a.roff, a.counters, a.out,
                                    pass, halo_end, a.status);
-            hipLaunchKernelGGL(k_lz_finish_small<ASCII>, dim3(1), dim3(1024), 0, stream, a.plist[0], a.plist[1], lcount, kLzPasses + 1u,
+            hipLaunchKernelGGL(k_lz_finish_small<ASCII>, dim3(1), dim3(1024), 0, stream, a.plist[0], a.plist[1], lcount, passes + 1u,
                                a.seqs, a.meta, a.cidx, a.blk_pending, a.roff, a.counters, a.out, halo_end, 0u, n_total,
                                wait ? a.tail_elems : 0, a.status);
         }

@@ -647,6 +647,8 @@ struct Walker {
 // buffer of a block with many sequences second: the two groups never share a task (the first
 // may expand 4-bit codes to ASCII on the fly, the second never does).  Tasks are then grouped
 // into launch classes (table format x destination x segment-aware kernel).
+static uint32_t g_task_lanes = kHufWave;
+
 void pack_tasks(ZPlan *plan) {
     std::vector<HufRef> &stream_tbl = plan->stream_ref;
     std::vector<uint32_t> class_key;
@@ -685,7 +687,7 @@ void pack_tasks(ZPlan *plan) {
     auto pack_group = [&](size_t g0, size_t g1) {
         size_t s = g0;
         while (s < g1) {
-            size_t e = std::min(g1, s + kHufWave);
+            size_t e = std::min(g1, s + g_task_lanes);
             // k_huf_decode addresses a task's input and output with 32-bit offsets from the lowest
             // address of the task: keep both spans within kHufTaskSpan (output of a block with
             // sequences is not known here: bound it by the block maximum, x2 for the ASCII expansion)
@@ -817,6 +819,7 @@ void pack_tasks(ZPlan *plan) {
 }  // namespace
 
 void pack_tasks_public(ZPlan *plan) { pack_tasks(plan); }
+void set_task_lanes(uint32_t lanes) { g_task_lanes = lanes >= 4 && lanes <= static_cast<uint32_t>(kHufWave) ? lanes : kHufWave; }
 
 std::string walk_zstd(const uint8_t *payload, size_t n, ZPlan *master, bool *truncated) {
     Walker w{payload, n, master, {}, {}};

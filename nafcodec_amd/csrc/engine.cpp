@@ -357,6 +357,7 @@ Failure SectionJob::load_tile(uint32_t t, hipStream_t stream) {
         plan_.src_lo = 0;
         plan_.src_hi = plan_.blk_off.empty() ? 0 : plan_.blk_off.back();
         if (const char *tl = hook_env("NAFGPU_TASK_LANES")) set_task_lanes(static_cast<uint32_t>(std::atoi(tl)));
+        if (const char *ds = hook_env("NAFGPU_DICT_SLOTS")) set_dict_slots(static_cast<uint32_t>(std::atoi(ds)));
         pack_tasks_public(&plan_);
     } else {
         select_zplan(master_, tile.b0, tile.b1, halo_elems_, &plan_, proto_lz_ && halo_cap_ != 0);

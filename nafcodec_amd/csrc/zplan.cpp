@@ -648,6 +648,7 @@ struct Walker {
 // may expand 4-bit codes to ASCII on the fly, the second never does).  Tasks are then grouped
 // into launch classes (table format x destination x segment-aware kernel).
 static uint32_t g_task_lanes = kHufWave;
+static uint32_t g_dict_slots = kHufLdsSlots2;
 
 void pack_tasks(ZPlan *plan) {
     std::vector<HufRef> &stream_tbl = plan->stream_ref;
@@ -733,7 +734,7 @@ void pack_tasks(ZPlan *plan) {
                 // several trees: 2-byte dictionary entries (small alphabets) or compact 4-byte entries, and a
                 // larger budget, so that the task keeps 64 lanes
                 kind = distinct.size() == 1 ? kTblBaked : (small ? kTblDict : kTblCompact);
-                const uint32_t budget = kind == kTblBaked ? kHufLdsEntries : (kind == kTblDict ? kHufLdsSlots2 : kHufLdsEntries4);
+                const uint32_t budget = kind == kTblBaked ? kHufLdsEntries : (kind == kTblDict ? g_dict_slots : kHufLdsEntries4);
                 const uint32_t per_tree = kind == kTblDict ? kHufDictSlots : 0;
                 bool fits = false;
                 for (W = 8; W >= 6; W--) {
@@ -819,6 +820,7 @@ void pack_tasks(ZPlan *plan) {
 }  // namespace
 
 void pack_tasks_public(ZPlan *plan) { pack_tasks(plan); }
+void set_dict_slots(uint32_t slots) { g_dict_slots = slots >= 512 && slots <= kHufLdsSlots2 ? slots : kHufLdsSlots2; }
 void set_task_lanes(uint32_t lanes) { g_task_lanes = lanes >= 4 && lanes <= static_cast<uint32_t>(kHufWave) ? lanes : kHufWave; }
 
 std::string walk_zstd(const uint8_t *payload, size_t n, ZPlan *master, bool *truncated) {

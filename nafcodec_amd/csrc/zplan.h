@@ -83,6 +83,7 @@ bool shard_range(const ZPlan &master, uint32_t shard_rank, uint32_t shard_count,
 void select_zplan(const ZPlan &master, uint32_t b0, uint32_t b1, uint64_t halo_elems, ZPlan *out, bool force_halo = false);
 // packs the tasks of a plan that holds a whole walk (no selection needed)
 void pack_tasks_public(ZPlan *plan);
+void set_dict_slots(uint32_t slots);   // LDS budget of a dictionary-format task in 2-byte slots (experiments)
 void set_task_lanes(uint32_t lanes);   // streams per K1 task (experiments; 64 otherwise)
 // walk + (shard) + select: the whole section, or one shard of it, in one call
 std::string build_zplan(const uint8_t *payload, size_t n, ZPlan *plan, bool *truncated, uint32_t shard_rank = 0,

@@ -196,6 +196,24 @@ def test_real_genome_archive_with_a_few_plain_tasks_beside_many_segmented_ones(l
     assert all("tbl 2, out, " not in l for l in plans), plans[-1]
 
 
+def test_many_small_archives_one_after_the_other(lib):
+    """A directory's worth of small archives in one process: every fixture opened, read to the end through the iterator and closed
+    fifty times over -- decoders hand their streams on through the pool, small tiles upload as one packed buffer, sections of a few
+    sequences take the short match stage (engine.cpp, kernels.hip) -- and every pass yields the oracle's records."""
+    import nafcodec_amd
+    names = ["LuxC.naf", "phix.naf", "masked.naf", "NZ_AAEN01000029.naf"]
+    rec = lambda r: tuple(getattr(r, f) for f in FIELDS)
+    want = {n: [rec(r) for r in oracle.Decoder(golden_bytes(n))] for n in names}
+    for rep in range(50):
+        for n in names:
+            if n.startswith("NZ_") and rep % 10:
+                continue                                   # (5.5 Mbases of Python strings: every tenth pass)
+            dec = nafcodec_amd.Decoder(io.BytesIO(golden_bytes(n)))
+            got = [rec(r) for r in dec]
+            dec.close()
+            assert got == want[n], (n, rep)
+
+
 def test_gigabase_archive_against_the_oracle(lib):
     """Full-size parity pinned on the ORACLE, not on the writer: a 1.2 Gbase synthetic archive (with a Mask
     section) is drained by the CPU oracle in C, which accumulates the position-keyed checksum of the

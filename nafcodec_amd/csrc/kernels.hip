@@ -3661,8 +3661,11 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
             // a section of a few thousand sequences goes to the one-workgroup stage after the second pass: launches that find
             // nothing to do still cost 5 us each, and they were a third of the 350 launches a small FASTQ archive takes
             const uint32_t passes = (!wait && a.n_sequences <= kLzFewSequences) ? 2u : kLzPasses;
+            // (what is still pending after three passes is a small fraction: the later passes -- grid-stride loops, most of them
+            // with nothing left to do -- get an eighth of the workgroups, 5 us a launch instead of 15)
+            const uint64_t lgrid_late = std::max<uint64_t>(std::min<uint64_t>(lgrid, 64), lgrid / 8);
             for (uint32_t pass = 2; pass <= passes; pass++)   // pass k reads list k & 1 (its length in lcount[k % 3]): pass 1 wrote list 0 / lcount[2]
-                hipLaunchKernelGGL(k_lz_match_list<ASCII>, dim3(static_cast<uint32_t>(lgrid)), dim3(256), 0, stream, a.plist[pass & 1u],
+                hipLaunchKernelGGL(k_lz_match_list<ASCII>, dim3(static_cast<uint32_t>(pass <= 3 ? lgrid : lgrid_late)), dim3(256), 0, stream, a.plist[pass & 1u],
                                    a.plist[(pass & 1u) ^ 1u], lcount, a.seqs, a.meta, a.cidx, a.blk_pending, a.roff, a.counters, a.out,
                                    pass, halo_end, a.status);
             hipLaunchKernelGGL(k_lz_finish_small<ASCII>, dim3(1), dim3(1024), 0, stream, a.plist[0], a.plist[1], lcount, passes + 1u,

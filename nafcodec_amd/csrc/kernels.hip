@@ -1153,6 +1153,167 @@ __global__ __launch_bounds__(64) void k_seq_states_lds(const uint8_t *__restrict
     }
 }
 
+// The same chain for sections of up to about twice as many blocks: 2-byte cells and a 512-byte ring (3 KB of LDS per block
+// instead of 7).  A cell's next_base is a multiple of 2^nb (it is (next << nb) - table size), so next_base >> nb and nb fit one
+// ten-bit number with a leading one -- (1 << (9 - nb)) | (next_base >> nb): the position of the top bit says nb -- and the
+// extra-bit count takes five more.  Decoding that costs five instructions per table and sequence (0.15 us per sequence
+// against 0.12, and 0.23 out of L2); the ring's half is 256 bytes, a batch twenty sequences, the chunk in flight one dword per
+// thread, so a wave takes up to sixteen blocks.
+constexpr uint32_t kSeqRingS = 512;          // bytes of bitstream per block in LDS (+ a 16-byte guard)
+constexpr uint32_t kSeqBatchS = 20;          // 20 x 89 bits + a dword pair < 240 bytes
+constexpr uint32_t kSeqLdsLanesS = 16;       // most blocks per wave
+
+__device__ inline uint32_t seq_cell_pack(uint32_t c) {     // c = next_base | nb << 16 | extra_bits << 24
+    const uint32_t nb = (c >> 16) & 0xFFu, base = c & 0xFFFFu, ex = c >> 24;
+    return ((1u << (9u - nb)) | (base >> nb)) | (ex << 10);
+}
+
+__global__ __launch_bounds__(64) void k_seq_states_lds16(const uint8_t *__restrict__ src, const SeqBlock *__restrict__ blocks,
+                                                         uint32_t n_blocks, const SeqCell *__restrict__ cells, SeqRec *recs,
+                                                         uint32_t lanes, uint32_t cells_cap, long long src_min, uint32_t *status) {
+    HIP_DYNAMIC_SHARED(uint32_t, s_seq)                   // per block: cells_cap 2-byte cells, then (kSeqRingS + 16) / 4 ring dwords
+    __shared__ uint64_t s_at[kSeqLdsLanesS];
+    __shared__ uint32_t s_cmd[kSeqLdsLanesS], s_ro[kSeqLdsLanesS];
+    if (status[0] != 0) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b0 = blockIdx.x * lanes;
+    const uint32_t cell_dw = cells_cap / 2;               // (cells_cap is even)
+    const uint32_t per = cell_dw + (kSeqRingS + 16) / 4;
+    for (uint32_t j = 0; j < lanes && b0 + j < n_blocks; j++) {
+        const SeqBlock bj = blocks[b0 + j];
+        uint16_t *t = reinterpret_cast<uint16_t *>(s_seq + j * per);
+        const uint32_t nl = 1u << bj.ll_al, no = 1u << bj.of_al, nm = 1u << bj.ml_al;
+        for (uint32_t i = tid; i < nl; i += 64) t[i] = static_cast<uint16_t>(seq_cell_pack(*reinterpret_cast<const uint32_t *>(cells + bj.ll_tbl + i)));
+        for (uint32_t i = tid; i < no; i += 64) t[nl + i] = static_cast<uint16_t>(seq_cell_pack(*reinterpret_cast<const uint32_t *>(cells + bj.of_tbl + i)));
+        for (uint32_t i = tid; i < nm; i += 64) t[nl + no + i] = static_cast<uint16_t>(seq_cell_pack(*reinterpret_cast<const uint32_t *>(cells + bj.ml_tbl + i)));
+    }
+    const bool live = tid < lanes && b0 + tid < n_blocks;
+    SeqBlock sb{};
+    if (live) sb = blocks[b0 + tid];
+    // ring geometry as in k_seq_states_lds, with halves of 256 bytes: a chunk is one dword per thread
+    const uint64_t end_off = sb.bits_off + sb.bits_len;
+    const uint64_t lo0 = ((end_off + 15) & ~uint64_t(15)) - kSeqRingS;
+    uint64_t lo = lo0;
+    if (live) s_at[tid] = lo0;
+    wave_sync();
+    uint32_t fly[kSeqLdsLanesS];
+    auto load4 = [&](uint64_t at) -> uint32_t {
+        uint32_t v = 0;
+        if (static_cast<long long>(at) >= src_min) __builtin_memcpy(&v, src + at, 4);
+        return v;
+    };
+#pragma unroll
+    for (uint32_t j = 0; j < kSeqLdsLanesS; j++) {
+        fly[j] = 0;
+        if (j < lanes && b0 + j < n_blocks) {
+            const uint64_t base = s_at[j];
+            uint32_t *rj = s_seq + j * per + cell_dw;
+            const uint32_t h0 = load4(base + 4 * tid), h1 = load4(base + kSeqRingS / 2 + 4 * tid);
+            rj[tid] = h0;
+            rj[kSeqRingS / 8 + tid] = h1;
+            if (tid < 4) rj[kSeqRingS / 4 + tid] = h0;                       // the guard mirrors ring bytes 0..15
+            fly[j] = load4(base - kSeqRingS / 2 + 4 * tid);
+        }
+    }
+    wave_sync();
+    const uint32_t *ring = s_seq + (tid < lanes ? tid : 0) * per + cell_dw;
+    const uint32_t bit0 = static_cast<uint32_t>((sb.bits_off - lo0) & (kSeqRingS - 1)) * 8u;
+    auto field = [&](uint32_t p_low) -> uint32_t {
+        const uint32_t rb = (bit0 + p_low) & (kSeqRingS * 8 - 1);
+        const uint32_t *w = ring + (rb >> 5);
+        return __builtin_amdgcn_alignbit(w[1], w[0], rb & 31u);
+    };
+    int32_t pos = -1;
+    uint32_t sl = 0, so = 0, sm = 0, n = 0;
+    SeqRec *dst = recs + sb.seq_first;
+    if (live) {
+        const uint32_t lastb = src[end_off - 1];                         // host checked: non-zero
+        pos = static_cast<int32_t>(sb.bits_len - 1) * 8 + (31 - __clz(static_cast<int>(lastb | 1u)));
+        n = sb.n_seq;
+        const int32_t p1 = pos - static_cast<int32_t>(sb.ll_al + sb.of_al + sb.ml_al);
+        if (p1 >= 0) {
+            const uint32_t f = field(static_cast<uint32_t>(p1));
+            sl = __builtin_amdgcn_ubfe(f, sb.of_al + sb.ml_al, sb.ll_al);
+            so = __builtin_amdgcn_ubfe(f, sb.ml_al, sb.of_al);
+            sm = __builtin_amdgcn_ubfe(f, 0, sb.ml_al);
+        }
+        pos = p1;
+    }
+#ifndef NAFGPU_EMU
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    const uint16_t *tl = reinterpret_cast<const uint16_t *>(s_seq + (tid < lanes ? tid : 0) * per), *tof = tl + (1u << sb.ll_al),
+                   *tm = tof + (1u << sb.of_al);
+    // a packed cell -> {next_base, nb}; the extra bits are c >> 10
+    auto unpack = [](uint32_t c, uint32_t *nb) -> uint32_t {
+        const uint32_t code = c & 1023u;
+        const uint32_t msb = 31u - static_cast<uint32_t>(__clz(static_cast<int>(code | 1u)));
+        *nb = 9u - msb;
+        return (code ^ (1u << msb)) << (9u - msb);
+    };
+    uint32_t i = 0;
+    bool pending = live;
+    for (;;) {
+        const uint32_t stop = i + kSeqBatchS;
+        for (; i < stop; i++) {
+            const bool on = live && i + 1 < n && pos >= 0;
+            if (!__any(on ? 1 : 0)) break;
+            if (!on) continue;
+            const uint32_t cl = tl[sl], co = tof[so], cm = tm[sm];
+            dst[i] = SeqRec{pos, sl | sm << 9 | so << 18};
+            uint32_t nbl, nbm, nbo;
+            const uint32_t bl = unpack(cl, &nbl), bm = unpack(cm, &nbm), bo = unpack(co, &nbo);
+            const int32_t p1 = pos - static_cast<int32_t>((cl >> 10) + (co >> 10) + (cm >> 10) + nbl + nbm + nbo);
+            const uint32_t f = field(static_cast<uint32_t>(p1 < 0 ? 0 : p1));
+            sl = bl + __builtin_amdgcn_ubfe(f, nbm + nbo, nbl);
+            sm = bm + __builtin_amdgcn_ubfe(f, nbo, nbm);
+            so = bo + __builtin_amdgcn_ubfe(f, 0, nbo);
+            pos = p1;
+        }
+        const bool more = live && i + 1 < n && pos >= 0;
+        if (!__any(more ? 1 : 0)) break;
+        if (tid < kSeqLdsLanesS) s_cmd[tid] = 0;
+        wave_sync();
+        if (more) {
+            const uint64_t cur = sb.bits_off + (static_cast<uint32_t>(pos > 0 ? pos - 1 : 0) >> 3);
+            uint32_t cmd = 0;
+            if (pending && static_cast<long long>(cur) + 16 <= static_cast<long long>(lo) + kSeqRingS / 2) {
+                lo -= kSeqRingS / 2;
+                s_ro[tid] = static_cast<uint32_t>((lo - lo0) & (kSeqRingS - 1));
+                cmd = 1;
+                pending = false;
+            }
+            if (!pending) {
+                s_at[tid] = lo - kSeqRingS / 2;
+                cmd |= 2;
+                pending = true;
+            }
+            s_cmd[tid] = cmd;
+        }
+        wave_sync();
+#pragma unroll
+        for (uint32_t j = 0; j < kSeqLdsLanesS; j++) {
+            const uint32_t cmd = s_cmd[j];                               // (uniform)
+            if (cmd & 1u) {
+                uint32_t *rj = s_seq + j * per + cell_dw;
+                const uint32_t ro = s_ro[j];
+                rj[ro / 4 + tid] = fly[j];
+                if (ro == 0 && tid < 4) rj[kSeqRingS / 4 + tid] = fly[j];
+            }
+            if (cmd & 2u) fly[j] = load4(s_at[j] + 4 * tid);
+        }
+        wave_sync();
+    }
+    if (live) {
+        if (pos >= 0 && n > 0) {                                         // the last: no state update after it
+            const uint32_t cl = tl[sl], co = tof[so], cm = tm[sm];
+            dst[n - 1] = SeqRec{pos, sl | sm << 9 | so << 18};
+            pos -= static_cast<int32_t>((cl >> 10) + (co >> 10) + (cm >> 10));
+        }
+        if (pos != 0) flag_error(status, kStSeqBadEnd, sb.blk);
+    }
+}
+
 constexpr uint32_t kSeqPerLane = 4;
 
 __global__ __launch_bounds__(64) void k_seq_values(const uint8_t *__restrict__ src, const SeqBlock *__restrict__ blocks,
@@ -3389,8 +3550,30 @@ void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *b
     if (lds_lanes * per_block > 64u * 1024u) lds_lanes = (64u * 1024u) / per_block;
     if (lds_lanes) per_cu = ((160u * 1024u - 1024u) / (lds_lanes * per_block + 256u)) * lds_lanes;
     bool use_lds = cells_cap != 0 && lds_lanes != 0 && static_cast<uint64_t>(n_blocks) <= static_cast<uint64_t>(n_cu) * per_cu;
-    if (const char *e = hook_env("NAFGPU_K2_LDS")) use_lds = cells_cap != 0 && lds_lanes != 0 && e[0] == '1';
-    if (use_lds) {
+    // ... or, for sections up to about twice that size, with 2-byte cells and a 512-byte ring (k_seq_states_lds16): about one
+    // wave per SIMD again, each with as many blocks as it takes to have every block of the section resident
+    const uint32_t per_block_s = cells_cap * 2u + kSeqRingS + 16u;
+    uint32_t lanes16 = 0;
+    if (cells_cap != 0) {
+        const uint32_t spread = (n_blocks + 4u * n_cu - 1u) / (4u * n_cu);
+        for (uint32_t l = spread < 1 ? 1 : spread; l <= kSeqLdsLanesS && l * per_block_s <= 64u * 1024u; l++) {
+            uint32_t wgs = (160u * 1024u - 1024u) / (l * per_block_s + 256u);
+            if (wgs > 32u) wgs = 32u;
+            if (static_cast<uint64_t>(n_cu) * wgs * l >= n_blocks) {
+                lanes16 = l;
+                break;
+            }
+        }
+    }
+    bool use_lds16 = !use_lds && lanes16 != 0;
+    if (const char *e = hook_env("NAFGPU_K2_LDS")) {
+        use_lds = cells_cap != 0 && lds_lanes != 0 && e[0] == '1';
+        use_lds16 = lanes16 != 0 && e[0] == '2';
+    }
+    if (use_lds16) {
+        hipLaunchKernelGGL(k_seq_states_lds16, dim3((n_blocks + lanes16 - 1) / lanes16), dim3(64), lanes16 * per_block_s, stream, src, blocks,
+                           n_blocks, cells, recs, lanes16, cells_cap, src_min, status);
+    } else if (use_lds) {
         // fewer lanes per wave than fit, when there are few blocks: every CU gets its share of the chains
         uint32_t lanes = (n_blocks + 4u * n_cu - 1u) / (4u * n_cu);
         lanes = lanes < 1 ? 1 : (lanes > lds_lanes ? lds_lanes : lanes);

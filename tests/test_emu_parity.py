@@ -93,7 +93,7 @@ def test_sequence_chains_out_of_lds_and_out_of_l2(emu, all_cases, monkeypatch):
     bitstream ring is topped up many times), one-sequence blocks, RLE and predefined tables, corrupt streams."""
     emu.c.nafgpu_test_hooks(1)
     names = ("dna_l3_big", "text_quality", "fastq_flush_per_record", "truncated_mid", "bitflip_sequence", "checksum_text_l3")
-    for force in ("1", "0"):
+    for force in ("1", "2", "0"):
         monkeypatch.setenv("NAFGPU_K2_LDS", force)
         for name, blob, opts in all_cases:
             if name in names:

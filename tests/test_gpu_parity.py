@@ -295,12 +295,12 @@ def test_lz_stages_dense_and_sparse(lib, monkeypatch):
 
 
 def test_sequence_chains_out_of_lds_and_out_of_l2(lib, monkeypatch):
-    """Both bodies of k_seq_states (NAFGPU_K2_LDS forces one) on every archive case with LZ sequences and on the fuzz set."""
+    """The three bodies of k_seq_states (NAFGPU_K2_LDS forces one: 4-byte cells in LDS, 2-byte cells in LDS, out of L2) on every archive case with LZ sequences and on the fuzz set."""
     import cases
     lib.c.nafgpu_test_hooks(1)
     todo = [c for c in cases.build_cases(scale=4) if c[0].startswith(("dna_l", "text_", "fastq_", "dna_repeat", "dna_dense", "dna_homo", "protein",
                                                                       "rna", "checksum", "truncated", "bitflip"))]
-    for force in ("1", "0"):
+    for force in ("1", "2", "0"):
         monkeypatch.setenv("NAFGPU_K2_LDS", force)
         for name, blob, opts in todo:
             assert cases.run_product(blob, opts) == cases.run_oracle(blob, opts), (name, force)

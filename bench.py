@@ -49,6 +49,7 @@ def parse_args():
                     help="N=1 only: the same at the size of a human genome (x 565 = 3.1 Gbases), reported as path.real_genome_3g; 0 skips it")
     ap.add_argument("--fastq-reads", type=float, default=10e6,
                     help="N=1 only: a FASTQ-shaped archive of this many 151-base reads (bulk decode + the record iterator), path.fastq_like; 0 skips it")
+    ap.add_argument("--no-masked-leg", action="store_true", help="N=1 only: skip path.masked (configs[3]: the headline archive with a Mask section)")
     ap.add_argument("--no-iterator", action="store_true", help="skip path.iterator (the headline archive through nafgpu_next)")
     ap.add_argument("--real-copies-per-gpu", type=int, default=1000,
                     help="N>1: the real-genome archive (WITH LZ sequences) holds this many tiles per GPU, ONE archive decoded through the "
@@ -262,6 +263,42 @@ def iterator_leg(path, device):
             "end_to_end_Gbases_s": round(j["bases"] / max(j["total_s"], 1e-9) / 1e9, 3),
             "note": "first next() to last through nafgpu_next (the first one decodes every section on the GPU); end_to_end from nafgpu_open_path: "
                     "host walk + H2D + decode + every record's bytes D2H through the 64 MiB pinned window"}
+
+
+def masked_leg(lib, device, n_bases):
+    """configs[3]: the headline archive WITH a Mask section (the same bases, 11 M masked runs over a sixth of them): K1 as in the
+    headline, then the run table scan and k_mask_apply's second trip over the lines that hold masked bases.  Two untimed decodes,
+    five timed; the output checked against the writer's checksum of the masked bases."""
+    ffi = _ffi_mod()
+    arc = lib.synth(n_bases, seed=0x4E4146, with_mask=True)
+    h, err, res = ctypes.c_void_p(), ffi.Error(), ffi.DeviceResult()
+    try:
+        opts = ffi.Opts()
+        lib.c.nafgpu_opts_default(ctypes.byref(opts))
+        opts.device = device
+        if lib.c.nafgpu_open_bytes(ctypes.cast(arc.bytes, ctypes.c_char_p), arc.n, ctypes.byref(opts), ctypes.byref(h), ctypes.byref(err)) != 0:
+            raise RuntimeError("masked leg: open failed: %s" % err.message.decode())
+        tot, huf, oth = [], [], []
+        for k in range(7):
+            if lib.c.nafgpu_decode_all_device(h, ctypes.byref(res)) != 0:
+                lib.c.nafgpu_last_error(h, ctypes.byref(err))
+                raise RuntimeError("masked leg: decode failed: %s" % err.message.decode())
+            if k >= 2:
+                tot.append(res.ms_total)
+                huf.append(res.ms_huf)
+                oth.append(res.ms_other + res.ms_seq_lz)
+        out = ctypes.c_uint64()
+        lib.c.nafgpu_hash64_device(h, res.d_sequence, res.n_bases, ctypes.byref(out))
+        if out.value != arc.seq_hash or res.n_bases != arc.n_bases:
+            raise RuntimeError("masked leg: decoded bases differ from the writer's checksum")
+        ms = sum(tot) / len(tot)
+        return {"workload": "synthetic %.1f GB DNA .naf (seq+mask+len), %d bases; masked output equals the writer's checksum" % (arc.n / 1e9, res.n_bases),
+                "bases": int(res.n_bases), "ms_per_step": round(ms, 3), "value": round(res.n_bases / ms / 1e6, 1), "unit": "Gbases/s",
+                "ms_huf": round(sum(huf) / len(huf), 3), "ms_mask_and_scans": round(sum(oth) / len(oth), 3)}
+    finally:
+        if h:
+            lib.c.nafgpu_close(h)
+        lib.c.nafgpu_synth_free(ctypes.byref(arc))
 
 
 def fixtures_leg(device):
@@ -672,6 +709,8 @@ def main():
         # first decode of a fresh archive, everything included: host walk + H2D (PCIe) + the device decode
         e2e_s = (res.ms_host_plan + res.ms_h2d + dev_ms) * 1e-3
         line["path"]["end_to_end_Gbases_s"] = round(total_bases / world / e2e_s / 1e9, 1) if e2e_s > 0 else None
+        if not args.mask and not args.no_masked_leg and not args.iupac and world == 1 and not args.rehearsal_lib:
+            line["path"]["masked"] = masked_leg(lib, device, n_bases)
         if args.real_copies and world == 1 and not args.rehearsal_lib:
             line["path"]["real_genome"] = real_genome_leg(lib, device, args.real_copies)
         if args.small_real_copies and world == 1 and not args.rehearsal_lib:

@@ -74,7 +74,7 @@ for line in (pmc_line, bench_line):
         break
 if fetch and write:
     out = {
-        "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu --no-verify --real-copies 0 --small-real-copies 0 --fastq-reads 0 --no-iterator, one rocprofv3 --pmc pass per counter group (tools/profile_round.sh)",
+        "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu --no-verify --real-copies 0 --small-real-copies 0 --fastq-reads 0 --no-iterator --no-masked-leg, one rocprofv3 --pmc pass per counter group (tools/profile_round.sh)",
         "n_bases": n_bases,
         "kernel": "k_huf_decode<true, 0, false>",
         "launches_averaged": nf.get("FETCH_SIZE"),

@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--real-copies-per-gpu", type=int, default=1000,
                     help="N>1: the real-genome archive (WITH LZ sequences) holds this many tiles per GPU, ONE archive decoded through the "
                          "shard protocol and reported as path.real_genome; 0 skips it")
-    ap.add_argument("--sharded-leg-limit", type=int, default=300,
+    ap.add_argument("--sharded-leg-limit", type=int, default=180,
                     help="N>1: seconds the path.real_genome leg may take before the line is printed without it")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--rehearsal-one-gpu", action="store_true",

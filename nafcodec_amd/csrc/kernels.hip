@@ -1319,7 +1319,8 @@ constexpr uint32_t kSeqPerLane = 4;
 __global__ __launch_bounds__(64) void k_seq_values(const uint8_t *__restrict__ src, const SeqBlock *__restrict__ blocks,
                                                    uint32_t n_blocks, const SeqCell *__restrict__ cells,
                                                    const SeqRec *__restrict__ recs, Seq *seqs, uint32_t *blk_size,
-                                                   uint32_t *rep_final, uint32_t *status) {
+                                                   uint32_t *rep_final, uint32_t cells_cap, uint32_t *status) {
+    HIP_DYNAMIC_SHARED(uint2, s_cells)          // the block's three tables (cells_cap cells), when it has sequences enough to pay for them
     __shared__ uint32_t s_sum[2][2][64];        // [ping-pong][ll, ml][lane]
     __shared__ uint32_t s_map[2][3][64];        // [ping-pong][slot][lane]
     if (status[0] != 0) return;                 // (k_seq_states flagged a stream: its records are not all there)
@@ -1328,6 +1329,27 @@ __global__ __launch_bounds__(64) void k_seq_values(const uint8_t *__restrict__ s
     const SeqBlock sb = blocks[b];
     const uint8_t *bits = src + sb.bits_off;
     const SeqCell *tll = cells + sb.ll_tbl, *tof = cells + sb.of_tbl, *tml = cells + sb.ml_tbl;
+    // Three cells per sequence at random places of the tables: out of L2 that is 64 different sectors per load instruction
+    // (a block of 30 k sequences asks for its 10 KB of tables 90 k times).  A block with at least as many sequences as its
+    // tables have cells stages them in LDS first.
+    const uint32_t nl = 1u << sb.ll_al, nof = 1u << sb.of_al, nml = 1u << sb.ml_al;
+    const bool staged = cells_cap != 0 && nl + nof + nml <= cells_cap && sb.n_seq >= nl + nof + nml;
+    if (staged) {
+        for (uint32_t i = lane; i < nl; i += 64) s_cells[i] = *reinterpret_cast<const uint2 *>(tll + i);
+        for (uint32_t i = lane; i < nof; i += 64) s_cells[nl + i] = *reinterpret_cast<const uint2 *>(tof + i);
+        for (uint32_t i = lane; i < nml; i += 64) s_cells[nl + nof + i] = *reinterpret_cast<const uint2 *>(tml + i);
+        wave_sync();
+    }
+    auto cell_at = [&](const SeqCell *tbl, uint32_t lds_base, uint32_t idx) -> SeqCell {
+        SeqCell c;
+        if (staged) {
+            const uint2 v = s_cells[lds_base + idx];
+            __builtin_memcpy(&c, &v, 8);
+        } else {
+            c = tbl[idx];
+        }
+        return c;
+    };
     const SeqRec *rec = recs + sb.seq_first;
     Seq *dst = seqs + sb.seq_first;
     const uint32_t id0 = kRepToken | (0u << 24), id1 = kRepToken | (1u << 24), id2 = kRepToken | (2u << 24);
@@ -1343,7 +1365,8 @@ __global__ __launch_bounds__(64) void k_seq_values(const uint8_t *__restrict__ s
             offs[j] = 0;
             if (i0 + j >= sb.n_seq) continue;
             const SeqRec q = rec[i0 + j];
-            const SeqCell cl = tll[q.states & 511u], cm = tml[(q.states >> 9) & 511u], co = tof[q.states >> 18];
+            const SeqCell cl = cell_at(tll, 0, q.states & 511u), cm = cell_at(tml, nl + nof, (q.states >> 9) & 511u),
+                          co = cell_at(tof, nl, q.states >> 18);
             SeqWindow r{bits, q.pos, 0, 0, 0};
             r.load();
             const uint32_t ofv = co.base_value + r.read(co.extra_bits);   // extra bits in the order OF, ML, LL
@@ -3607,8 +3630,8 @@ void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *b
         hipLaunchKernelGGL(k_seq_states, dim3((n_blocks + lanes - 1) / lanes), dim3(64), 0, stream, src, blocks, n_blocks, cells, recs,
                            lanes, status);
     }
-    hipLaunchKernelGGL(k_seq_values, dim3(n_blocks), dim3(64), 0, stream, src, blocks, n_blocks, cells, recs, seqs, blk_size,
-                       rep_final, status);
+    hipLaunchKernelGGL(k_seq_values, dim3(n_blocks), dim3(64), cells_cap * 8u, stream, src, blocks, n_blocks, cells, recs, seqs, blk_size,
+                       rep_final, cells_cap, status);
 }
 
 size_t scan_tmp_bytes(uint64_t n) { return static_cast<size_t>((n + kScanTile - 1) / kScanTile + 1) * sizeof(TileAgg); }

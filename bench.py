@@ -245,24 +245,29 @@ def real_genome_leg(lib, device, copies):
         lib.c.nafgpu_close(h)
 
 
-def iterator_leg(path, device):
+def iterator_leg(path, device, batch=0):
     """The drop-in API itself (Decoder::from_path + Iterator::next, mod.rs:304-306, 356-399): nafcodec_amd/iter_bench -- plain C++
-    on the C-ABI, what a Rust / C++ shim does -- opens the archive at `path` and calls nafgpu_next until the end; every record's
-    sequence / quality comes to the host through the decoder's pinned window.  Seconds from open to the last record."""
+    on the C-ABI, what a Rust / C++ shim does -- opens the archive at `path` and calls nafgpu_next until the end (`batch` > 0:
+    nafgpu_next_batch, that many records a call); every record's sequence / quality comes to the host through the decoder's
+    pinned window.  Seconds from open to the last record; `records_per_s_after_first` leaves out the first call (which decodes
+    every section on the GPU)."""
     import subprocess
     tool = os.path.join(ROOT, "nafcodec_amd", "iter_bench")
     if not os.path.exists(tool):
         return None
-    p = subprocess.run([tool, path, str(device)], capture_output=True, text=True, timeout=900)
+    p = subprocess.run([tool, path, str(device), "1", str(batch)], capture_output=True, text=True, timeout=900)
     if p.returncode != 0:
         raise RuntimeError("iter_bench failed: %s" % p.stderr[-500:])
     j = json.loads(p.stdout.strip().splitlines()[-1])
     it = max(j["iterate_s"], 1e-9)
+    rest = max(j["iterate_s"] - j["first_next_s"], 1e-9)
     return {"records": j["records"], "bases": j["bases"], "open_s": round(j["open_s"], 4), "first_next_s": round(j["first_next_s"], 4),
             "iterate_s": round(j["iterate_s"], 4), "records_per_s": round(j["records"] / it), "Gbases_per_s": round(j["bases"] / it / 1e9, 3),
+            "records_per_s_after_first": round(j["records"] / rest), "calls": j["calls"], "batch": batch,
             "end_to_end_Gbases_s": round(j["bases"] / max(j["total_s"], 1e-9) / 1e9, 3),
-            "note": "first next() to last through nafgpu_next (the first one decodes every section on the GPU); end_to_end from nafgpu_open_path: "
-                    "host walk + H2D + decode + every record's bytes D2H through the 64 MiB pinned window"}
+            "note": "first next() to last through %s (the first call decodes every section on the GPU); end_to_end from nafgpu_open_path: "
+                    "host walk + H2D + decode + every record's bytes D2H through the 64 MiB pinned window"
+                    % ("nafgpu_next_batch, %d records a call" % batch if batch else "nafgpu_next")}
 
 
 def masked_leg(lib, device, n_bases):
@@ -394,6 +399,7 @@ def fastq_like_leg(lib, device, n_reads, level=1):
             f.write(blob)
         del blob
         out["iterator"] = iterator_leg(path, device)
+        out["iterator_batch"] = iterator_leg(path, device, batch=4096)     # the same records through nafgpu_next_batch
     finally:
         if os.path.exists(path):
             os.unlink(path)
@@ -477,13 +483,14 @@ def _ffi_mod():
 
 
 def committed_traffic(n_bases):
-    """HBM-side bytes per k_huf_decode launch from the committed rocprofv3 PMC passes of this same
+    """(bytes, file): HBM-side bytes per k_huf_decode launch from the committed rocprofv3 PMC passes of this same
     command (profiles/*_pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, values in bytes;
-    see the note in that file about the gfx950 FETCH_SIZE correction).  None for other workloads."""
-    best = None
+    see the note in that file about the gfx950 FETCH_SIZE correction), and the file they were read from -- the bench
+    run itself collects no counters (they need the profiler).  (None, None) for other workloads."""
+    best = (None, None)
     pdir = os.path.join(ROOT, "profiles")
     if not os.path.isdir(pdir):
-        return None
+        return best
     for name in sorted(os.listdir(pdir)):
         if name.endswith("_pmc_summary.json"):
             try:
@@ -494,7 +501,7 @@ def committed_traffic(n_bases):
             # the summary names the workload it was taken on (older ones: in the command text, the default size)
             same = j.get("n_bases") == n_bases or ("n_bases" not in j and "40e9 bases" in j.get("command", "") and n_bases == DEFAULT_BASES)
             if same:
-                best = int(j["FETCH_SIZE_bytes"] + j["WRITE_SIZE_bytes"])
+                best = (int(j["FETCH_SIZE_bytes"] + j["WRITE_SIZE_bytes"]), "profiles/" + name)
     return best
 
 
@@ -517,7 +524,9 @@ def main():
     from nafcodec_amd import _ffi
     # raises if libnafgpu.so is missing: no CPU fallback.  Nothing in the environment may redirect the
     # measured path: the product library is the in-tree nafcodec_amd/libnafgpu.so, without debug switches.
-    for var in ("NAFGPU_LIB", "NAFGPU_PJ_MAX_DIST", "NAFGPU_LZ_MODE", "NAFGPU_TILE_KIB", "NAFGPU_K2_LANES", "NAFGPU_PROBE_LIBS"):
+    for var in ("NAFGPU_LIB", "NAFGPU_PJ_MAX_DIST", "NAFGPU_LZ_MODE", "NAFGPU_TILE_KIB", "NAFGPU_K2_LANES", "NAFGPU_PROBE_LIBS",
+                "NAFGPU_K2_LDS", "NAFGPU_PJ_STRIPS", "NAFGPU_ALLOC_PLAIN", "NAFGPU_VMM_CHUNK_MIB", "NAFGPU_TASK_LANES", "NAFGPU_DICT_SLOTS",
+                "NAFGPU_HUF_SPLIT", "NAFGPU_PJ_HOPS", "NAFGPU_DEBUG_PLAN", "NAFGPU_PROBE_ONE_DECODE"):
         if os.environ.get(var):
             raise SystemExit("bench.py: %s is set; refusing to print a headline from a redirected or ablated build" % var)
     lib = _ffi.Library(args.rehearsal_lib) if args.rehearsal_lib else _ffi.default()
@@ -696,7 +705,8 @@ def main():
                                    if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_huf_decode", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": committed_traffic(n_bases), "ms_per_launch": round(k1, 3),
+                         "traffic": committed_traffic(n_bases)[0], "traffic_source": committed_traffic(n_bases)[1],
+                         "ms_per_launch": round(k1, 3),
                          "algorithmic_bytes_per_launch": int(k1_bytes)},
             "path": {"device_ms_per_step": round(dev_ms, 3),
                      "algorithmic_GBps": round(path_bytes / (dev_ms * 1e-3) / 1e9, 1) if dev_ms else None,
@@ -744,18 +754,34 @@ def main():
         if rank == 0 and world > 1 and shared_path and os.path.exists(shared_path):
             os.unlink(shared_path)
 
+    if world > 1:
+        # what ran, in the run's own words: the backend and the world size the process group reports, every rank's device
+        names = [None] * world
+        dist.all_gather_object(names, "rank %d: %s" % (rank, (torch.cuda.get_device_name(local_rank) + " cuda:%d" % local_rank) if tdev == "cuda"
+                                                       else "%s device %d (exchange on the CPU)" % (lib.device_info(device)[0] if not args.rehearsal_lib else "CPU harness", device)))
+        if rank == 0:
+            line["backend"] = "%s%s" % (dist.get_backend(), " (RCCL over xGMI)" if tdev == "cuda" else "")
+            line["rccl_ranks" if tdev == "cuda" else "ranks"] = dist.get_world_size()
+            line["devices"] = names
     if world > 1 and args.real_copies_per_gpu:
         # sections WITH LZ sequences over the same ranks (every rank takes part).  The headline above is already measured: a
         # rank that fails or stalls in this leg must not take the line with it, so the leg runs under a per-rank time limit,
         # after which rank 0 prints the line with the failure named in it and every rank leaves.
         import threading
 
+        from nafcodec_amd import sharding
+
         def leave(reason):
+            # the headline is printed (it was measured), and the process then ends with a status that says the run did
+            # NOT complete: a stall or a failure of the N-GPU leg must never reach the driver as rc 0
+            where = "rank %d at step %r, section %r" % (rank, sharding.PROGRESS["step"], sharding.PROGRESS["section"])
+            sys.stderr.write("bench.py: sharded real-genome leg: %s (%s)\n" % (reason, where))
+            sys.stderr.flush()
             if rank == 0:
-                line["path"]["real_genome"] = {"error": reason}
+                line["path"]["real_genome"] = {"error": reason, "where": where}
                 print(json.dumps(line), flush=True)
             cleanup_shared()
-            os._exit(0)
+            os._exit(3)
 
         limit = threading.Timer(args.sharded_leg_limit, leave, ["sharded real-genome leg not finished after %d s" % args.sharded_leg_limit])
         limit.daemon = True

@@ -8,6 +8,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <vector>
 
 #include "nafgpu.h"
 
@@ -58,11 +59,18 @@ private:
 
 class Decoder {   // mod.rs:285-461
 public:
-    Decoder(Decoder &&o) noexcept : d_(std::exchange(o.d_, nullptr)) {}
+    Decoder(Decoder &&o) noexcept
+        : d_(std::exchange(o.d_, nullptr)), batch_(std::move(o.batch_)), at_(std::exchange(o.at_, 0)), n_(std::exchange(o.n_, 0)),
+          pending_(std::exchange(o.pending_, NAFGPU_OK)), pending_err_(o.pending_err_) {}
     Decoder &operator=(Decoder &&o) noexcept {
         if (this != &o) {
             nafgpu_close(d_);
             d_ = std::exchange(o.d_, nullptr);
+            batch_ = std::move(o.batch_);
+            at_ = std::exchange(o.at_, 0);
+            n_ = std::exchange(o.n_, 0);
+            pending_ = std::exchange(o.pending_, NAFGPU_OK);
+            pending_err_ = o.pending_err_;
         }
         return *this;
     }
@@ -76,18 +84,33 @@ public:
         return Header(h);
     }
     SequenceType sequence_type() const { return header().sequence_type(); }
-    size_t len() const { return static_cast<size_t>(nafgpu_remaining(d_)); }   // ExactSizeIterator
+    size_t len() const { return static_cast<size_t>(nafgpu_remaining(d_)) + (n_ - at_); }   // ExactSizeIterator (records fetched ahead count)
 
-    // Iterator::next: nullopt at the end; throws Error (the iterator stays usable, mod.rs:391)
+    // Iterator::next: nullopt at the end; throws Error (the iterator stays usable, mod.rs:391).
+    // Records cross the C boundary a batch at a time (nafgpu_next_batch); what the caller sees is what one nafgpu_next
+    // per record gives: an error met by record k of a batch is thrown when record k is asked for, not before.
     std::optional<Record> next() {
-        nafgpu_record r;
-        int rc = nafgpu_next(d_, &r);
-        if (rc == NAFGPU_END) return std::nullopt;
-        if (rc != NAFGPU_OK) {
-            nafgpu_error e;
-            nafgpu_last_error(d_, &e);
-            throw Error(e);
+        if (at_ == n_) {
+            if (pending_ != NAFGPU_OK) {
+                const int rc = std::exchange(pending_, NAFGPU_OK);
+                if (rc == NAFGPU_END) return std::nullopt;
+                throw Error(pending_err_);
+            }
+            if (batch_.empty()) batch_.resize(kBatch);
+            uint64_t got = 0;
+            const int rc = nafgpu_next_batch(d_, batch_.data(), kBatch, &got);
+            at_ = 0;
+            n_ = static_cast<size_t>(got);
+            if (rc != NAFGPU_OK) {
+                if (rc != NAFGPU_END) nafgpu_last_error(d_, &pending_err_);
+                if (n_ == 0) {
+                    if (rc == NAFGPU_END) return std::nullopt;
+                    throw Error(pending_err_);
+                }
+                pending_ = rc;
+            }
         }
+        const nafgpu_record &r = batch_[at_++];
         auto own = [](const nafgpu_field &f) -> std::optional<std::string> {
             if (!f.present) return std::nullopt;
             return std::string(reinterpret_cast<const char *>(f.ptr), static_cast<size_t>(f.len));
@@ -123,6 +146,11 @@ private:
     friend class DecoderBuilder;
     explicit Decoder(nafgpu_decoder *d) : d_(d) {}
     nafgpu_decoder *d_ = nullptr;
+    static constexpr size_t kBatch = 1024;
+    std::vector<nafgpu_record> batch_;
+    size_t at_ = 0, n_ = 0;
+    int pending_ = NAFGPU_OK;          // what the batch call returned behind its records (an error, or the end)
+    nafgpu_error pending_err_{};
 };
 
 class DecoderBuilder {   // mod.rs:53-257

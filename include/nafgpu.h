@@ -149,6 +149,13 @@ uint64_t nafgpu_remaining(const nafgpu_decoder *dec);
  * Field pointers stay valid until the next call on this decoder; the shim copies them into
  * owned strings to honour Record<'static>.  An error does not fuse the iterator (mod.rs:391). */
 int nafgpu_next(nafgpu_decoder *dec, nafgpu_record *rec);
+/* Up to `cap` calls of Iterator::next (mod.rs:444-451) in one crossing of the boundary: a binding that reads millions of
+ * 151-base records pays one call per few thousand of them.  Fills recs[0 .. *n) -- exactly the records, in order, that *n
+ * calls of nafgpu_next would have handed out -- and returns NAFGPU_OK (with *n >= 1; *n < cap when the next record's bytes
+ * are not on the host yet: call again), NAFGPU_END (*n == 0: nothing left), or the error the (*n + 1)-th call of nafgpu_next
+ * would have returned: recs[0 .. *n) are valid then too, the iterator is not fused, and the next call goes on behind the
+ * record that failed (mod.rs:391).  All views of one batch stay valid until the next call on this decoder. */
+int nafgpu_next_batch(nafgpu_decoder *dec, nafgpu_record *recs, uint64_t cap, uint64_t *n);
 /* Drop for Decoder / into_inner (mod.rs:343-350) */
 void nafgpu_close(nafgpu_decoder *dec);
 /* last error raised on this decoder (or by the failed open when dec == NULL is not possible:

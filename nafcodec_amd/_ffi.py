@@ -101,7 +101,7 @@ EXPORTS = [
     "nafgpu_encoder_opts_default", "nafgpu_encoder_opts_from_flags", "nafgpu_encoder_new", "nafgpu_encoder_push",
     "nafgpu_encoder_finish", "nafgpu_encoder_free", "nafgpu_test_hooks",
     "nafgpu_hash64_host_at", "nafgpu_shard_begin", "nafgpu_shard_place", "nafgpu_shard_halo", "nafgpu_shard_export_tail",
-    "nafgpu_shard_import_halo", "nafgpu_shard_finish",
+    "nafgpu_shard_import_halo", "nafgpu_shard_finish", "nafgpu_next_batch",
 ]
 
 
@@ -125,6 +125,7 @@ class Library:
         L.nafgpu_remaining.argtypes = [c_void_p]
         L.nafgpu_remaining.restype = c_uint64
         L.nafgpu_next.argtypes = [c_void_p, POINTER(Record)]
+        L.nafgpu_next_batch.argtypes = [c_void_p, POINTER(Record), ctypes.c_uint64, POINTER(ctypes.c_uint64)]
         L.nafgpu_close.argtypes = [c_void_p]
         L.nafgpu_close.restype = None
         L.nafgpu_last_error.argtypes = [c_void_p, POINTER(Error)]

@@ -137,6 +137,8 @@ struct nafgpu_decoder {
     uint64_t tile_blocks = 0;            // > 0: the sequence / quality sections are decoded in tiles of this many zstd blocks
     bool tiled_output = false;           // ... and their output is held a tile at a time (record iterator)
     Failure fatal;                       // device failure: every later call reports it
+    // the shard protocol is a sequence: begin -> place -> halo / export_tail / import_halo (any order the exchange needs) -> finish
+    enum ShardPhase { kShardIdle, kShardBegun, kShardPlaced } shard_phase = kShardIdle;
     Failure last;
     // iterator state (mod.rs:285-296)
     uint64_t n = 0;                      // records yielded
@@ -565,13 +567,20 @@ void nafgpu_last_error(const nafgpu_decoder *d, nafgpu_error *err) {
     if (d) d->last.to_c(err);
 }
 
-int nafgpu_next(nafgpu_decoder *d, nafgpu_record *rec) {
-    if (!d || !rec) return NAFGPU_E_INVALID_ARG;
+// One record (next_record, mod.rs:356-399).  `in_batch`: the record is not the first of a nafgpu_next_batch call -- the views of
+// the records in front of it must stay valid, so a record whose bytes are not in the host windows yet is left for the next
+// call (NAFGPU_END + 1 = "not now": nothing consumed).
+constexpr int kNotNow = NAFGPU_END + 1;
+static int next_one(nafgpu_decoder *d, nafgpu_record *rec, bool in_batch) {
     if (d->n >= d->header.number_of_sequences) return NAFGPU_END;          // mod.rs:447-449
     if (d->opts.shard_count > 1)
         return fail(d, Failure::make(NAFGPU_E_INVALID_ARG, "record iteration needs the whole archive (shard_count == 1)"));
     Failure f = ensure_decoded(d, true);
     if (!f.ok()) return fail(d, f);
+    if (in_batch && d->use[kLengths] && d->rec_idx < d->rec_ends.size()) {
+        const uint64_t s0 = d->rec_idx ? d->rec_ends[d->rec_idx - 1] : 0, l0 = d->rec_ends[d->rec_idx] - s0;
+        if (l0 && ((d->use[kSequence] && !d->seq_win.holds(s0, l0)) || (d->use[kQuality] && !d->qual_win.holds(s0, l0)))) return kNotNow;
+    }
     std::memset(rec, 0, sizeof *rec);
     // state consumed before an error is not rolled back, as in the reference (mod.rs:391)
     if (d->use[kIds]) {
@@ -630,6 +639,24 @@ int nafgpu_next(nafgpu_decoder *d, nafgpu_record *rec) {
     return NAFGPU_OK;
 }
 
+int nafgpu_next(nafgpu_decoder *d, nafgpu_record *rec) {
+    if (!d || !rec) return NAFGPU_E_INVALID_ARG;
+    return next_one(d, rec, false);
+}
+
+int nafgpu_next_batch(nafgpu_decoder *d, nafgpu_record *recs, uint64_t cap, uint64_t *n_out) {
+    if (!d || !n_out || (cap && !recs)) return NAFGPU_E_INVALID_ARG;
+    *n_out = 0;
+    while (*n_out < cap) {
+        const int rc = next_one(d, recs + *n_out, *n_out != 0);
+        if (rc == kNotNow) break;                                          // the next record needs the host window moved: next call
+        if (rc == NAFGPU_END) return *n_out ? NAFGPU_OK : NAFGPU_END;
+        if (rc != NAFGPU_OK) return rc;                                    // recs[0 .. *n_out) are good; the error is this call's result
+        *n_out += 1;
+    }
+    return NAFGPU_OK;
+}
+
 int nafgpu_decode_all_device(nafgpu_decoder *d, nafgpu_device_result *out) {
     if (!d || !out) return NAFGPU_E_INVALID_ARG;
     if (d->opts.shard_protocol && d->opts.shard_count > 1)
@@ -650,11 +677,13 @@ int nafgpu_shard_begin(nafgpu_decoder *d, nafgpu_shard_summary *mine) {
         return fail(d, Failure::make(NAFGPU_E_INVALID_ARG, "the shard protocol needs opts.shard_protocol = 1 and shard_count > 1"));
     if (!d->fatal.ok()) return fail(d, d->fatal);
     d->decoded = false;
+    d->shard_phase = nafgpu_decoder::kShardIdle;
     Failure f = ensure_uploaded(d, false);
     if (!f.ok()) return fail(d, f);
     ShardSummary m[2];
     f = d->job.shard_begin(m);
     if (!f.ok()) return fail(d, f.status == NAFGPU_E_DEVICE ? (d->fatal = f) : f);
+    d->shard_phase = nafgpu_decoder::kShardBegun;
     std::memset(mine, 0, sizeof *mine);
     for (int w = 0; w < 2; w++) {
         mine->decoded[w] = m[w].decoded;
@@ -667,6 +696,9 @@ int nafgpu_shard_begin(nafgpu_decoder *d, nafgpu_shard_summary *mine) {
 
 int nafgpu_shard_place(nafgpu_decoder *d, const nafgpu_shard_summary *all, int n_ranks) {
     if (!d || !all || n_ranks != d->opts.shard_count) return NAFGPU_E_INVALID_ARG;
+    if (!d->fatal.ok()) return fail(d, d->fatal);
+    if (d->shard_phase != nafgpu_decoder::kShardBegun)
+        return fail(d, Failure::make(NAFGPU_E_INVALID_ARG, "nafgpu_shard_place needs a successful nafgpu_shard_begin in front of it"));
     std::vector<ShardSummary> sq(static_cast<size_t>(n_ranks)), ql(static_cast<size_t>(n_ranks));
     for (int r = 0; r < n_ranks; r++)
         for (int w = 0; w < 2; w++) {
@@ -677,12 +709,19 @@ int nafgpu_shard_place(nafgpu_decoder *d, const nafgpu_shard_summary *all, int n
             t.failed = all[r].failed[w] != 0;
         }
     Failure f = d->job.shard_place(sq.data(), ql.data(), static_cast<uint32_t>(n_ranks));
-    if (!f.ok()) return fail(d, f.status == NAFGPU_E_DEVICE ? (d->fatal = f) : f);
+    if (!f.ok()) {
+        d->shard_phase = nafgpu_decoder::kShardIdle;
+        return fail(d, f.status == NAFGPU_E_DEVICE ? (d->fatal = f) : f);
+    }
+    d->shard_phase = nafgpu_decoder::kShardPlaced;
     return NAFGPU_OK;
 }
 
 int nafgpu_shard_halo(nafgpu_decoder *d, int section, uint64_t *recv_bytes, uint64_t *send_bytes, int *tail_ready) {
     if (!d || !recv_bytes || !send_bytes || !tail_ready || section < 0 || section > 1) return NAFGPU_E_INVALID_ARG;
+    if (!d->fatal.ok()) return fail(d, d->fatal);
+    if (d->shard_phase != nafgpu_decoder::kShardPlaced)
+        return fail(d, Failure::make(NAFGPU_E_INVALID_ARG, "the shard protocol is begin, place, then halo / export_tail / import_halo, then finish"));
     bool ready = true;
     Failure f = d->job.shard_halo(section, recv_bytes, send_bytes, &ready);
     *tail_ready = ready ? 1 : 0;
@@ -692,6 +731,9 @@ int nafgpu_shard_halo(nafgpu_decoder *d, int section, uint64_t *recv_bytes, uint
 
 int nafgpu_shard_export_tail(nafgpu_decoder *d, int section, void *dst, uint64_t n) {
     if (!d || section < 0 || section > 1 || (n && !dst)) return NAFGPU_E_INVALID_ARG;
+    if (!d->fatal.ok()) return fail(d, d->fatal);
+    if (d->shard_phase != nafgpu_decoder::kShardPlaced)
+        return fail(d, Failure::make(NAFGPU_E_INVALID_ARG, "the shard protocol is begin, place, then halo / export_tail / import_halo, then finish"));
     Failure f = d->job.shard_export(section, dst, n);
     if (!f.ok()) return fail(d, f.status == NAFGPU_E_DEVICE ? (d->fatal = f) : f);
     return NAFGPU_OK;
@@ -699,6 +741,9 @@ int nafgpu_shard_export_tail(nafgpu_decoder *d, int section, void *dst, uint64_t
 
 int nafgpu_shard_import_halo(nafgpu_decoder *d, int section, const void *src, uint64_t n) {
     if (!d || section < 0 || section > 1 || (n && !src)) return NAFGPU_E_INVALID_ARG;
+    if (!d->fatal.ok()) return fail(d, d->fatal);
+    if (d->shard_phase != nafgpu_decoder::kShardPlaced)
+        return fail(d, Failure::make(NAFGPU_E_INVALID_ARG, "the shard protocol is begin, place, then halo / export_tail / import_halo, then finish"));
     Failure f = d->job.shard_import(section, src, n);
     if (!f.ok()) return fail(d, f.status == NAFGPU_E_DEVICE ? (d->fatal = f) : f);
     return NAFGPU_OK;
@@ -706,8 +751,12 @@ int nafgpu_shard_import_halo(nafgpu_decoder *d, int section, const void *src, ui
 
 int nafgpu_shard_finish(nafgpu_decoder *d, nafgpu_device_result *out) {
     if (!d || !out) return NAFGPU_E_INVALID_ARG;
+    if (!d->fatal.ok()) return fail(d, d->fatal);
+    if (d->shard_phase != nafgpu_decoder::kShardPlaced)
+        return fail(d, Failure::make(NAFGPU_E_INVALID_ARG, "the shard protocol is begin, place, then halo / export_tail / import_halo, then finish"));
+    d->shard_phase = nafgpu_decoder::kShardIdle;
     Failure f = d->job.shard_finish();
-    if (!f.ok()) return fail(d, d->fatal = f);
+    if (!f.ok()) return fail(d, f.status == NAFGPU_E_DEVICE ? (d->fatal = f) : f);   // (a corrupt range is this decode's error, not the decoder's end)
     f = after_decode(d);
     if (!f.ok()) return fail(d, f);
     d->decoded = true;

@@ -20,6 +20,14 @@ void Failure::to_c(nafgpu_error *e) const {
 bool utf8_valid(const uint8_t *p, uint64_t n) {
     uint64_t i = 0;
     while (i < n) {
+        // (ASCII, the only thing names, sequences and qualities hold in practice: eight bytes a step)
+        while (i + 8 <= n) {
+            uint64_t w;
+            std::memcpy(&w, p + i, 8);
+            if (w & 0x8080808080808080ull) break;
+            i += 8;
+        }
+        if (i >= n) break;
         const uint8_t c = p[i];
         if (c < 0x80) {
             i++;

@@ -858,7 +858,10 @@ Failure SectionJob::shard_summary(hipStream_t stream, ShardSummary *mine) {
     if (last_frame != 0xFFFFFFFFu)
         ok = ok && hip_ok(hipMemcpyAsync(&at_frame, d_blk_base_.as<uint64_t>() + (last_frame - b0 + plan_.halo), 8, hipMemcpyDeviceToHost, stream));
     if (n_seq_blocks_) ok = ok && hip_ok(hipMemcpyAsync(map, d_counters_.bytes() + 192, sizeof map, hipMemcpyDeviceToHost, stream));
-    if (!ok) return Failure::make(NAFGPU_E_DEVICE, "shard summary read-back failed");
+    if (!ok) {
+        (void)hipStreamSynchronize(stream);                  // (copies already enqueued write into this frame's variables)
+        return Failure::make(NAFGPU_E_DEVICE, "shard summary read-back failed");
+    }
     Failure f = check(stream);                               // synchronises
     if (!f.ok()) {
         mine->failed = true;

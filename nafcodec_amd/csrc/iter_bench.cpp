@@ -1,11 +1,12 @@
 // iter_bench.cpp -- times the API the reference exposes: Decoder::from_path + Iterator::next
 // (nafcodec/src/decoder/mod.rs:304-306, 356-399, 444-451) through the C-ABI, the way a Rust / C++ / Python shim drives
 // it: open by path, then nafgpu_next until NAFGPU_END, touching every field it is handed (length sums), first next() to
-// last.  Prints one JSON object.  Built by `make tools` into nafcodec_amd/iter_bench; bench.py runs it (path.iterator).
+// last (with a fourth argument N: through nafgpu_next_batch, N records a call).  Prints one JSON object.  Built by `make tools` into nafcodec_amd/iter_bench; bench.py runs it (path.iterator).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "../../include/nafgpu.h"
 
@@ -55,7 +56,7 @@ static int repeat_mode(const char *path, int device, int repeat) {
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        std::fprintf(stderr, "usage: iter_bench ARCHIVE.naf [device [repeat]]\n");
+        std::fprintf(stderr, "usage: iter_bench ARCHIVE.naf [device [repeat [batch]]]\n");
         return 2;
     }
     if (argc > 3 && std::atoi(argv[3]) > 1) return repeat_mode(argv[1], std::atoi(argv[2]), std::atoi(argv[3]));
@@ -69,31 +70,37 @@ int main(int argc, char **argv) {
         std::fprintf(stderr, "open failed: %s\n", err.message);
         return 1;
     }
-    nafgpu_record rec;
-    unsigned long long n = 0, bases = 0, qual = 0, names = 0, xsum = 0;
+    // `batch` > 0: records come through nafgpu_next_batch, `batch` at a time (what a binding does that hands out millions of reads)
+    const unsigned long long batch = argc > 4 ? std::strtoull(argv[4], nullptr, 10) : 0;
+    std::vector<nafgpu_record> recs(batch ? batch : 1);
+    unsigned long long n = 0, bases = 0, qual = 0, names = 0, xsum = 0, calls = 0;
     const double t0 = now_s();
     double t_first = 0;
     for (;;) {
-        const int rc = nafgpu_next(dec, &rec);
-        if (n == 0) t_first = now_s();
+        uint64_t got = 1;
+        const int rc = batch ? nafgpu_next_batch(dec, recs.data(), batch, &got) : nafgpu_next(dec, recs.data());
+        if (calls++ == 0) t_first = now_s();
         if (rc == NAFGPU_END) break;
         if (rc != NAFGPU_OK) {
             nafgpu_last_error(dec, &err);
             std::fprintf(stderr, "next failed at record %llu: %s\n", n, err.message);
             return 1;
         }
-        n++;
-        bases += rec.sequence.len;
-        qual += rec.quality.len;
-        names += rec.id.len + rec.comment.len;
-        // (one byte of every field is read: the views must be on the host)
-        if (rec.sequence.len) xsum += rec.sequence.ptr[0] + rec.sequence.ptr[rec.sequence.len - 1];
-        if (rec.quality.len) xsum += rec.quality.ptr[rec.quality.len - 1];
+        for (uint64_t k = 0; k < got; k++) {
+            const nafgpu_record &rec = recs[k];
+            n++;
+            bases += rec.sequence.len;
+            qual += rec.quality.len;
+            names += rec.id.len + rec.comment.len;
+            // (one byte of every field is read: the views must be on the host)
+            if (rec.sequence.len) xsum += rec.sequence.ptr[0] + rec.sequence.ptr[rec.sequence.len - 1];
+            if (rec.quality.len) xsum += rec.quality.ptr[rec.quality.len - 1];
+        }
     }
     const double t1 = now_s();
     nafgpu_close(dec);
     std::printf("{\"records\": %llu, \"bases\": %llu, \"quality_bytes\": %llu, \"name_bytes\": %llu, \"open_s\": %.6f, "
-                "\"first_next_s\": %.6f, \"iterate_s\": %.6f, \"total_s\": %.6f, \"xsum\": %llu}\n",
-                n, bases, qual, names, t0 - t_open, t_first - t0, t1 - t0, t1 - t_open, xsum);
+                "\"first_next_s\": %.6f, \"iterate_s\": %.6f, \"total_s\": %.6f, \"xsum\": %llu, \"batch\": %llu, \"calls\": %llu}\n",
+                n, bases, qual, names, t0 - t_open, t_first - t0, t1 - t0, t1 - t_open, xsum, batch, calls);
     return 0;
 }

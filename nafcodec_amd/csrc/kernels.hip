@@ -437,8 +437,10 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     const uint32_t src_rel = have ? static_cast<uint32_t>(ptop - sbase) : 0u;   // sbase is 128-byte aligned: offsets and addresses share their low 7 bits
     uint8_t *const obase = (to_lit ? lit : out) + dbase;
     const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(obase, 0, static_cast<int>(kBufRange), kBufWord3);
+#ifdef NAFGPU_EMU
     const __amdgpu_buffer_rsrc_t rs_src =
         __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(static_cast<uintptr_t>(sbase)), 0, static_cast<int>(kBufRange), kBufWord3);
+#endif
 
     // ---- input.  The stream is consumed in 32-byte aligned PIECES, numbered backwards from the one
     // that holds its last byte (piece j = bytes [ptop - 32 j, ptop - 32 j + 32); ring word 8 j + i is the
@@ -446,17 +448,91 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     // in 32 VGPRs: every line of compressed input is requested from L2 exactly once (with 16- or
     // 32-byte refills the line had been evicted before its next piece was needed: twice the fetch
     // traffic, four times the requests -- the refill loads then cost as much as the decode itself).
+    //
+    // The wait for a line is in the author's hands.  Vector memory operations retire in order, so hipcc's own wait in front of
+    // the first use of a line -- requested a round earlier -- is vmcnt(0) whenever a data-dependent number of stores was issued
+    // in between (the flush), and that also waits for those stores: written a moment ago, to 64 scattered fronts.  Here the
+    // eight loads of a line are ONE asm statement whose outputs are tied to the registers that hold the line ("+v": the
+    // load overwrites the old line in place, no copy can come between), the wait is `s_waitcnt vmcnt(k)` with k = the store
+    // instructions issued since (a scalar branch picks the immediate; any other vector memory operation in between -- the
+    // byte-wise units, SEG's sequence reads -- only makes the true count larger than k, and a wait for more is a safe wait),
+    // and the registers pass through the wait statement, so no use of theirs can move in front of it.  hipcc does not know the
+    // line registers are in flight between the two statements: nothing but land_piece reads them, and a last wait behind the
+    // main loop keeps them out of the allocator's hands until the last load has landed.  (Round 1 found asm loads unsafe with
+    // plain "=v" outputs -- the allocator reused them; tied operands and the wait that carries them are what changed.
+    // Round 3 had measured the relaxed wait at 0.8 ms of the 10 GB archive's 10.8 with filler stores that cost 1.5.)
     u32x4 line[8];                       // line[2 q], line[2 q + 1] = piece at offset 32 q of the line
     uint32_t line_rel = 0;               // offset (from sbase) of the line held in `line`
 #pragma unroll
     for (int i = 0; i < 8; i++) line[i] = u32x4{0, 0, 0, 0};
+#ifndef NAFGPU_EMU
+    u32x4 srd_src;                       // the input descriptor as four scalars (uniform: sbase is)
+    srd_src[0] = static_cast<uint32_t>(sbase);
+    srd_src[1] = static_cast<uint32_t>(sbase >> 32) & 0xFFFFu;
+    srd_src[2] = kBufRange;
+    srd_src[3] = static_cast<uint32_t>(kBufWord3);
+    auto load_line = [&](uint32_t rel) {
+        line_rel = rel;
+        asm volatile("buffer_load_dwordx4 %0, %8, %9, 0 offen\n\t"
+                     "buffer_load_dwordx4 %1, %8, %9, 0 offen offset:16\n\t"
+                     "buffer_load_dwordx4 %2, %8, %9, 0 offen offset:32\n\t"
+                     "buffer_load_dwordx4 %3, %8, %9, 0 offen offset:48\n\t"
+                     "buffer_load_dwordx4 %4, %8, %9, 0 offen offset:64\n\t"
+                     "buffer_load_dwordx4 %5, %8, %9, 0 offen offset:80\n\t"
+                     "buffer_load_dwordx4 %6, %8, %9, 0 offen offset:96\n\t"
+                     "buffer_load_dwordx4 %7, %8, %9, 0 offen offset:112"
+                     : "+v"(line[0]), "+v"(line[1]), "+v"(line[2]), "+v"(line[3]), "+v"(line[4]), "+v"(line[5]), "+v"(line[6]), "+v"(line[7])
+                     : "v"(rel), "s"(srd_src)
+                     : "memory");
+    };
+    // `younger` (uniform): vector memory instructions KNOWN to have been issued since the loads that must have landed.
+    // s_waitcnt takes an immediate only: a computed jump into a table of {s_waitcnt vmcnt(k); s_branch end} pairs, eight
+    // bytes each (seven scalar instructions in all; hipcc's own lowering of a switch in this loop is a chain of twenty).
+    // Behind it ONE empty statement carries the line registers, so that every use of theirs comes after it -- and, the
+    // statements being volatile, after the wait.
+    auto wait_line = [&](uint32_t younger) {
+        asm volatile("s_min_u32 s92, %0, 16\n\t"
+                     "s_getpc_b64 s[90:91]\n\t"            // = the address of the next instruction
+                     "s_lshl3_add_u32 s92, s92, 16\n\t"     //   + 0
+                     "s_add_u32 s90, s90, s92\n\t"          //   + 4
+                     "s_addc_u32 s91, s91, 0\n\t"           //   + 8
+                     "s_setpc_b64 s[90:91]\n\t"             //   + 12; the table begins at + 16
+                     "s_waitcnt vmcnt(0)\n\ts_branch .Lnafgpu_wl_%=\n\t"
+                     "s_waitcnt vmcnt(1)\n\ts_branch .Lnafgpu_wl_%=\n\t"
+                     "s_waitcnt vmcnt(2)\n\ts_branch .Lnafgpu_wl_%=\n\t"
+                     "s_waitcnt vmcnt(3)\n\ts_branch .Lnafgpu_wl_%=\n\t"
+                     "s_waitcnt vmcnt(4)\n\ts_branch .Lnafgpu_wl_%=\n\t"
+                     "s_waitcnt vmcnt(5)\n\ts_branch .Lnafgpu_wl_%=\n\t"
+                     "s_waitcnt vmcnt(6)\n\ts_branch .Lnafgpu_wl_%=\n\t"
+                     "s_waitcnt vmcnt(7)\n\ts_branch .Lnafgpu_wl_%=\n\t"
+                     "s_waitcnt vmcnt(8)\n\ts_branch .Lnafgpu_wl_%=\n\t"
+                     "s_waitcnt vmcnt(9)\n\ts_branch .Lnafgpu_wl_%=\n\t"
+                     "s_waitcnt vmcnt(10)\n\ts_branch .Lnafgpu_wl_%=\n\t"
+                     "s_waitcnt vmcnt(11)\n\ts_branch .Lnafgpu_wl_%=\n\t"
+                     "s_waitcnt vmcnt(12)\n\ts_branch .Lnafgpu_wl_%=\n\t"
+                     "s_waitcnt vmcnt(13)\n\ts_branch .Lnafgpu_wl_%=\n\t"
+                     "s_waitcnt vmcnt(14)\n\ts_branch .Lnafgpu_wl_%=\n\t"
+                     "s_waitcnt vmcnt(15)\n\ts_branch .Lnafgpu_wl_%=\n\t"
+                     "s_waitcnt vmcnt(16)\n"
+                     ".Lnafgpu_wl_%=:"
+                     :
+                     : "s"(__builtin_amdgcn_readfirstlane(younger))
+                     : "s90", "s91", "s92", "scc", "memory");
+        asm volatile(""
+                     : "+v"(line[0]), "+v"(line[1]), "+v"(line[2]), "+v"(line[3]), "+v"(line[4]), "+v"(line[5]), "+v"(line[6]), "+v"(line[7])
+                     :
+                     : "memory");
+    };
+#else
     auto load_line = [&](uint32_t rel) {
         line_rel = rel;
 #pragma unroll
         for (int i = 0; i < 8; i++) line[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, rel + 16u * i, 0, 0);
     };
+    auto wait_line = [&](uint32_t) {};
+#endif
     // piece `wp` -> ring words 8 wp .. 8 wp + 7 (mod 16); requests the next lower line once this one is used up
-    auto land_piece = [&]() {
+    auto land_piece = [&]() -> bool {                      // (the caller has waited for the line: wait_line)
         const uint32_t pa = src_rel - 32u * wp;
         const uint32_t q = (pa >> 5) & 3u;
         const bool b0 = q & 1u, b1 = q & 2u;
@@ -468,12 +544,14 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
             r[(4 + i) * 64] = sel(line[0][3 - i], line[2][3 - i], line[4][3 - i], line[6][3 - i]);
         }
         wp++;
-        if (q == 0) load_line(line_rel - 128u);            // wanted one or two rounds from now
+        return q == 0;                                     // the line is used up: the caller requests the next lower one (load_line)
     };
+    if (have) load_line(src_rel & ~127u);
+    wait_line(0);
+    if (have && land_piece()) load_line(line_rel - 128u);  // the ring holds two pieces
+    wait_line(0);
     if (have) {
-        load_line(src_rel & ~127u);
-        land_piece();                                      // the ring holds two pieces
-        land_piece();
+        if (land_piece()) load_line(line_rel - 128u);
         const uint32_t *rw = reinterpret_cast<const uint32_t *>(s_ring) + lane;
         L.hi = rw[rp0 * 64];
         L.lo = rw[(rp0 + 1) * 64];
@@ -509,7 +587,7 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         if (n_part) s_pv[lane] = (h > rbase ? h - rbase : 0u) | (avail << 8);   // only the byte-wise path needs these
         return static_cast<uint32_t>(__popcll(m));
     };
-    auto flush = [&](uint32_t n_ready) {
+    auto flush = [&](uint32_t n_ready) {                   // (issues exactly ceil(n_ready / kRowsPerStore) store instructions, and the byte-wise ones)
         uint32_t c[kStoreIters];
         {
             const uint4 c0v = *reinterpret_cast<const uint4 *>(&s_cunit[grp * kStoreIters]);
@@ -787,6 +865,7 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         const uint32_t n_ready = publish(seg_done);
         wave_sync();
         flush(n_ready);
+        const uint32_t n_stores = (n_ready + kRowsPerStore - 1u) / kRowsPerStore;   // store instructions the flush issued at least
         wave_sync();
         if (static_cast<uint32_t>(wa - orow) >= kUnit) {   // the flush above took this row's first unit: < 64 bytes stay
             const uint8_t *mv = orow + kUnit;
@@ -831,10 +910,17 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         {
             const uint32_t rp_mod = ((L.ra >> 8) - 2u) & 15u;
             const uint32_t d = (rp_mod - 8u * wp) & 15u;
-            if (have && d >= 8u && !(kAblate & 4u)) land_piece();
+            const bool lands = have && d >= 8u && !(kAblate & 4u);
+            // The wave has ONE counter: the wait serves all the lanes that land now.  (Measured and dropped: leaving the loads
+            // of the round before in flight as well -- vmcnt(stores + 8) unless a landing lane made its request only then --
+            // so that a line has two rounds to arrive: 10.79 ms against 10.63 for the round-3 build in the same processes,
+            // profiles/r04_k1_wait_experiments.log.  The landing does not wait for memory to any extent that matters.)
+            if (__any(lands ? 1 : 0)) wait_line(n_stores);
+            if (lands && land_piece()) load_line(line_rel - 128u);     // wanted one or two rounds from now
         }
         any = __any((rbase + static_cast<uint32_t>(wa - orow) < end_abs || (SEG && syms_after != 0)) ? 1 : 0);
     }
+    wait_line(0);                                          // (a line requested by the last landing may still be on its way: see load_line)
     for (uint32_t t = 0; t < 2; t++) {                     // at most kUnit - 1 + 64 bytes are left in a row
         const uint32_t n_ready = publish(true);
         wave_sync();
@@ -870,7 +956,12 @@ __device__ inline uint32_t rep_minus_one(uint32_t r) {      // rep - 1 for a con
 // `tok` (an offset, or "incoming rep[slot] - d") applied after the map `f` (three entries of the same kind): maps compose
 __device__ inline uint32_t rep_apply_entry(uint32_t tok, const uint32_t *f, bool *bad) {
     if (!(tok & kRepToken)) return tok;
-    const uint32_t fv = f[(tok >> 24) & 3u], d = tok & 0xFFFFFFu;
+    const uint32_t slot = (tok >> 24) & 3u, d = tok & 0xFFFFFFu;
+    if (slot > 2u) {                                        // (three repeat offsets: a token never names a fourth)
+        *bad = true;
+        return 1;
+    }
+    const uint32_t fv = f[slot];
     if (!(fv & kRepToken)) {
         if (fv <= d) {
             *bad = true;

@@ -127,7 +127,12 @@ constexpr uint32_t kRepToken = 0x80000000u;
 // the kernels' rep_apply_entry (shard protocol: the ranks' maps are put together on the host).
 inline uint32_t rep_compose(uint32_t tok, const uint32_t *f, bool *bad) {
     if (!(tok & kRepToken)) return tok;
-    const uint32_t fv = f[(tok >> 24) & 3u], d = tok & 0xFFFFFFu;
+    const uint32_t slot = (tok >> 24) & 3u, d = tok & 0xFFFFFFu;
+    if (slot > 2u) {                                        // (three repeat offsets: a token never names a fourth)
+        *bad = true;
+        return 1;
+    }
+    const uint32_t fv = f[slot];
     if (!(fv & kRepToken)) {
         if (fv <= d) {
             *bad = true;

@@ -48,6 +48,7 @@ class Decoder:
                  device=-1, spec_mask=False, shard_rank=0, shard_count=1, shard_protocol=False, _lib=None):
         self._lib = _lib or _ffi.default()
         self._h = None
+        self._pending_error = None
         opts = _ffi.Opts()
         self._lib.c.nafgpu_opts_default(byref(opts))
         opts.id, opts.comment, opts.sequence, opts.quality, opts.mask = map(int, (id, comment, sequence, quality, mask))
@@ -141,6 +142,37 @@ class Decoder:
 
         return Record(id=text(rec.id), comment=text(rec.comment), sequence=text(rec.sequence),
                       quality=text(rec.quality), length=rec.length if rec.has_length else None)
+
+    def read_batch(self, n=4096):
+        """Up to `n` records in ONE call into the library (nafgpu_next_batch): the records `n` calls of read() would return, in
+        order; fewer when the archive ends or the next record's bytes are not on the host yet, [] at the end.  An error
+        raised by record k of the batch is raised by this call AFTER records 0 .. k-1 were collected: they are returned by
+        the call, the exception is kept and raised by the next one (so no record is lost and the order of events is the
+        one read() gives)."""
+        if self._pending_error is not None:
+            e, self._pending_error = self._pending_error, None
+            raise e
+        recs = (_ffi.Record * n)()
+        got = ctypes.c_uint64()
+        rc = self._lib.c.nafgpu_next_batch(self._h, recs, n, byref(got))
+
+        def text(f):
+            if not f.present:
+                return None
+            return ctypes.string_at(f.ptr, f.len).decode("utf-8") if f.len else ""
+
+        out = [Record(id=text(r.id), comment=text(r.comment), sequence=text(r.sequence), quality=text(r.quality),
+                      length=r.length if r.has_length else None) for r in recs[:got.value]]
+        if rc not in (_ffi.OK, _ffi.END):
+            err = _ffi.Error()
+            self._lib.c.nafgpu_last_error(self._h, byref(err))
+            try:
+                _raise(err)
+            except Exception as e:                          # noqa: BLE001
+                if not out:
+                    raise
+                self._pending_error = e
+        return out
 
     def __len__(self):
         return int(self._lib.c.nafgpu_remaining(self._h))

@@ -69,9 +69,17 @@ def gather_placement(dist, torch, bases, packed_bytes, first_record, carry, tota
 #   3. every rank places its literals and resolves every match that does not reach -- directly or through other
 #      matches -- into that window;
 #   4. the windows travel down the line, point to point (ncclSend / ncclRecv, at most window_size bytes each): a rank
-#      whose last window is final already (nothing pending touches it: the usual case) sends at once and receives
-#      afterwards, the others receive, finish, send; the serial part is the handful of matches that waited.
+#      whose last window is final already (nothing pending touches it: the usual case) posts its send and its receive as
+#      one group, the others receive, finish, send; the serial part is the handful of matches that waited.
 SUMMARY_BYTES = 64
+
+# Where the protocol stands in this process: {"step": ..., "section": ..., "rank": ...}.  A caller that puts a time limit around
+# decode_sharded (bench.py) names the step that did not return.
+PROGRESS = {"step": None, "section": None, "rank": None}
+
+
+def _at(step, section=None):
+    PROGRESS["step"], PROGRESS["section"] = step, section
 
 
 def decode_sharded(dec, dist, torch, device):
@@ -79,9 +87,14 @@ def decode_sharded(dec, dist, torch, device):
     process group: returns the nafgpu_device_result of this rank's share.  `device`: "cuda" (RCCL) or "cpu" (gloo).
     A rank that fails (a corrupt block in its range, say) still takes part in every exchange -- nobody is left waiting in
     a receive -- and every rank raises: the ranks agree on one flag (a 1-element all-reduce) after the placement step, and
-    skip the window exchange together when any of them has failed by then, and on one more at the end."""
+    skip the window exchange together when any of them has failed by then, and on one more at the end.
+    The windows of a section travel as ONE group of point-to-point operations per rank (`batch_isend_irecv`: on RCCL a
+    single grouped launch): a rank whose tail is final posts its send and its receive together; a rank whose tail waits
+    for the window in front posts the receive, finishes, and then posts the send."""
     rank, world = dist.get_rank(), dist.get_world_size()
+    PROGRESS["rank"] = rank
     error = None
+    _at("shard_begin")
     try:
         summary = dec.shard_begin()
     except Exception as e:                                 # noqa: BLE001 -- carried past the collectives, raised below
@@ -89,54 +102,72 @@ def decode_sharded(dec, dist, torch, device):
         summary = bytes(56) + b"\x01\x01" + bytes(6)        # nafgpu_shard_summary with failed[0] = failed[1] = 1
     mine = torch.frombuffer(bytearray(summary), dtype=torch.uint8).to(device)
     everyone = torch.empty(SUMMARY_BYTES * world, dtype=torch.uint8, device=device)
+    _at("all_gather(summaries)")
     dist.all_gather_into_tensor(everyone, mine)
     halo = [(0, 0, True), (0, 0, True)]
     if error is None:
         try:
+            _at("shard_place")
             dec.shard_place(everyone.cpu().numpy().tobytes())
+            _at("shard_halo")
             halo = [dec.shard_halo(0), dec.shard_halo(1)]  # (synchronises: what the placement step found wrong is known here)
         except Exception as e:                             # noqa: BLE001
             error = e
     flag = torch.tensor([0 if error is None else 1], dtype=torch.int32, device=device)
+    _at("all_reduce(error flag after placement)")
     dist.all_reduce(flag, op=dist.ReduceOp.MAX)
     if int(flag.item()) != 0:
+        _at("failed")
         if error is not None:
             raise error
         raise OSError(0, "zstd: another rank could not decode its part of the archive")
+
+    def exchange(ops, what, section):                      # one group: every operation of the list is in flight at once
+        _at(what, section)
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if device != "cpu":
+            torch.cuda.current_stream().synchronize()
+
     for section in (0, 1):
         recv_n, send_n, ready = halo[section]
-        pending = None
-        sbuf = rbuf = None
-        if send_n and rank + 1 < world:
-            sbuf = torch.empty(send_n, dtype=torch.uint8, device=device)
-        if send_n and rank + 1 < world and ready:           # the tail is final: it leaves before anything is received
+        sends = bool(send_n) and rank + 1 < world
+        recvs = bool(recv_n) and rank > 0
+        sbuf = torch.empty(send_n, dtype=torch.uint8, device=device) if sends else None
+        rbuf = torch.empty(recv_n, dtype=torch.uint8, device=device) if recvs else None
+        ops = []
+        if sends and ready:                                 # the tail is final: it leaves together with the receive
+            _at("shard_export_tail", section)
             dec.shard_export_tail(section, sbuf.data_ptr(), send_n)
-            pending = dist.isend(sbuf, rank + 1)
-        if recv_n and rank > 0:
-            rbuf = torch.empty(recv_n, dtype=torch.uint8, device=device)
-            dist.recv(rbuf, rank - 1)
-            if device != "cpu":
-                torch.cuda.current_stream().synchronize()
+            ops.append(dist.P2POp(dist.isend, sbuf, rank + 1))
+        if recvs:
+            ops.append(dist.P2POp(dist.irecv, rbuf, rank - 1))
+        if ops:
+            exchange(ops, "window exchange (%s)" % ("send + recv" if len(ops) == 2 else "send" if sends and ready else "recv"), section)
+        if recvs:
             try:
+                _at("shard_import_halo", section)
                 dec.shard_import_halo(section, rbuf.data_ptr(), recv_n)
             except Exception as e:                         # noqa: BLE001 -- the ranks behind still get their window (of a failed decode)
                 error = error or e
-        if send_n and rank + 1 < world and not ready:
+        if sends and not ready:
             try:
+                _at("shard_export_tail", section)
                 dec.shard_export_tail(section, sbuf.data_ptr(), send_n)
             except Exception as e:                         # noqa: BLE001
                 error = error or e
-            pending = dist.isend(sbuf, rank + 1)
-        if pending is not None:
-            pending.wait()
+            exchange([dist.P2POp(dist.isend, sbuf, rank + 1)], "window exchange (send after finishing)", section)
     res = None
     if error is None:
         try:
+            _at("shard_finish")
             res = dec.shard_finish()                       # (synchronises: a corrupt block in this rank's range is known here at the latest)
         except Exception as e:                             # noqa: BLE001
             error = e
     flag = torch.tensor([0 if error is None else 1], dtype=torch.int32, device=device)
+    _at("all_reduce(error flag at the end)")
     dist.all_reduce(flag, op=dist.ReduceOp.MAX)            # one archive, one verdict: every rank raises when any of them failed
+    _at("done" if error is None and int(flag.item()) == 0 else "failed")
     if error is not None:
         raise error
     if int(flag.item()) != 0:

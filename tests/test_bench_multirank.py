@@ -51,6 +51,7 @@ def test_bench_contract(world):
         assert j["config"]["oracle_checked_bases"] > 0
     else:
         assert "ONE archive" in j["config"]["sharding"]      # configs[4]: block ranges of one archive, not one archive per rank
+        assert j["backend"].startswith("gloo") and j["ranks"] == world and len(j["devices"]) == world   # the run describes itself
         if zstd_ref.available():                             # the archive WITH LZ sequences went through the shard protocol on the same ranks
             real = j["path"]["real_genome"]
             assert real["n_gpus"] == world and real["bases"] == 2 * 5488676 and "shard protocol" in real["workload"]
@@ -59,7 +60,8 @@ def test_bench_contract(world):
 
 def test_headline_line_survives_a_sharded_leg_that_does_not_finish():
     """The second workload of the multi-rank run has a time limit of its own: when it runs out every rank leaves, and rank 0
-    still prints the one line -- with the headline in it and the failure named where the leg's numbers would be."""
+    still prints the one line -- with the headline in it and the failure named where the leg's numbers would be (which step
+    of the protocol, which rank) -- but the run's status is NOT zero: a stall on N GPUs must not look like a finished run."""
     if not zstd_ref.available():
         pytest.skip("libzstd not loadable")
     csrc = os.path.join(ROOT, "nafcodec_amd", "csrc")
@@ -69,12 +71,13 @@ def test_headline_line_survives_a_sharded_leg_that_does_not_finish():
            "--bases", "300001", "--real-copies-per-gpu", "1", "--sharded-leg-limit", "0",
            "--rehearsal-lib", os.path.join(ROOT, "tests", "emu", "_build", "libnafgpu_emu.so")]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert p.returncode != 0, p.stdout[-2000:] + p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and "passed" in j["config"]["workload"]
-    assert "not finished" in j["path"]["real_genome"]["error"]
+    assert "not finished" in j["path"]["real_genome"]["error"] and "rank 0 at step" in j["path"]["real_genome"]["where"]
+    assert "sharded real-genome leg" in p.stderr
 
 
 def test_real_genome_leg_runs_and_checks_itself():

@@ -153,6 +153,51 @@ def test_block_range_sharding(emu):
     cases.check_sharding(emu, 1_500_000, False, worlds=(2, 8))
 
 
+def test_next_batch_equals_next(emu, all_cases, monkeypatch):
+    """nafgpu_next_batch hands out exactly what as many calls of nafgpu_next do -- fixtures, every shared case (malformed
+    archives included: the error comes with the call that reaches it, the records in front of it are delivered, the iterator
+    goes on), and an archive whose output is held a tile at a time (batches end where the host window has to move)."""
+    from conftest import golden_bytes
+    for name in ("LuxC", "masked", "phix", "CP040672"):
+        assert cases.check_next_batch(golden_bytes(name + ".naf"), lib=emu) > 0
+    for name, blob, opts in all_cases:
+        cases.check_next_batch(blob, opts, lib=emu, caps=(2, 4096))
+    monkeypatch.setenv("NAFGPU_TILE_KIB", "256")
+    cases.check_next_batch(golden_bytes("NZ_AAEN01000029.naf"), lib=emu, caps=(7, 4096))
+
+
+def test_archive_ends_against_the_oracle(emu):
+    """cases.check_archive_ends at a size the harness decodes in seconds (the GPU suite runs it on the 40-Gbase archive)."""
+    cases.check_archive_ends(emu, 40_000_001, 0x4E4146, 70)
+
+
+def test_shard_protocol_calls_out_of_order_are_refused(emu):
+    """The protocol is begin -> place -> halo / export / import -> finish: anything else is NAFGPU_E_INVALID_ARG, never a
+    decode over buffers that were not prepared."""
+    import ctypes
+    import io
+    from nafcodec_amd import _ffi
+    from nafcodec_amd.decoder import Decoder
+    from nafcodec_amd.sharding import decode_sharded_local
+    name, blob, want_seq, _q, _l = next(x for x in cases.lz_shard_archives(1) if x[0] == "real_genome_l1")
+    decs = [Decoder(io.BytesIO(blob), shard_rank=r, shard_count=2, shard_protocol=True, _lib=emu) for r in range(2)]
+    d = decs[1]
+    res, n, m, ready = _ffi.DeviceResult(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_int()
+    c = emu.c
+    assert c.nafgpu_shard_finish(d._h, ctypes.byref(res)) == _ffi.E_INVALID_ARG            # nothing begun
+    assert c.nafgpu_shard_halo(d._h, 0, ctypes.byref(n), ctypes.byref(m), ctypes.byref(ready)) == _ffi.E_INVALID_ARG
+    everyone = b"".join(x.shard_begin() for x in decs)
+    assert c.nafgpu_shard_finish(d._h, ctypes.byref(res)) == _ffi.E_INVALID_ARG            # begun, not placed
+    assert c.nafgpu_shard_import_halo(d._h, 0, everyone, 0) == _ffi.E_INVALID_ARG
+    # ... and the decoders are still good for a whole, ordered run
+    out = decode_sharded_local(decs)
+    got = b"".join(x.copy_to_host(r.d_sequence, r.n_bases) for x, r in zip(decs, out))
+    assert got == want_seq
+    assert c.nafgpu_shard_finish(d._h, ctypes.byref(res)) == _ffi.E_INVALID_ARG            # finished: a second finish needs a new begin
+    for x in decs:
+        x.close()
+
+
 def test_shard_protocol_on_sections_with_lz_sequences(emu):
     """SURVEY 8e for archives as found in the wild: sections WITH LZ sequences over 2 / 3 / 8 block ranges through the
     shard protocol (nafgpu_shard_*) -- real-genome statistics, level-3 DNA in one and in three frames, FASTQ-like reads

@@ -232,6 +232,22 @@ def test_gigabase_archive_against_the_oracle(lib):
         lib.c.nafgpu_synth_free(ctypes.byref(arc))
 
 
+def test_next_batch_equals_next(lib):
+    """nafgpu_next_batch against nafgpu_next through the C-ABI on the GPU: fixtures, the shared cases at 4x the harness
+    sizes (malformed archives included), batch sizes 1 .. 4096."""
+    for name in FIXTURES:
+        assert cases.check_next_batch(golden_bytes(name + ".naf")) > 0
+    for name, blob, opts in cases.build_cases(scale=4):
+        cases.check_next_batch(blob, opts, caps=(3, 4096))
+
+
+def test_both_ends_of_the_full_size_archive_against_the_oracle(lib):
+    """The bench's own archive (configs[1]: 40 Gbases, 10 GB) at FULL size.  `bench.py` checks its decode against the
+    writer's checksums -- product code vouching for product code; here the first and the last 256 Mi bases of the decode
+    are pinned on the oracle (cases.check_archive_ends)."""
+    cases.check_archive_ends(lib, 40_000_000_000, 0x4E4146, 1024)
+
+
 def test_hash_sees_compensating_and_swapped_bytes(lib):
     """The checksum mixes every 8-byte word with its position before adding: errors that a linear sum
     would let cancel (+1 here, -1 there; two words swapped) change it."""

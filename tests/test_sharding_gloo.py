@@ -1,4 +1,4 @@
-"""The N>1 exchange step (nafcodec_amd/sharding.py) on CPU: two gloo ranks, no GPU."""
+"""The N>1 exchange steps (nafcodec_amd/sharding.py) on CPU: gloo ranks (2, 3 and 8), no GPU."""
 import os
 import socket
 import subprocess
@@ -59,7 +59,7 @@ dist.init_process_group("gloo")
 r, w = dist.get_rank(), dist.get_world_size()
 emu = _ffi.Library(os.path.join(%r, "tests", "emu", "_build", "libnafgpu_emu.so"))
 for name, blob, want_seq, want_qual, lens in cases.lz_shard_archives(1):
-    if name not in ("real_genome_l1", "fastq_like_l1"):
+    if name not in os.environ.get("NAFGPU_TEST_ARCHIVES", "real_genome_l1,fastq_like_l1").split(","):
         continue
     dec = Decoder(io.BytesIO(blob), shard_rank=r, shard_count=w, shard_protocol=True, _lib=emu)
     for _ in range(2):                                     # (a second decode: the protocol starts over)
@@ -79,7 +79,7 @@ for name, blob, want_seq, want_qual, lens in cases.lz_shard_archives(1):
     dist.all_reduce(offs)
     assert list(offs) == sorted(offs) and int(offs[0]) == 0
     dec.close()
-    if name == "real_genome_l1":
+    if name == "real_genome_l1" and w <= 3:
         # damage inside ONE rank's range (a stretch of a Huffman stream zeroed): that rank finds out while it decodes, the
         # others learn of it through the protocol -- nobody waits for a window that never comes, every rank raises
         bad = bytearray(blob)
@@ -110,10 +110,14 @@ def test_shard_protocol_over_gloo_two_and_three_ranks(tmp_path):
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     script = tmp_path / "protocol_worker.py"
     script.write_text(PROTOCOL_WORKER % (ROOT, ROOT, ROOT))
-    for n in (2, 3):
+    for n in (2, 3, 8):
+        # (eight ranks: the world of configs[4]; the FASTQ-like archive only -- both of its sections are swept, the ranks in
+        # the middle both receive and send a window, posted as one group)
+        env = dict(os.environ, OMP_NUM_THREADS="1")
+        if n == 8:
+            env["NAFGPU_TEST_ARCHIVES"] = "fastq_like_l1"
         p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
                             "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
-                           capture_output=True, text=True, timeout=900,
-                           env=dict(os.environ, OMP_NUM_THREADS="1"))
+                           capture_output=True, text=True, timeout=900, env=env)
         assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
         assert p.stdout.count("ok") == n

@@ -15,7 +15,7 @@ packed = (nib[0::2] | (nib[1::2] << 4)).astype(np.uint8).tobytes()
 qalpha = np.frombuffer(b"#8CGGGGGGGGGG<AFFFJJJJJJJJJJJJJJ", dtype=np.uint8)
 qual = qalpha[rng.integers(0, len(qalpha), n_bases)].tobytes()
 lens = np.full(n_reads, L, dtype="<u4").tobytes()
-for level in (1, 3):
+for level in ([int(sys.argv[2])] if len(sys.argv) > 2 else [1, 3]):
     t = time.time()
     secs = [(0x08, len(lens), zstd_ref.compress_magicless(lens, level, True)),
             (0x02, n_bases, zstd_ref.compress_magicless(packed, level, True)),
@@ -28,7 +28,8 @@ for level in (1, 3):
     for path in [None] + [x for x in os.environ.get("NAFGPU_PROBE_LIBS", "").split(",") if x]:
         lib = _ffi.default() if path is None else _ffi.Library(os.path.join(R, path))
         dec = nafcodec_amd.Decoder(io.BytesIO(bytes(blob)), _lib=lib)
-        res = dec.decode_all_device(); res = dec.decode_all_device()
+        res = dec.decode_all_device()
+        if not os.environ.get("NAFGPU_PROBE_ONE_DECODE"): res = dec.decode_all_device()
         okq = dec.hash_device(res.d_quality, res.n_quality) == lib.c.nafgpu_hash64_host(qual, len(qual))
         print("level", level, "product" if path is None else path, "reads", n_reads, "bases", n_bases, "archive MB %.1f" % (len(blob) / 1e6),
               "compress s %.1f" % tc, "qual ok", okq, "records", res.n_records,

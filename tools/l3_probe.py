@@ -6,7 +6,7 @@ import nafcodec_amd
 from nafcodec_amd import _ffi
 rng = np.random.default_rng(1)
 n_packed = int(float(sys.argv[1]) if len(sys.argv) > 1 else 64e6)
-for level in (1, 3):
+for level in ([int(sys.argv[2])] if len(sys.argv) > 2 else [1, 3]):
     codes = np.array([1, 2, 4, 8], dtype=np.uint8)
     packed = (codes[rng.integers(0, 4, n_packed)] | (codes[rng.integers(0, 4, n_packed)] << 4)).astype(np.uint8).tobytes()
     t = time.time(); payload = zstd_ref.compress_magicless(packed, level, True); tc = time.time() - t
@@ -22,7 +22,8 @@ for level in (1, 3):
     for path in [None] + [x for x in os.environ.get("NAFGPU_PROBE_LIBS", "").split(",") if x]:
         lib = _ffi.default() if path is None else _ffi.Library(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), path))
         dec = nafcodec_amd.Decoder(io.BytesIO(blob), _lib=lib)
-        res = dec.decode_all_device(); res = dec.decode_all_device()
+        res = dec.decode_all_device()
+        if not os.environ.get("NAFGPU_PROBE_ONE_DECODE"): res = dec.decode_all_device()
         ok = dec.hash_device(res.d_sequence, res.n_bases) == want_hash
         print("level", level, "product" if path is None else path, "bases", n_bases, "compress s %.1f" % tc, "B/base %.4f" % (len(payload) / n_bases), "ok", ok,
               "ms total %.2f huf %.2f seq_lz %.2f other %.2f" % (res.ms_total, res.ms_huf, res.ms_seq_lz, res.ms_other),

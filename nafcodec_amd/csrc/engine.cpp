@@ -242,6 +242,19 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
     tiles_.clear();
     loaded_tile_ = 0xFFFFFFFFu;
     tiles_done_ = 0;
+    {   // sub-streams (zplan.cpp: g_split_target): a section is cut when its streams are fewer than half the lanes named here --
+        // a quarter of what the chip keeps resident (eight waves per CU), the two passes in front being work too
+        static const uint32_t lanes = [] {
+            hipDeviceProp_t p;
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            const int cus = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+            return static_cast<uint32_t>(cus) * 256u;
+        }();
+        const char *fs = hook_env("NAFGPU_HUF_SPLIT");     // tests: that many parts per stream whatever the size (0: never)
+        const uint32_t force = fs ? static_cast<uint32_t>(std::atoi(fs)) : 0u;
+        set_huf_split(fs && force == 0 ? 0u : lanes, force);
+    }
     const double t0 = now_ms();
     bool truncated = false;
     std::string err = walk_zstd(host_payload, n, &master_, &truncated);
@@ -395,7 +408,7 @@ Failure SectionJob::load_tile(uint32_t t, hipStream_t stream) {
                      t, tiles_.size(), n_blocks_, n_streams_, n_seq_blocks_, static_cast<unsigned long long>(plan_.n_sequences),
                      static_cast<unsigned long long>(plan_.lit_bytes), static_cast<unsigned long long>(plan_.src_hi - plan_.src_lo));
         for (const HufClass &c : classes_)
-            std::fprintf(stderr, " {%u tasks, tbl %u, %s%s, lds %u B}", c.n_tasks, c.tbl, c.to_lit ? "lit" : "out", c.seg ? "+seg" : "", c.lds_bytes);
+            std::fprintf(stderr, " {%u tasks, tbl %u, %s%s, lds %u B, %u parts}", c.n_tasks, c.tbl, c.to_lit ? "lit" : "out", c.seg ? "+seg" : "", c.lds_bytes, c.split);
         uint64_t cells = 0;
         for (const SeqBlock &sb : plan_.seq_blocks) cells += (1u << sb.ll_al) + (1u << sb.of_al) + (1u << sb.ml_al);
         uint64_t fresh = 0;                                    // tables that are not the block in front's (Repeat_Mode)
@@ -479,6 +492,9 @@ Failure SectionJob::load_tile(uint32_t t, hipStream_t stream) {
          d_rep_scratch_.alloc((n_seq_blocks_ / 64 + 1) * 24 + 16) &&
          d_blk_pending_.alloc(n_seq_blocks_ * 4 + 16) &&
          (xxh_segs_.empty() || d_xxh_carry_.alloc(2 * sizeof(XxhCarry)));
+    bool parts = false;                                        // streams in parts (plan.h: HufStream::sub): a HufSync record per part
+    for (const HufClass &c : plan_.classes) parts = parts || c.split > 1;
+    ok = ok && (!parts || d_huf_sync_.alloc(n_streams_ * sizeof(HufSync) + 16));
     if (!ok) return Failure::make(NAFGPU_E_DEVICE, "out of device memory while preparing a section");
     // the host vectors were consumed by asynchronous copies: keep them until the stream drains
     if (!hip_ok(hipStreamSynchronize(stream))) return Failure::make(NAFGPU_E_DEVICE, "upload of task lists failed");
@@ -601,6 +617,20 @@ void SectionJob::run_front(hipStream_t stream, StageTimer *timer, hipStream_t au
     const bool k2_done = k2_ahead_ && hip_ok(hipStreamWaitEvent(stream, ev_k2_, 0));
     k2_ahead_ = false;
     if (!k2_done) (void)hipMemsetAsync(status, 0, 64, stream);
+    {   // streams in parts (plan.h: HufStream::sub): where the parts begin -- once, in front of every class of k_huf_decode
+        uint32_t sync_lds = 0;
+        bool parts = false;
+        for (const HufClass &c : classes_) {
+            parts = parts || c.split > 1;
+            sync_lds = std::max(sync_lds, c.sync_lds);
+        }
+        if (parts) {
+            if (timer) timer->begin(stream, StageTimer::kHuf);
+            launch_huf_parts(stream, d_src_, d_tasks_.as<HufTask>(), static_cast<uint32_t>(n_tasks_), d_tbl_copies_.as<HufTblCopy>(),
+                             d_streams_.as<HufStream>(), d_pool_.as<uint16_t>(), d_huf_sync_.as<HufSync>(), sync_lds, status);
+            if (timer) timer->end(stream);
+        }
+    }
     // Streams bound for the literal buffer need nothing from K2 (their destinations are the plan's): they start on `aux`
     // now, beside k_seq_states -- a chain per block that keeps one wave per CU busy and leaves the rest of the chip idle.
     bool early = false;

@@ -224,6 +224,7 @@ private:
     DevBuf d_pj_dist_, d_pj_tiles_;               // dense LZ sections: one word per output element + one per tile (allocated on first use, kept)
     bool lz_dense_ = false;
     DevBuf d_streams_, d_tasks_, d_tbl_copies_, d_pool_, d_dicts_, d_copies_, d_seq_blocks_, d_cells_;
+    DevBuf d_huf_sync_;                  // one HufSync per part, when the plan's streams come in parts (plan.h)
 };
 
 struct ArchiveOptions {

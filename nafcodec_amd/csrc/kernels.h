@@ -81,6 +81,8 @@ void launch_copy_fill(hipStream_t stream, const uint8_t *src, const CopyTask *ta
 // HufClass): `tasks` is the section's whole task list, cls names the run to launch, its table format,
 // destination and whether the segment-aware variant is needed (streams of blocks with a few sequences:
 // seq_blocks / seqs are then read, so k_seq_values must have run).
+void launch_huf_parts(hipStream_t stream, const uint8_t *src, const HufTask *tasks, uint32_t n_tasks, const HufTblCopy *copies,
+                      HufStream *streams, const uint16_t *pool, HufSync *sync, uint32_t sync_lds, uint32_t *status);
 void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *tasks, const HufClass &cls,
                        const HufTblCopy *copies, const HufStream *streams, const uint16_t *pool,
                        const uint64_t *blk_base, uint8_t *out, uint8_t *lit, const SeqBlock *seq_blocks, const Seq *seqs,

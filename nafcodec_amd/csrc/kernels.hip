@@ -162,6 +162,259 @@ struct HufLook {           // what one table look-up says about the next one or 
     uint32_t first;        // format-specific handle for "bits of the first symbol alone" (stream tail only)
 };
 
+// ---- sub-streams (plan.h: HufStream::sub, HufSync): where the parts of a stream begin ----------------------------------
+// Both kernels take the tasks of k_huf_decode as they are -- a wave per task, the task's trees staged once -- but stage ONE
+// BYTE per table entry, the code length: all that is asked here is where symbols begin.  Bits come straight from memory
+// (an unaligned 8-byte load per symbol: the sections this is for are small, the loads hit L2).
+struct HufLens {
+    const uint8_t *lut;       // 2^mb code lengths of the lane's tree (LDS)
+    uint32_t mb;
+    const uint8_t *bits;      // first byte of the stream
+    // ---- the bits, a WINDOW at a time: 32 bytes in registers serve kHufLensBatch symbols (of <= 11 bits each), so that a
+    // memory latency is paid once per batch and not once per symbol -- every lane of the wave loads its window at the same
+    // place in the code (uniform control flow: one wait for all), then the symbols come out of a 64-bit buffer that is
+    // topped up a dword at a time from the window.
+    uint32_t w0, w1, w2, w3, w4, w5;   // the window's lower 24 bytes (the upper 8 go into buf at once); scalars, not an array: registers
+    uint64_t buf;             // the next bits, first bit on top
+    int32_t nbits;            // valid bits in buf
+    int32_t j;                // next window dword to append (7 .. 0, then none)
+    __device__ void load(uint32_t pos) {                                   // the window that ends with the byte holding bit pos - 1
+        const int64_t e = (static_cast<int64_t>(pos) + 7) >> 3;
+        uint4 qa, qb;
+        __builtin_memcpy(&qa, bits + (e - 32), 16);                          // (in front of the stream: readable, kSrcFrontPad)
+        __builtin_memcpy(&qb, bits + (e - 16), 16);
+        w0 = qa.x; w1 = qa.y; w2 = qa.z; w3 = qa.w;
+        w4 = qb.x; w5 = qb.y;
+        const uint32_t drop = static_cast<uint32_t>(8 * e - static_cast<int64_t>(pos));   // bits of the top byte above the cursor (0 .. 7)
+        buf = ((static_cast<uint64_t>(qb.w) << 32) | qb.z) << drop;
+        nbits = 64 - static_cast<int32_t>(drop);
+        j = 5;
+    }
+    // length of the code under the cursor; 0: invalid, or longer than the `left` bits the stream still has.
+    // (Measured and dropped: a second table with as many symbols as the index holds whole -- two per look-up on DNA -- made
+    //  the walk no faster, 2.4 against 2.0 ms for 8 K symbols: at one wave per SIMD the walk runs at the latency of its
+    //  forty-odd dependent instructions and five branches per step, not at the rate of its look-ups.)
+    __device__ uint32_t len_next(uint32_t left) const {
+        const uint32_t len = lut[static_cast<uint32_t>(buf >> (64u - mb))];
+        return len <= left ? len : 0u;
+    }
+    __device__ void consume(uint32_t len) {
+        buf <<= len;
+        nbits -= static_cast<int32_t>(len);
+        if (nbits <= 32 && j >= 0) {
+            // the next dword is always w5: the window moves down a register (indexing w by j -- even as a chain of selects --
+            // is turned into an indexed load from a stack array by hipcc: a trip to scratch memory per top-up)
+            const uint32_t x = w5;
+            w5 = w4;
+            w4 = w3;
+            w3 = w2;
+            w2 = w1;
+            w1 = w0;
+            buf |= static_cast<uint64_t>(x) << (32 - nbits);
+            nbits += 32;
+            j--;
+        }
+    }
+};
+constexpr uint32_t kHufLensBatch = 20;       // steps per window: 20 x 11 bits + a look-up's 11 < the 249 bits a window holds at least
+// the task's trees as length bytes, tree c at s_len + lens_off(c); returns the lane's table through its copy's lds_off
+__device__ inline void huf_stage_lens(const HufTask &task, const HufTblCopy *copies, const uint16_t *pool, uint8_t *s_len) {
+    uint32_t at = 0;
+    for (uint32_t k = 0; k < task.n_copies; k++) {
+        const HufTblCopy cp = copies[task.first_copy + k];
+        const uint32_t mb = cp.bits & 0xFFu;
+        const uint16_t *x1 = pool + cp.pool_off;
+        for (uint32_t i = threadIdx.x; i < (1u << mb); i += blockDim.x) s_len[at + i] = static_cast<uint8_t>(x1[i] >> 8);
+        at += (1u << mb) < 16u ? 16u : (1u << mb);
+    }
+}
+__device__ inline HufLens huf_lens_of(const HufTask &task, const HufTblCopy *copies, const uint8_t *s_len, const HufStream &st, const uint8_t *src) {
+    HufLens L{};
+    L.lut = s_len;
+    L.mb = 1;
+    L.bits = src + st.src_end - st.src_len;                 // (a lane without a stream: never dereferenced)
+    uint32_t at = 0;
+    for (uint32_t k = 0; k < task.n_copies; k++) {
+        const HufTblCopy cp = copies[task.first_copy + k];
+        const uint32_t mb = cp.bits & 0xFFu;
+        if (cp.lds_off == st.tbl_lds) {
+            L.lut = s_len + at;
+            L.mb = mb;
+        }
+        at += (1u << mb) < 16u ? 16u : (1u << mb);
+    }
+    return L;
+}
+__device__ inline uint32_t huf_stream_bits(const HufStream &st, const uint8_t *src) {   // data bits of the stream (0: no end mark)
+    const uint32_t lastb = src[st.src_end - 1];
+    if (lastb == 0) return 0;
+    return (st.src_len - 1u) * 8u + (31u - static_cast<uint32_t>(__clz(static_cast<int>(lastb))));
+}
+// part k of S begins (as a guess) at bit total * (S - k) / S; the marks of a part are `step` bits apart
+__device__ inline uint32_t huf_part_guess(uint32_t total, uint32_t k, uint32_t S) {
+    return static_cast<uint32_t>(static_cast<uint64_t>(total) * (S - k) / S);
+}
+__device__ inline uint32_t huf_mark_step(uint32_t total, uint32_t S) {
+    const uint32_t part = total / S + 1u;
+    const uint32_t step = (part + kHufSyncMarks - 1u) / kHufSyncMarks;
+    return step < 64u ? 64u : step;
+}
+
+// lane = part: decode from the guessed first bit, note the boundaries at the marks and where the next part's guess is crossed.
+// The walk is a chain of dependent instructions -- table look-up, shifts, comparisons, a handful of branches: some 600 cycles
+// a symbol for a wave alone on its SIMD -- and a section that is cut has few tasks: the task's 64 parts are therefore spread
+// over kHufSyncSpread waves (every kHufSyncSpread-th thread of the workgroup has a part), so that a SIMD has several walks to
+// switch between.
+constexpr uint32_t kHufSyncSpread = 4;
+__global__ __launch_bounds__(64 * kHufSyncSpread) void k_huf_sync(const uint8_t *__restrict__ src, const HufTask *__restrict__ tasks,
+                                                 const HufTblCopy *__restrict__ copies, const HufStream *__restrict__ streams,
+                                                 const uint16_t *__restrict__ pool, HufSync *sync, const uint32_t *status) {
+    HIP_DYNAMIC_SHARED(uint8_t, s_len)
+    if (status[0] != 0) return;
+    const uint32_t lane = threadIdx.x / kHufSyncSpread;
+    const HufTask task = tasks[blockIdx.x];
+    huf_stage_lens(task, copies, pool, s_len);
+    __syncthreads();
+    const bool have = threadIdx.x % kHufSyncSpread == 0 && lane < task.n_streams;
+    HufStream st{};
+    if (have) st = streams[task.first_stream + lane];
+    const uint32_t k = st.sub & 0xFFu, S = st.sub >> 8;
+    // (the record is written in place, mark by mark: a private copy indexed by `j` would live in scratch memory)
+    HufSync *out = sync + task.first_stream + (have ? lane : 0u);
+    uint32_t end_pos = kHufSyncBad, n_total = 0;
+    const uint32_t total = have ? huf_stream_bits(st, src) : 0u;
+    HufLens L = huf_lens_of(task, copies, s_len, st, src);
+    const uint32_t g = huf_part_guess(total, k, S ? S : 1u), r = k + 1 < S ? huf_part_guess(total, k + 1, S) : 0u;
+    const uint32_t step = huf_mark_step(total, S ? S : 1u);
+    uint32_t pos = g, cnt = 0, j = 0;
+    int64_t mark = static_cast<int64_t>(g) - step;             // mark j = g - (j + 1) step, as long as it lies above the part's end
+    bool done = !(have && S > 1 && total != 0);
+    auto at_boundary = [&]() {                                // pos is a symbol boundary: marks crossed, the end reached?
+        while (j < kHufSyncMarks && mark > static_cast<int64_t>(r) && static_cast<int64_t>(pos) <= mark) {
+            out->off[j] = static_cast<uint8_t>(mark - pos);
+            out->cnt[j] = static_cast<uint16_t>(cnt);
+            j++;
+            mark -= step;
+        }
+        if (pos <= r) {
+            end_pos = pos;
+            n_total = cnt;
+            done = true;
+        }
+    };
+    // (the per-symbol path is a table look-up, two shifts and ONE comparison: `thr` is the next place where something is to
+    //  be noted -- the next mark, or the part's end)
+    auto next_thr = [&]() -> uint32_t { return j < kHufSyncMarks && mark > static_cast<int64_t>(r) ? static_cast<uint32_t>(mark) : r; };
+    if (!done) at_boundary();
+    uint32_t thr = next_thr();
+    while (__any(done ? 0 : 1)) {                              // (every lane of the wave takes part in every window load)
+        if (!done) L.load(pos);
+#pragma unroll 1
+        for (uint32_t i = 0; i < kHufLensBatch; i++) {
+            const uint32_t len = done ? 0u : L.len_next(pos);
+            if (!done && (len == 0 || cnt >= 0xFFFFu)) done = true;   // (a wrong start may run into anything: the part is then decoded from its true one)
+            if (done) continue;
+            L.consume(len);
+            pos -= len;
+            cnt++;
+            if (pos <= thr) {
+                at_boundary();
+                thr = next_thr();
+            }
+        }
+    }
+    if (have) {
+        out->end_pos = end_pos;
+        out->total = n_total;
+        for (; j < kHufSyncMarks; j++) out->off[j] = 0xFF;    // marks not reached: no boundary noted
+    }
+}
+
+// lane = stream (the lane of its part 0): the parts one after the other from their TRUE first bits -- each a short decode,
+// until it stands on a boundary the guessed decode noted -- and the three words k_huf_decode wants written into every part
+__global__ __launch_bounds__(64) void k_huf_bounds(const uint8_t *__restrict__ src, const HufTask *__restrict__ tasks,
+                                                   const HufTblCopy *__restrict__ copies, HufStream *streams,
+                                                   const uint16_t *__restrict__ pool, const HufSync *__restrict__ sync, uint32_t *status) {
+    HIP_DYNAMIC_SHARED(uint8_t, s_len)
+    if (status[0] != 0) return;
+    const uint32_t lane = threadIdx.x;
+    const HufTask task = tasks[blockIdx.x];
+    huf_stage_lens(task, copies, pool, s_len);
+    __syncthreads();
+    if (lane >= task.n_streams) return;
+    const uint32_t me = task.first_stream + lane;
+    const HufStream st = streams[me];
+    const uint32_t S = st.sub >> 8;
+    if (S <= 1 || (st.sub & 0xFFu) != 0) return;
+    const uint32_t total = huf_stream_bits(st, src);
+    HufLens L = huf_lens_of(task, copies, s_len, st, src);
+    const uint32_t step = huf_mark_step(total, S);
+    uint32_t t = total, before = 0;
+    bool bad = total == 0;
+    for (uint32_t k = 0; k < S && !bad; k++) {
+        const HufSync *rec = sync + me + k;
+        const uint32_t g = huf_part_guess(total, k, S), r = k + 1 < S ? huf_part_guess(total, k + 1, S) : 0u;
+        const bool guess_ok = rec->end_pos != kHufSyncBad;
+        uint32_t n_k = 0, e = 0;
+        if (t == g && guess_ok) {                         // the guess was a boundary (part 0 always): the noted decode is the true one
+            n_k = rec->total;
+            e = rec->end_pos;
+        } else {
+            uint32_t pos = t, cnt = 0, j = 0;
+            int64_t mark = static_cast<int64_t>(g) - step;
+            bool done = false;
+            auto at_boundary = [&]() {                        // pos is a symbol boundary: on one the guessed decode noted? at the end?
+                while (j < kHufSyncMarks && mark > static_cast<int64_t>(r) && static_cast<int64_t>(pos) <= mark) {
+                    if (guess_ok && rec->off[j] == static_cast<uint32_t>(mark - pos)) {   // the same boundary: the same decode from here on
+                        n_k = cnt + (rec->total - rec->cnt[j]);
+                        e = rec->end_pos;
+                        done = true;
+                        return;
+                    }
+                    j++;
+                    mark -= step;
+                }
+                if (pos <= r) {
+                    n_k = cnt;
+                    e = pos;
+                    done = true;
+                }
+            };
+            auto next_thr = [&]() -> uint32_t { return j < kHufSyncMarks && mark > static_cast<int64_t>(r) ? static_cast<uint32_t>(mark) : r; };
+            at_boundary();
+            uint32_t thr = next_thr();
+            while (!done && !bad) {
+                L.load(pos);
+#pragma unroll 1
+                for (uint32_t i = 0; i < kHufLensBatch && !done; i++) {
+                    const uint32_t len = L.len_next(pos);
+                    if (len == 0) {
+                        bad = true;
+                        break;
+                    }
+                    L.consume(len);
+                    pos -= len;
+                    cnt++;
+                    if (pos <= thr) {
+                        at_boundary();
+                        thr = next_thr();
+                    }
+                }
+            }
+        }
+        if (bad) break;
+        streams[me + k].sub_start = t;
+        streams[me + k].sub_syms = n_k;
+        streams[me + k].sub_first = before;
+        before += n_k;
+        t = e;
+    }
+    if (bad || t != 0 || before != st.n_syms) {           // (what k_huf_decode flags for a whole stream that does not end at its first bit)
+        flag_error(status, kStHufBadEnd, me);
+        for (uint32_t k = 0; k < S; k++) streams[me + k].sub_syms = 0;
+    }
+}
+
 template <bool ASCII, int TBL, bool SEG>
 __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ src, const HufTask *__restrict__ tasks,
                                                    const HufTblCopy *__restrict__ copies,
@@ -268,9 +521,18 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
         }
     }
 
-    const bool have = lane < task.n_streams;
+    bool have = lane < task.n_streams;
     HufStream st{};
     if (have) st = streams[task.first_stream + lane];
+    // a part of a stream (HufStream::sub): its symbols, and where they go; an empty part's lane sits the task out
+    const bool is_part = (st.sub >> 8) > 1u;
+    uint32_t part_end = 0;               // bits of the stream below the part's last symbol
+    if (is_part) {
+        if ((st.sub & 0xFFu) + 1u < (st.sub >> 8)) part_end = streams[task.first_stream + lane + 1].sub_start;
+        st.n_syms = st.sub_syms;
+        st.dst += st.sub_first;          // (the literal buffer holds a byte per symbol; else: the index of the stream's first literal)
+        have = st.sub_syms != 0;
+    }
     const uint32_t W = st.max_bits;                        // max_bits holds W here
     const uint32_t sh = 32u - W;
     const uint32_t esc_bits = st.flags >> 4;               // tree max_bits - W
@@ -361,10 +623,17 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
     };
     if (have) {
         const uint8_t *lastp = src + st.src_end - 1;
-        const uint32_t lastb = *lastp;
+        uint32_t lastb = *lastp;
         bad = lastb == 0;                                        // no end mark
-        const uint32_t hb = 31u - static_cast<uint32_t>(__clz(static_cast<int>(lastb | 1u)));
-        bits_total = (st.src_len - 1u) * 8u + hb;
+        uint32_t hb = 31u - static_cast<uint32_t>(__clz(static_cast<int>(lastb | 1u)));
+        if (is_part) {
+            // the part begins sub_start bits above the stream's first bit: as if the stream ended there, with its end mark
+            // at that bit -- and it is done part_end bits above the stream's first bit, not at it (bits_total: what it consumes)
+            lastp = src + st.src_end - st.src_len + (st.sub_start >> 3);
+            hb = st.sub_start & 7u;
+            bad = false;
+        }
+        bits_total = is_part ? st.sub_start - part_end : (st.src_len - 1u) * 8u + hb;
         const uintptr_t a = reinterpret_cast<uintptr_t>(lastp);
         ptop = a - (a & 31);
         rp0 = 7u - static_cast<uint32_t>((a >> 2) & 7u);
@@ -1414,6 +1683,10 @@ __global__ __launch_bounds__(64) void k_seq_values(const uint8_t *__restrict__ s
     HIP_DYNAMIC_SHARED(uint2, s_cells)          // the block's three tables (cells_cap cells), when it has sequences enough to pay for them
     __shared__ uint32_t s_sum[2][2][64];        // [ping-pong][ll, ml][lane]
     __shared__ uint32_t s_map[2][3][64];        // [ping-pong][slot][lane]
+    // a tile's 256 records on their way out: a lane's four are 80 contiguous bytes, and stored from registers every store
+    // instruction touches 64 different lines; through LDS the wave writes its 5 KB as twenty runs of 256 contiguous bytes
+    __shared__ uint32_t s_stage[64 * kSeqPerLane * 5];
+    static_assert(sizeof(Seq) == 20, "Seq records are staged as five dwords");
     if (status[0] != 0) return;                 // (k_seq_states flagged a stream: its records are not all there)
     const uint32_t b = blockIdx.x, lane = threadIdx.x;
     if (b >= n_blocks) return;
@@ -1538,15 +1811,24 @@ __global__ __launch_bounds__(64) void k_seq_values(const uint8_t *__restrict__ s
         }
         for (uint32_t j = 0; j < kSeqPerLane; j++) {
             if (i0 + j >= sb.n_seq) break;
-            Seq s;
-            s.ll = ll[j];
-            s.ml = ml[j];
-            s.off = rep_apply_entry(offs[j], init, &bad);
-            s.opos = pre_ll + pre_ml;
-            s.lpos = pre_ll;
-            dst[i0 + j] = s;
+            uint32_t *st = s_stage + (kSeqPerLane * lane + j) * 5u;   // {ll, ml, off, opos, lpos}: struct Seq
+            st[0] = ll[j];
+            st[1] = ml[j];
+            st[2] = rep_apply_entry(offs[j], init, &bad);
+            st[3] = pre_ll + pre_ml;
+            st[4] = pre_ll;
             pre_ll += ll[j];
             pre_ml += ml[j];
+        }
+        wave_sync();
+        {
+            const uint32_t n_here = sb.n_seq - base < 64u * kSeqPerLane ? sb.n_seq - base : 64u * kSeqPerLane;
+            uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + base);
+#pragma unroll
+            for (uint32_t k = 0; k < kSeqPerLane * 5u; k++) {
+                const uint32_t idx = lane + 64u * k;
+                if (idx < n_here * 5u) d32[idx] = s_stage[idx];
+            }
         }
         // the tile's totals and its whole map, for the next tile
         {
@@ -2656,6 +2938,10 @@ __device__ inline bool pj_pending(uint32_t v) { return v - 1u < kPjWait - 1u; } 
 constexpr uint32_t kPjLocal = 4;             // jumps inside the tile (LDS) before a sweep looks into memory
 constexpr uint32_t kPjStripSweeps = 1;       // ... for the first this-many sweeps; what they leave is scattered: tile-wise from there
 constexpr uint32_t kPjWin = 1;               // tiles a strip-wise sweep keeps in LDS behind the current one (k_pj_sweep)
+constexpr uint32_t kPjHops = 2;              // look-ups per element and pass (a pending source hands over its distance: look again) ...
+constexpr uint32_t kPjHopsDeep = 4;          // ... where chains are deep (few literals: no strip-wise sweep).  Same box, hops 1 / 2 / 3 / 4
+                                             // (profiles/r04_pj_hops_probe.log): FASTQ-like level 1 29.85 / 28.41 / 28.81 / 29.27 ms, level 3
+                                             // 79.6 / 72.0 / 67.1 / 64.9, level-3 DNA 6.27 / 6.12 / 6.19 / 6.26
 constexpr uint32_t kPjFinishSweeps = 4;      // a shard's sweeps after the window in front of it has arrived
 constexpr uint32_t kPjSweeps = 24;           // a sweep at least halves every chain: 2^24 matches deep; what is left after them goes to the
                                              // frame-order walk (every launch that finds nothing left still costs its 4-5 us: 40 of them
@@ -2797,7 +3083,14 @@ __global__ __launch_bounds__(256) void k_pj_fill(const SeqBlock *__restrict__ bl
                         // (off <= kk: a run) that is an element of the same match, and so on down to the `off` elements in
                         // front of it -- point there at once instead of leaving kk / off hops to the sweeps
                         w[k] = off;
-                        if (kk >= off) w[k] = off * (kk / off + 1u);
+                        if (kk >= off) {
+                            // kk / off without the twenty instructions of an integer division, eight times a step: both are
+                            // below 2^24, the quotient of the float reciprocal is off by one at most
+                            uint32_t q = static_cast<uint32_t>(static_cast<float>(kk) * __frcp_rn(static_cast<float>(off)));
+                            const int32_t rem = static_cast<int32_t>(kk - q * off);
+                            q += rem < 0 ? 0xFFFFFFFFu : (rem >= static_cast<int32_t>(off) ? 1u : 0u);
+                            w[k] = off * (q + 1u);
+                        }
                     }
                 }
                 if (has_lit) {                             // all literal bytes of the step on their way together
@@ -2887,7 +3180,8 @@ __device__ inline void pj_list_flush(PjLister<N> *L, uint32_t *list_out, unsigne
 template <bool ASCII, uint32_t WIN>
 __global__ __launch_bounds__(256, WIN ? 5 : 6) void k_pj_sweep(uint32_t *D, uint8_t *out_bytes, uint32_t *tile_pending, unsigned long long *pcount,
                                                   uint64_t n_elems, uint32_t sweep, uint32_t max_dist, uint32_t *list_out,
-                                                  uint64_t list_cap, unsigned long long *lstate, uint32_t first_list, const uint32_t *status) {
+                                                  uint64_t list_cap, unsigned long long *lstate, uint32_t first_list, uint32_t hops,
+                                                  const uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
     constexpr uint32_t kSlots = WIN + 1;
@@ -2961,7 +3255,7 @@ __global__ __launch_bounds__(256, WIN ? 5 : 6) void k_pj_sweep(uint32_t *D, uint
         // further back), so the order inside a sweep does not matter -- but eight dependent round trips to memory do.
         uint64_t p[2];
         uint32_t v[2][4], w[2][4];
-        Elem e[2][4];
+        uint32_t dirty = 0;                                // bit 4 half + k: the element's word differs from what memory holds
 #pragma unroll
         for (uint32_t half = 0; half < 2; half++) {
             p[half] = tile0 + tid * 4 + half * (kPjTile / 2);
@@ -2984,11 +3278,8 @@ __global__ __launch_bounds__(256, WIN ? 5 : 6) void k_pj_sweep(uint32_t *D, uint
         // advances a chain by up to 2^kPjLocal doublings for one pass over D in memory.  No barriers between the rounds: a
         // thread writes its own eight words only, and a word read a moment early or late is a valid ancestor (or the final
         // value) either way.
-        uint32_t v0[2][4];                                 // as loaded: what differs at the end is stored
 #pragma unroll
         for (uint32_t half = 0; half < 2; half++) {
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) v0[half][k] = v[half][k];
             // literals (0: final, element in the output) become final WORDS the first time a sweep sees them: from then on
             // whoever copies from them -- in this tile's LDS rounds right away -- needs no second look-up
             if ((v[half][0] == 0 || v[half][1] == 0 || v[half][2] == 0 || v[half][3] == 0) && p[half] < n_elems) {
@@ -2999,7 +3290,10 @@ __global__ __launch_bounds__(256, WIN ? 5 : 6) void k_pj_sweep(uint32_t *D, uint
                     for (uint32_t k = 0; k < static_cast<uint32_t>(n_elems - p[half]); k++) el[k] = out[p[half] + k];
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++)
-                    if (v[half][k] == 0 && p[half] + k < n_elems) v[half][k] = kPjFinal | el[k];
+                    if (v[half][k] == 0 && p[half] + k < n_elems) {
+                        v[half][k] = kPjFinal | el[k];
+                        dirty |= 1u << (4 * half + k);
+                    }
             }
             *reinterpret_cast<uint4 *>(&s_cur[tid * 4 + half * (kPjTile / 2)]) = make_uint4(v[half][0], v[half][1], v[half][2], v[half][3]);
         }
@@ -3026,50 +3320,69 @@ __global__ __launch_bounds__(256, WIN ? 5 : 6) void k_pj_sweep(uint32_t *D, uint
                     if (ws >= kPjFinal) {
                         v[half][k] = ws;                                        // (mark and element of the source: ours too)
                         s_cur[li] = ws;
+                        dirty |= 1u << (4 * half + k);
                     } else if (ws != 0 && static_cast<uint64_t>(d) + ws < max_dist) {
                         v[half][k] = d + ws;
                         s_cur[li] = d + ws;
+                        dirty |= 1u << (4 * half + k);
                     }                                                           // (a literal in the tile: its element is in the output -- below)
                 }
         }
+        // Up to `hops` look-ups per element, one behind the other: a source that is itself pending hands over its distance
+        // (the chain above the element halves, as in every sweep) and the element looks again at once, instead of waiting
+        // for the next pass over all of D -- a pass is 4 bytes per element read and written, a look-up one sector.  All
+        // the look-ups of one round are issued together; an element whose distance cannot grow (max_dist, or a source
+        // that waits for a shard's window) is `stuck` and stops looking.
+        uint32_t stuck = 0;
+#pragma unroll 1
+        for (uint32_t hop = 0; hop < hops; hop++) {
+            bool more = false;
 #pragma unroll
-        for (uint32_t half = 0; half < 2; half++)
+            for (uint32_t half = 0; half < 2; half++)
 #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                const bool pending = pj_pending(v[half][k]);                       // else: literal / final already
-                w[half][k] = pending ? D[p[half] + k - v[half][k]] : 1u;
-            }
+                for (uint32_t k = 0; k < 4; k++) {
+                    const bool pending = pj_pending(v[half][k]) && !(stuck & (1u << (4 * half + k)));   // else: literal / final already
+                    w[half][k] = pending ? D[p[half] + k - v[half][k]] : 1u;
+                }
 #pragma unroll
-        for (uint32_t half = 0; half < 2; half++)
+            for (uint32_t half = 0; half < 2; half++)
 #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {             // a literal as the source (D == 0): its element is in the output only
-                const bool pending = pj_pending(v[half][k]);
-                if (pending && w[half][k] == 0) e[half][k] = out[p[half] + k - v[half][k]];
-            }
+                for (uint32_t k = 0; k < 4; k++) {         // a literal as the source (D == 0): its element is in the output only
+                    const bool pending = pj_pending(v[half][k]) && !(stuck & (1u << (4 * half + k)));
+                    if (pending && w[half][k] == 0) w[half][k] = kPjFinal | out[p[half] + k - v[half][k]];
+                }
+#pragma unroll
+            for (uint32_t half = 0; half < 2; half++)
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t bit = 1u << (4 * half + k);
+                    if (!pj_pending(v[half][k]) || (stuck & bit)) continue;
+                    const uint32_t ws = w[half][k];
+                    if (ws >= kPjFinal) {
+                        // final: the word of a final element carries the element itself, so ONE look-up both tells that the
+                        // source is final and fetches it (and there is no "became final a moment ago, is its byte visible?")
+                        v[half][k] = ws;                   // (the output gets it from here when the sweeps are over: k_pj_emit)
+                        dirty |= bit;
+                    } else if (static_cast<uint64_t>(v[half][k]) + ws < max_dist) {
+                        v[half][k] += ws;
+                        dirty |= bit;
+                        more = true;
+                    } else {
+                        stuck |= bit;                      // (a distance that cannot grow waits for its source)
+                    }
+                }
+            if (!__any(more ? 1 : 0)) break;               // (per wave: nobody in it has anything to look at again)
+        }
         uint32_t remaining = 0, survivors = 0;
 #pragma unroll
         for (uint32_t half = 0; half < 2; half++) {
-            bool changed = v[half][0] != v0[half][0] || v[half][1] != v0[half][1] || v[half][2] != v0[half][2] || v[half][3] != v0[half][3];
+            const bool changed = ((dirty >> (4 * half)) & 15u) != 0;
 #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                const bool pending = pj_pending(v[half][k]);
-                if (!pending) continue;
-                const uint32_t ws = w[half][k];
-                if (ws == 0 || ws >= kPjFinal) {
-                    // final: the word of a final element carries the element itself, so ONE look-up both tells that the
-                    // source is final and fetches it (and there is no "became final a moment ago, is its byte visible?")
-                    const Elem el = ws == 0 ? e[half][k] : static_cast<Elem>(ws & 0xFFFFu);
-                    v[half][k] = kPjFinal | el;            // (the output gets it from here when the sweeps are over: k_pj_emit)
-                    changed = true;
-                } else {
-                    if (static_cast<uint64_t>(v[half][k]) + ws < max_dist) {   // (a distance that cannot grow waits for its source)
-                        v[half][k] += ws;
-                        changed = true;
-                    }
+            for (uint32_t k = 0; k < 4; k++)
+                if (pj_pending(v[half][k])) {
                     remaining++;
                     survivors |= 1u << (4 * half + k);
                 }
-            }
             // the thread's four words go back as one store (nobody else writes them; readers take the old or the new value)
             if (changed) {
                 if (n_elems - p[half] >= 4) {
@@ -3110,7 +3423,7 @@ __global__ __launch_bounds__(256, WIN ? 5 : 6) void k_pj_sweep(uint32_t *D, uint
 template <bool ASCII>
 __global__ __launch_bounds__(256) void k_pj_list(uint32_t *D, uint8_t *out_bytes, unsigned long long *pcount, const uint32_t *list_in,
                                                  uint32_t *list_out, uint64_t list_cap, unsigned long long *lstate, uint32_t sweep,
-                                                 uint32_t max_dist, uint32_t emit, const uint32_t *status) {
+                                                 uint32_t max_dist, uint32_t emit, uint32_t hops, const uint32_t *status) {
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
     __shared__ PjLister<kPjBatch + 256> s_list;
@@ -3135,15 +3448,26 @@ __global__ __launch_bounds__(256) void k_pj_list(uint32_t *D, uint8_t *out_bytes
         const uint64_t i = r * stride + static_cast<uint64_t>(blockIdx.x) * 256 + tid;
         if (i < n_in) {
             const uint32_t p = list_in[i];
-            const uint32_t v = D[p];
-            if (pj_pending(v)) {
-                const uint32_t ws = D[p - v];
-                if (ws == 0 || ws >= kPjFinal) {
-                    const Elem el = ws == 0 ? out[p - v] : static_cast<Elem>(ws & 0xFFFFu);
+            const uint32_t v0 = D[p];
+            if (pj_pending(v0)) {
+                uint32_t v = v0;
+                bool final = false;
+                Elem el = 0;
+                for (uint32_t hop = 0; hop < hops; hop++) {                     // (as in k_pj_sweep: a pending source hands over its distance, look again)
+                    const uint32_t ws = D[p - v];
+                    if (ws == 0 || ws >= kPjFinal) {
+                        el = ws == 0 ? out[p - v] : static_cast<Elem>(ws & 0xFFFFu);
+                        final = true;
+                        break;
+                    }
+                    if (static_cast<uint64_t>(v) + ws >= max_dist) break;
+                    v += ws;
+                }
+                if (final) {
                     D[p] = kPjFinal | el;
                     if (emit) out[p] = el;                                      // (after k_pj_emit has run: the finishing passes of a shard)
                 } else {
-                    if (static_cast<uint64_t>(v) + ws < max_dist) D[p] = v + ws;
+                    if (v != v0) D[p] = v;
                     mine++;
                     s_list.buf[atomicAdd(&s_list.n, 1u)] = p;                    // (at most 256 a round on top of < 2 048)
                 }
@@ -3668,8 +3992,10 @@ void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *b
     // wave per SIMD again, each with as many blocks as it takes to have every block of the section resident
     const uint32_t per_block_s = cells_cap * 2u + kSeqRingS + 16u;
     uint32_t lanes16 = 0;
+    uint32_t k2_waves = 1;                                            // waves per SIMD the chains are spread over
+    if (const char *e = hook_env("NAFGPU_K2_WAVES")) k2_waves = static_cast<uint32_t>(std::atoi(e)) > 0 ? static_cast<uint32_t>(std::atoi(e)) : 1u;
     if (cells_cap != 0) {
-        const uint32_t spread = (n_blocks + 4u * n_cu - 1u) / (4u * n_cu);
+        const uint32_t spread = (n_blocks + 4u * k2_waves * n_cu - 1u) / (4u * k2_waves * n_cu);
         for (uint32_t l = spread < 1 ? 1 : spread; l <= kSeqLdsLanesS && l * per_block_s <= 64u * 1024u; l++) {
             uint32_t wgs = (160u * 1024u - 1024u) / (l * per_block_s + 256u);
             if (wgs > 32u) wgs = 32u;
@@ -3689,7 +4015,7 @@ void launch_seq_decode(hipStream_t stream, const uint8_t *src, const SeqBlock *b
                            n_blocks, cells, recs, lanes16, cells_cap, src_min, status);
     } else if (use_lds) {
         // fewer lanes per wave than fit, when there are few blocks: every CU gets its share of the chains
-        uint32_t lanes = (n_blocks + 4u * n_cu - 1u) / (4u * n_cu);
+        uint32_t lanes = (n_blocks + 4u * k2_waves * n_cu - 1u) / (4u * k2_waves * n_cu);
         lanes = lanes < 1 ? 1 : (lanes > lds_lanes ? lds_lanes : lanes);
         hipLaunchKernelGGL(k_seq_states_lds, dim3((n_blocks + lanes - 1) / lanes), dim3(64), lanes * per_block, stream, src, blocks, n_blocks,
                            cells, recs, lanes, cells_cap, src_min, status);
@@ -3806,6 +4132,17 @@ void launch_copy_fill(hipStream_t stream, const uint8_t *src, const CopyTask *ta
                            status);
 }
 
+// Streams in parts (plan.h: HufStream::sub): where the parts begin, for ALL the tasks of the selection at once -- one launch
+// each of k_huf_sync and k_huf_bounds in front of the classes' decodes (a launch per class would be a part's serial decode
+// per class, one after the other).
+void launch_huf_parts(hipStream_t stream, const uint8_t *src, const HufTask *tasks, uint32_t n_tasks, const HufTblCopy *copies,
+                      HufStream *streams, const uint16_t *pool, HufSync *sync, uint32_t sync_lds, uint32_t *status) {
+    if (!n_tasks || !sync) return;
+    const uint32_t sl = (sync_lds + 15u) & ~15u;
+    hipLaunchKernelGGL(k_huf_sync, dim3(n_tasks), dim3(64 * kHufSyncSpread), sl, stream, src, tasks, copies, streams, pool, sync, status);
+    hipLaunchKernelGGL(k_huf_bounds, dim3(n_tasks), dim3(64), sl, stream, src, tasks, copies, streams, pool, sync, status);
+}
+
 void launch_huf_decode(hipStream_t stream, const uint8_t *src, const HufTask *tasks, const HufClass &cls,
                        const HufTblCopy *copies, const HufStream *streams, const uint16_t *pool,
                        const uint64_t *blk_base, uint8_t *out, uint8_t *lit, const SeqBlock *seq_blocks, const Seq *seqs,
@@ -3872,6 +4209,10 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
         // ---- dense: every element learns its source distance (the same walk puts the literals in place), then the frame
         // is swept (see k_pj_sweep)
         const uint32_t max_dist = pj_max_dist();
+        // look-ups per element and pass (k_pj_sweep); and whether the FIRST sweep already lists what it leaves pending
+        uint32_t hops = a.strips ? kPjHops : kPjHopsDeep, first_list = a.shallow;
+        if (const char *e = hook_env("NAFGPU_PJ_HOPS")) hops = static_cast<uint32_t>(std::atoi(e)) > 0 ? static_cast<uint32_t>(std::atoi(e)) : 1u;
+        if (const char *e = hook_env("NAFGPU_PJ_FIRST_LIST")) first_list = e[0] == '1' ? 1u : 0u;
         uint64_t tiles = (a.n_elems + kPjTile - 1) / kPjTile;
         // strips: at least 32 tiles each where there are that many; three workgroups per CU, four rounds of them at most
         uint64_t strips = tiles / 32 ? tiles / 32 : 1;
@@ -3909,14 +4250,14 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
             if (a.strips && sweep <= kPjStripSweeps)
                 hipLaunchKernelGGL((k_pj_sweep<ASCII, kPjWin>), dim3(static_cast<uint32_t>(strips)), dim3(256), 0, stream, a.pj_dist, a.out,
                                    a.pj_tiles, pcount, a.n_elems, sweep, max_dist, can_list ? lists[sweep & 1u] : nullptr, a.pj_list_cap, lstate,
-                                   a.shallow, a.status);
+                                   first_list, hops, a.status);
             else
                 hipLaunchKernelGGL((k_pj_sweep<ASCII, 0u>), dim3(static_cast<uint32_t>(tiles)), dim3(256), 0, stream, a.pj_dist, a.out,
                                    a.pj_tiles, pcount, a.n_elems, sweep, max_dist, can_list ? lists[sweep & 1u] : nullptr, a.pj_list_cap,
-                                   lstate, a.shallow, a.status);
+                                   lstate, first_list, hops, a.status);
             if (can_list && sweep >= 2)
                 hipLaunchKernelGGL(k_pj_list<ASCII>, dim3(list_grid), dim3(256), 0, stream, a.pj_dist, a.out, pcount,
-                                   lists[(sweep & 1u) ^ 1u], lists[sweep & 1u], a.pj_list_cap, lstate, sweep, max_dist, finish ? 1u : 0u, a.status);
+                                   lists[(sweep & 1u) ^ 1u], lists[sweep & 1u], a.pj_list_cap, lstate, sweep, max_dist, finish ? 1u : 0u, hops, a.status);
         }
         // (finish: the list passes wrote the output themselves; sweeps over all of D did not)
         hipLaunchKernelGGL(k_pj_emit<ASCII>, dim3(static_cast<uint32_t>(eg)), dim3(256), 0, stream, a.pj_dist, a.out, a.n_elems,

@@ -32,8 +32,31 @@ struct alignas(16) HufStream {
     uint8_t max_bits;    // index width W of the staged table (6..8, chosen per task by the host)
     uint8_t flags;       // bit0: write to the literal buffer (block has many sequences); bit1: block has a few sequences, the
                          // literals go to their final positions segment by segment; bits 4-7: tree max_bits - W (0 = no escapes)
+    // ---- sub-streams (sections with fewer streams than the chip has lanes: pack_tasks).  A stream is then `S` records
+    // in a row -- the fields above the same in all of them -- and lane k decodes the k-th part of it: the device finds
+    // where the parts begin (k_huf_sync, k_huf_bounds) and writes the three words below; the host only sets `sub`.
+    uint32_t sub;        // 0: a whole stream; else k | S << 8: part k of S
+    uint32_t sub_start;  // bits of the stream below this part's first symbol (part 0: all of them; the next part's: where this one ends)
+    uint32_t sub_syms;   // symbols in this part
+    uint32_t sub_first;  // symbols of the stream in front of it
 };
-static_assert(sizeof(HufStream) == 32, "HufStream layout");
+static_assert(sizeof(HufStream) == 48, "HufStream layout");
+
+// What k_huf_sync learns about one part decoded from its GUESSED first bit (an even split of the stream's bits), which
+// is a symbol boundary only by luck: prefix codes synchronise -- two decodes of the same bits from different starts
+// soon stand on the same boundaries -- so the guess is wrong for the part's first few symbols only.  At `kHufSyncMarks`
+// marks along the part it notes the first boundary at or below the mark and the symbols before it; k_huf_bounds
+// decodes from the TRUE first bit until it finds itself on a noted boundary, and takes the rest from here.
+constexpr uint32_t kHufSyncMarks = 32;
+constexpr uint32_t kHufSyncBad = 0xFFFFFFFFu;
+struct HufSync {
+    uint32_t end_pos;    // the first boundary at or below the next part's guessed first bit (kHufSyncBad: the decode ran into an invalid code)
+    uint32_t total;      // symbols in front of it
+    uint16_t cnt[kHufSyncMarks];   // symbols in front of the boundary noted at mark j
+    uint8_t off[kHufSyncMarks];    // mark j minus that boundary (< 12)
+};
+static_assert(sizeof(HufSync) == 104, "HufSync layout");
+constexpr uint32_t kHufSplitMax = 16;        // most parts per stream (a power of two: 64 lanes hold whole streams)
 
 struct HufTblCopy {      // build the two-symbol table of pool[pool_off ..) at LDS entry lds_off
     uint32_t pool_off;   // 2^max_bits single-symbol entries (len << 8 | sym) in the pool
@@ -67,6 +90,8 @@ struct HufClass {
     uint32_t to_lit;         // streams feed the literal buffer (never expanded to ASCII)
     uint32_t seg;            // some stream is interleaved with matches (flags&2): the segment-aware kernel variant
     uint32_t lds_bytes;      // dynamic LDS: the largest staged-table footprint over the tasks
+    uint32_t split;          // > 1: the class's streams come in that many parts each (HufStream::sub): k_huf_sync and k_huf_bounds run first
+    uint32_t sync_lds;       // ... and their dynamic LDS: one length byte per entry of the task's trees
 };
 
 struct CopyTask {        // Raw/RLE blocks and Raw/RLE literal sections

@@ -649,10 +649,42 @@ struct Walker {
 // into launch classes (table format x destination x segment-aware kernel).
 static uint32_t g_task_lanes = kHufWave;
 static uint32_t g_dict_slots = kHufLdsSlots2;
+// Sub-streams (plan.h: HufStream::sub).  Lane = stream leaves a section of a few thousand streams -- a bacterial genome is
+// 84 of them -- with most of the chip idle while every lane walks its 32 K symbols alone: 2.7 ms whatever the size.  Below
+// `g_split_target` / 8 streams a stream is cut into S parts (a power of two, so that 64 lanes hold whole streams), S the
+// largest that keeps the lanes at or under the target; the parts' first bits are found on the device by two passes
+// (k_huf_sync, k_huf_bounds).  Measured on the real-genome archive (profiles/r04_split_probe.log): the walk of k_huf_sync
+// costs 0.25 us per symbol of a part -- 0.5 ms for parts of 2 K symbols (S = 16), 1.75 ms at 8 K (S = 4) -- against 0.1 us per
+// symbol for k_huf_decode itself, so S = 16 and 8 pay (84 ... 2 516 streams: 2.7-3.2 -> 1.0-1.7 ms) and S = 4 and 2 do not
+// (8 376 streams: 2.8 -> 4.4 ms): below kHufSplitMin parts a section is left alone.  `g_split_force`: tests.
+constexpr uint32_t kHufSplitMin = 8;
+static uint32_t g_split_target = 0, g_split_force = 0;
 
 void pack_tasks(ZPlan *plan) {
     std::vector<HufRef> &stream_tbl = plan->stream_ref;
     std::vector<uint32_t> class_key;
+    uint32_t split = 1;
+    if (g_split_force) {
+        split = g_split_force;
+    } else if (g_split_target && !plan->streams.empty()) {
+        while (split < kHufSplitMax && plan->streams.size() * split * 2 <= g_split_target) split *= 2;
+        if (split < kHufSplitMin) split = 1;            // (fewer, longer parts: the walk in front costs more than the decode saves)
+    }
+    if (split > 1) {                                    // every stream becomes `split` records in a row
+        std::vector<HufStream> parts;
+        std::vector<HufRef> parts_tbl;
+        parts.reserve(plan->streams.size() * split);
+        parts_tbl.reserve(plan->streams.size() * split);
+        for (size_t s = 0; s < plan->streams.size(); s++)
+            for (uint32_t k = 0; k < split; k++) {
+                HufStream hs = plan->streams[s];
+                hs.sub = k | (split << 8);
+                parts.push_back(hs);
+                parts_tbl.push_back(stream_tbl[s]);
+            }
+        plan->streams.swap(parts);
+        stream_tbl.swap(parts_tbl);
+    }
     {   // stable partition by destination
         std::vector<HufStream> ordered;
         std::vector<HufRef> ordered_tbl;
@@ -683,6 +715,7 @@ void pack_tasks(ZPlan *plan) {
         HufTask task;
         uint32_t key;        // to_lit << 3 | tbl << 1 | seg
         uint32_t lds_bytes;
+        uint32_t sync_lds;   // one length byte per entry of the task's trees (k_huf_sync / k_huf_bounds)
     };
     std::vector<Packed> packed;
     auto pack_group = [&](size_t g0, size_t g1) {
@@ -702,6 +735,7 @@ void pack_tasks(ZPlan *plan) {
                     break;
                 }
             }
+            if (split > 1 && e - s > split) e = s + (e - s) / split * split;   // (the parts of a stream stay in one task)
             uint32_t W = 8, kind = kTblBaked;
             std::vector<HufRef> distinct;
             uint8_t min_len[256];                      // shortest code of every symbol over the task's trees (0xFF: unused)
@@ -745,8 +779,9 @@ void pack_tasks(ZPlan *plan) {
                         break;
                     }
                 }
-                if (fits || e == s + 1) break;
+                if (fits || e <= s + split) break;
                 e = s + (e - s + 1) / 2;                 // too many distinct deep trees: take fewer streams
+                if (split > 1) e = s + std::max<size_t>(split, (e - s) / split * split);
             }
             if (W < 6) W = 6;
             const uint32_t per_tree = kind == kTblDict ? kHufDictSlots : 0;
@@ -783,7 +818,9 @@ void pack_tasks(ZPlan *plan) {
             }
             const uint32_t to_lit = plan->streams[s].flags & 1u;
             const uint32_t entry_bytes = kind == kTblBaked ? 8u : (kind == kTblDict ? 2u : 4u);
-            packed.push_back(Packed{task, (to_lit << 3) | (kind << 1) | (seg ? 1u : 0u), lds_used * entry_bytes});
+            uint32_t sync_lds = 0;
+            for (const HufRef &d : distinct) sync_lds += std::max<uint32_t>(16u, 1u << d.max_bits);
+            packed.push_back(Packed{task, (to_lit << 3) | (kind << 1) | (seg ? 1u : 0u), lds_used * entry_bytes, sync_lds});
             s = e;
         }
     };
@@ -807,12 +844,13 @@ void pack_tasks(ZPlan *plan) {
     std::stable_sort(packed.begin(), packed.end(), [](const Packed &a, const Packed &b) { return a.key < b.key; });
     for (const Packed &pk : packed) {
         if (class_key.empty() || class_key.back() != pk.key) {
-            plan->classes.push_back(HufClass{static_cast<uint32_t>(plan->tasks.size()), 0, (pk.key >> 1) & 3u, pk.key >> 3, pk.key & 1u, 0});
+            plan->classes.push_back(HufClass{static_cast<uint32_t>(plan->tasks.size()), 0, (pk.key >> 1) & 3u, pk.key >> 3, pk.key & 1u, 0, split, 0});
             class_key.push_back(pk.key);
         }
         HufClass &c = plan->classes.back();
         c.n_tasks++;
         c.lds_bytes = std::max(c.lds_bytes, pk.lds_bytes);
+        c.sync_lds = std::max(c.sync_lds, pk.sync_lds);
         plan->tasks.push_back(pk.task);
     }
 }
@@ -821,6 +859,10 @@ void pack_tasks(ZPlan *plan) {
 
 void pack_tasks_public(ZPlan *plan) { pack_tasks(plan); }
 void set_dict_slots(uint32_t slots) { g_dict_slots = slots >= 512 && slots <= kHufLdsSlots2 ? slots : kHufLdsSlots2; }
+void set_huf_split(uint32_t target_lanes, uint32_t force) {
+    g_split_target = target_lanes;
+    g_split_force = force >= 2 && force <= kHufSplitMax && (force & (force - 1)) == 0 ? force : 0;
+}
 void set_task_lanes(uint32_t lanes) { g_task_lanes = lanes >= 4 && lanes <= static_cast<uint32_t>(kHufWave) ? lanes : kHufWave; }
 
 std::string walk_zstd(const uint8_t *payload, size_t n, ZPlan *master, bool *truncated) {

@@ -83,6 +83,8 @@ bool shard_range(const ZPlan &master, uint32_t shard_rank, uint32_t shard_count,
 void select_zplan(const ZPlan &master, uint32_t b0, uint32_t b1, uint64_t halo_elems, ZPlan *out, bool force_halo = false);
 // packs the tasks of a plan that holds a whole walk (no selection needed)
 void pack_tasks_public(ZPlan *plan);
+// sub-streams (zplan.cpp: g_split_target): sections below `target_lanes` / 2 streams are cut; force: that many parts, always (tests)
+void set_huf_split(uint32_t target_lanes, uint32_t force);
 void set_dict_slots(uint32_t slots);   // LDS budget of a dictionary-format task in 2-byte slots (experiments)
 void set_task_lanes(uint32_t lanes);   // streams per K1 task (experiments; 64 otherwise)
 // walk + (shard) + select: the whole section, or one shard of it, in one call

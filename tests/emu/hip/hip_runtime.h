@@ -90,6 +90,7 @@ inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t shi
 }
 // v_perm_b32: byte select from {hi (bytes 4-7), lo (bytes 0-3)}
 // v_bfe_u32: `width` bits of v from bit `offset`
+inline float __frcp_rn(float x) { return 1.0f / x; }
 inline uint32_t __umul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 inline uint32_t __builtin_amdgcn_ubfe(uint32_t v, uint32_t offset, uint32_t width) {
     offset &= 31u;

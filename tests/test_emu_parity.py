@@ -40,6 +40,33 @@ def test_cases_match_oracle(emu, all_cases):
     assert not bad
 
 
+@pytest.mark.parametrize("parts", [2, 16])
+def test_streams_in_parts(emu, all_cases, parts, monkeypatch):
+    """Huffman streams cut into parts (plan.h: HufStream::sub -- what sections with few streams get, so that a chip's lanes
+    have something to do): forced on EVERY case here, whatever its size -- one-tree (baked), compact and dictionary tables,
+    blocks with sequences (segment-aware streams, literal buffer), escapes, checksummed frames, streams of a few symbols
+    whose parts are empty -- and on corrupted archives, where a part's guessed decode may run into anything."""
+    monkeypatch.setenv("NAFGPU_HUF_SPLIT", str(parts))
+    emu.c.nafgpu_test_hooks(1)
+    try:
+        bad = [name for name, blob, opts in all_cases if cases.run_product(blob, opts, emu) != cases.run_oracle(blob, opts)]
+        for name in ("phix", "masked", "CP040672", "NZ_AAEN01000029"):
+            blob = golden_bytes(name + ".naf")
+            if cases.run_product(blob, {}, emu) != cases.run_oracle(blob, {}):
+                bad.append(name)
+        bad += cases.fuzz_disagreements(cases.fuzz_cases(seed=13, n=60), emu)
+        assert not bad
+        if parts == 2:                                      # ... and in tiles, and as block ranges of several ranks
+            monkeypatch.setenv("NAFGPU_TILE_KIB", "256")
+            blob = golden_bytes("NZ_AAEN01000029.naf")
+            assert cases.run_product(blob, {}, emu) == cases.run_oracle(blob, {})
+            monkeypatch.delenv("NAFGPU_TILE_KIB")
+            cases.check_sharding(emu, 1_500_000, True, worlds=(3,))
+            cases.check_lz_sharding(emu, 1, worlds=(3,), names=("real_genome_l1",))
+    finally:
+        emu.c.nafgpu_test_hooks(0)
+
+
 def test_zstd_multi_frame_many_blocks(emu):
     from oracle import oracle
     for name, payload, data in cases.zstd_payload_cases(scale=1):
@@ -258,6 +285,13 @@ todo += [(n, golden_bytes(n + ".naf"), {}) for n in ("phix", "masked", "CP040672
 todo = todo[part::parts]
 bad = [n for n, blob, opts in todo if cases.run_product(blob, opts, lib) != cases.run_oracle(blob, opts)]
 bad += cases.fuzz_disagreements(cases.fuzz_cases(seed=7, n=40)[part::parts], lib)      # corrupted archives: no OOB, no silent garbage
+import os
+os.environ["NAFGPU_HUF_SPLIT"] = "4"                     # ... and with every Huffman stream cut into parts (plan.h: HufStream::sub)
+lib.c.nafgpu_test_hooks(1)
+bad += ["parts:" + n for n, blob, opts in todo if cases.run_product(blob, opts, lib) != cases.run_oracle(blob, opts)]
+bad += ["parts:" + n for n in cases.fuzz_disagreements(cases.fuzz_cases(seed=7, n=40)[part::parts], lib)]
+del os.environ["NAFGPU_HUF_SPLIT"]
+lib.c.nafgpu_test_hooks(0)
 import io
 from nafcodec_amd.decoder import Decoder
 bad += ["text:" + n for n, blob in cases.text_cases(1)[part::parts] if Decoder(io.BytesIO(blob), _lib=lib).to_text() != cases.oracle_text(blob)]

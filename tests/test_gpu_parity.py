@@ -232,6 +232,28 @@ def test_gigabase_archive_against_the_oracle(lib):
         lib.c.nafgpu_synth_free(ctypes.byref(arc))
 
 
+@pytest.mark.parametrize("parts", [2, 16])
+def test_streams_in_parts(lib, parts, monkeypatch):
+    """Huffman streams cut into parts (plan.h: HufStream::sub; sections with fewer streams than half the chip's lanes get
+    them by themselves -- every fixture here does), forced on every shared case at 4x the harness sizes: all three table
+    formats, segment-aware streams and the literal buffer, escapes, parts without symbols; corrupted archives; the
+    reference's genome fixture as three block ranges through the shard protocol."""
+    monkeypatch.setenv("NAFGPU_HUF_SPLIT", str(parts))
+    lib.c.nafgpu_test_hooks(1)
+    try:
+        bad = [name for name, blob, opts in cases.build_cases(scale=4) if cases.run_product(blob, opts) != cases.run_oracle(blob, opts)]
+        for name in FIXTURES:
+            blob = golden_bytes(name + ".naf")
+            if cases.run_product(blob, {}) != cases.run_oracle(blob, {}):
+                bad.append(name)
+        bad += cases.fuzz_disagreements(cases.fuzz_cases(seed=13, n=60))
+        assert not bad
+        if parts == 2:
+            cases.check_lz_sharding(None, 1, worlds=(3,), names=("real_genome_l1",))
+    finally:
+        lib.c.nafgpu_test_hooks(0)
+
+
 def test_next_batch_equals_next(lib):
     """nafgpu_next_batch against nafgpu_next through the C-ABI on the GPU: fixtures, the shared cases at 4x the harness
     sizes (malformed archives included), batch sizes 1 .. 4096."""

@@ -5,6 +5,7 @@ import numpy as np
 import zstd_ref, naf_writer as nw
 import nafcodec_amd
 from nafcodec_amd import _ffi
+if os.environ.get("NAFGPU_PROBE_HOOKS"): _ffi.default().c.nafgpu_test_hooks(1)   # (experiments: the NAFGPU_* switches are read)
 rng = np.random.default_rng(2)
 n_reads = int(float(sys.argv[1]) if len(sys.argv) > 1 else 2e6)
 L = 151

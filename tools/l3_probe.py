@@ -4,6 +4,7 @@ import numpy as np
 import zstd_ref, naf_writer as nw
 import nafcodec_amd
 from nafcodec_amd import _ffi
+if os.environ.get("NAFGPU_PROBE_HOOKS"): _ffi.default().c.nafgpu_test_hooks(1)   # (experiments: the NAFGPU_* switches are read)
 rng = np.random.default_rng(1)
 n_packed = int(float(sys.argv[1]) if len(sys.argv) > 1 else 64e6)
 for level in ([int(sys.argv[2])] if len(sys.argv) > 2 else [1, 3]):

@@ -4,6 +4,8 @@ import os, sys, time
 R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 import nafcodec_amd
+from nafcodec_amd import _ffi
+if os.environ.get("NAFGPU_PROBE_HOOKS"): _ffi.default().c.nafgpu_test_hooks(1)   # (experiments: the NAFGPU_* switches are read)
 for name in ("NZ_AAEN01000029.naf", "masked.naf", "phix.naf", "LuxC.naf"):
     path = os.path.join(R, "tests", "golden", name)
     if not os.path.exists(path):

@@ -47,6 +47,8 @@ def parse_args():
                          "this many times, libzstd level 1) and report it as path.real_genome; 0 skips it")
     ap.add_argument("--small-real-copies", type=int, default=565,
                     help="N=1 only: the same at the size of a human genome (x 565 = 3.1 Gbases), reported as path.real_genome_3g; 0 skips it")
+    ap.add_argument("--l3-bases", type=float, default=1.024e9,
+                    help="level-3 DNA leg (path.l3_dna): bases of iid ACGT written by libzstd at level 3; 0 = skip")
     ap.add_argument("--fastq-reads", type=float, default=10e6,
                     help="N=1 only: a FASTQ-shaped archive of this many 151-base reads (bulk decode + the record iterator), path.fastq_like; 0 skips it")
     ap.add_argument("--no-masked-leg", action="store_true", help="N=1 only: skip path.masked (configs[3]: the headline archive with a Mask section)")
@@ -325,6 +327,64 @@ def fixtures_leg(device):
         out[name] = {"records": j["records"], "bases": j["bases"], "ms_per_archive": round(j["best_cycle_ms"], 3),
                      "first_in_process_ms": round(j["first_cycle_ms"], 1)}
     return out or None
+
+
+def l3_dna_leg(lib, device, n_bases):
+    """Level-3 DNA: `n_bases` of iid ACGT written by the system libzstd at level 3 -- about half the bytes are matches at
+    random distances in the window, the rest Huffman literals (what the reference's Encoder writes by default is this
+    shape, encoder/mod.rs:81,137): the sequence-chain / pointer-jumping stages of the path and none of the headline's.
+    Best of three decodes; output checksum against what was written."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import zstd_ref
+    if not zstd_ref.available():
+        return None
+    rng = np.random.default_rng(1)
+    n_packed = n_bases // 2
+    n_bases = 2 * n_packed
+    codes = np.array([1, 2, 4, 8], dtype=np.uint8)
+    packed = (codes[rng.integers(0, 4, n_packed)] | (codes[rng.integers(0, 4, n_packed)] << 4)).astype(np.uint8)
+    payload = zstd_ref.compress_magicless(packed.tobytes(), 3, True)
+
+    def varint(v):
+        out = [v & 0x7F]
+        v >>= 7
+        while v:
+            out.append(0x80 | (v & 0x7F))
+            v >>= 7
+        return bytes(reversed(out))
+
+    lens = n_bases.to_bytes(4, "little")
+    len_frame = bytes([0x20, 4, (4 << 3) | 1, 0, 0]) + lens                    # single-segment frame, one raw block
+    blob = (bytes([1, 0xF9, 0xEC, 1, 0x0A, 0x20]) + varint(60) + varint(1) + varint(4) + varint(len(len_frame)) + len_frame +
+            varint(n_bases) + varint(len(payload)) + payload)
+    lut = np.frombuffer(b"-TGKCYSBAWRDMHVN", dtype=np.uint8)
+    want = np.empty(n_bases, dtype=np.uint8)
+    want[0::2] = lut[packed & 15]
+    want[1::2] = lut[packed >> 4]
+    want_hash = lib.c.nafgpu_hash64_host(want.tobytes(), n_bases)
+    del want, packed
+    h, res = _decode_bulk(lib, device, blob)
+    try:
+        best = None
+        for _ in range(3):
+            if lib.c.nafgpu_decode_all_device(h, ctypes.byref(res)) != 0:
+                raise RuntimeError("decode failed")
+            if best is None or res.ms_total < best[0]:
+                best = (res.ms_total, res.ms_huf, res.ms_seq_lz, res.ms_other)
+        hs = ctypes.c_uint64()
+        lib.c.nafgpu_hash64_device(h, res.d_sequence, res.n_bases, ctypes.byref(hs))
+        if hs.value != want_hash or res.n_bases != n_bases:
+            raise RuntimeError("level-3 DNA leg: decoded bases differ from what was written")
+    finally:
+        lib.c.nafgpu_close(h)
+    alg = len(payload) + n_bases
+    return {"workload": "%d bases of iid ACGT, libzstd level 3 (%.3f B/base: half the bytes are matches at random distances, every block has "
+                        "thousands of LZ sequences); output checksum equals what was written" % (n_bases, len(payload) / n_bases),
+            "bases": n_bases, "ms_per_step": round(best[0], 3), "value": round(n_bases / best[0] / 1e6, 1), "unit": "Gbases/s",
+            "ms_huf": round(best[1], 3), "ms_seq_lz": round(best[2], 3),
+            "roofline": {"bound": "hbm", "achieved": round(alg / (best[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / (best[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": int(alg)}}
 
 
 def fastq_like_leg(lib, device, n_reads, level=1):
@@ -727,6 +787,8 @@ def main():
             line["path"]["real_genome_3g"] = real_genome_leg(lib, device, args.small_real_copies)
         if args.fastq_reads and world == 1 and not args.rehearsal_lib:
             line["path"]["fastq_like"] = fastq_like_leg(lib, device, int(args.fastq_reads))
+        if args.l3_bases and world == 1 and not args.rehearsal_lib:
+            line["path"]["l3_dna"] = l3_dna_leg(lib, device, int(args.l3_bases))
         if not args.no_iterator and world == 1 and not args.rehearsal_lib:
             line["path"]["fixtures"] = fixtures_leg(device)
             # the headline archive through the drop-in API: Decoder::from_path + Iterator::next (a file, as the reference reads one)

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -31,10 +32,60 @@ namespace {
 // consumed front to back, so one sliding window replaces the reference's per-record Strings.
 // The section may be resident whole, or a tile at a time (SectionJob::tiled_output): the window then
 // asks for the next tile whenever it runs off the end of the one in HBM -- positions only move forward.
+// Pinned memory outlives decoders: hipHostMalloc + hipHostFree of the window were 1.5 of the 5 ms a 5-Mbase archive takes open to
+// close (a caller that walks a directory of genomes pays them per file).  A closed decoder's windows go to a small per-process
+// pool -- at most kPinnedPoolKeep buffers -- and the next decoder takes the smallest one that is large enough.
+class PinnedPool {
+public:
+    static PinnedPool &get() {
+        static PinnedPool p;
+        return p;
+    }
+    uint8_t *take(uint64_t want, uint64_t *cap) {
+        std::lock_guard<std::mutex> g(mu_);
+        int best = -1;
+        for (int i = 0; i < n_; i++)
+            if (cap_[i] >= want && (best < 0 || cap_[i] < cap_[best])) best = i;
+        if (best < 0) return nullptr;
+        uint8_t *p = buf_[best];
+        *cap = cap_[best];
+        buf_[best] = buf_[n_ - 1];
+        cap_[best] = cap_[n_ - 1];
+        n_--;
+        return p;
+    }
+    void give(uint8_t *p, uint64_t cap) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (n_ < kPinnedPoolKeep) {
+                buf_[n_] = p;
+                cap_[n_] = cap;
+                n_++;
+                return;
+            }
+            int small = 0;                                 // full: the smallest buffer makes room for a larger one
+            for (int i = 1; i < n_; i++)
+                if (cap_[i] < cap_[small]) small = i;
+            if (cap_[small] < cap) {
+                std::swap(buf_[small], p);
+                std::swap(cap_[small], cap);
+            }
+        }
+        (void)hipHostFree(p);
+    }
+
+private:
+    static constexpr int kPinnedPoolKeep = 4;
+    std::mutex mu_;
+    uint8_t *buf_[kPinnedPoolKeep] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t cap_[kPinnedPoolKeep] = {0, 0, 0, 0};
+    int n_ = 0;
+};
+
 class HostWindow {
 public:
     ~HostWindow() {
-        if (buf_) (void)hipHostFree(buf_);
+        if (buf_) PinnedPool::get().give(buf_, cap_);
     }
     void bind(ArchiveJob *job, int section, uint64_t mult, uint64_t total, uint64_t window) {
         job_ = job;
@@ -53,15 +104,16 @@ public:
         const uint64_t want = std::max(len, std::min(window_, total_ - start));
         const uint64_t keep = (start >= lo_ && start < hi_) ? hi_ - start : 0;   // already on the host (a record straddling the old window)
         if (want > cap_) {
-            void *p = nullptr;
-            if (hipHostMalloc(&p, want) != hipSuccess) {
+            uint64_t cap = want;
+            void *p = PinnedPool::get().take(want, &cap);
+            if (!p && hipHostMalloc(&p, want) != hipSuccess) {
                 *f = Failure::make(NAFGPU_E_DEVICE, "cannot allocate the pinned read-back window");
                 return nullptr;
             }
             if (keep) std::memcpy(p, buf_ + (start - lo_), keep);
-            if (buf_) (void)hipHostFree(buf_);
+            if (buf_) PinnedPool::get().give(buf_, cap_);
             buf_ = static_cast<uint8_t *>(p);
-            cap_ = want;
+            cap_ = cap;
         } else if (keep) {
             std::memmove(buf_, buf_ + (start - lo_), keep);
         }

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
 out=gpurun_out/pmc_$tag
 rm -rf "$out"
-rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d "$out" -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-verify --real-copies 0 --small-real-copies 0 --fastq-reads 0 --no-iterator --no-masked-leg > gpurun_out/pmc_$tag.log 2>&1
+rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d "$out" -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-verify --real-copies 0 --small-real-copies 0 --fastq-reads 0 --l3-bases 0 --no-iterator --no-masked-leg > gpurun_out/pmc_$tag.log 2>&1
 python3 - "$out" "$tag" <<'PY'
 import csv, glob, sys, collections
 out, tag = sys.argv[1], sys.argv[2]

@@ -125,7 +125,8 @@ class Library:
         L.nafgpu_remaining.argtypes = [c_void_p]
         L.nafgpu_remaining.restype = c_uint64
         L.nafgpu_next.argtypes = [c_void_p, POINTER(Record)]
-        L.nafgpu_next_batch.argtypes = [c_void_p, POINTER(Record), ctypes.c_uint64, POINTER(ctypes.c_uint64)]
+        if hasattr(L, "nafgpu_next_batch"):                  # (absent from older builds loaded for A/B runs: tools/*_probe.py)
+            L.nafgpu_next_batch.argtypes = [c_void_p, POINTER(Record), ctypes.c_uint64, POINTER(ctypes.c_uint64)]
         L.nafgpu_close.argtypes = [c_void_p]
         L.nafgpu_close.restype = None
         L.nafgpu_last_error.argtypes = [c_void_p, POINTER(Error)]

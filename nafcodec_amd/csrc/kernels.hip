@@ -2957,6 +2957,10 @@ constexpr uint32_t kPjSweeps = 24;           // a sweep at least halves every ch
 // for them ("literal, value in the output").  What lies between the blocks with sequences (raw / RLE / literal-only
 // blocks, the window in front of a tile) gets zeros from the block behind it; the last block also zeroes the tail up to
 // n_elems.  skip_lo: leading elements that are somebody else's (a shard's window that has not arrived: kPjWait).
+// (Round 4, measured and dropped: sequence-ordered once more, but through LDS -- every thread writes the elements of ITS
+//  sequence into a 4 096-element window that then leaves as 16-byte stores, long sequences by the whole workgroup: no search, no
+//  selects -- and 2.5 ms against 1.57 on level-3 DNA, 31.4 against 28.8 ms on the FASTQ-like probe
+//  (profiles/r04_fill_ab.log): a wave's loop is as long as its longest sequence, three to five times the mean.)
 constexpr uint32_t kFillPer = 8;              // elements a thread of k_pj_fill takes per step
 template <bool ASCII>
 __global__ __launch_bounds__(256) void k_pj_fill(const SeqBlock *__restrict__ blocks, uint32_t n_blocks, const Seq *__restrict__ seqs,
@@ -2964,9 +2968,11 @@ __global__ __launch_bounds__(256) void k_pj_fill(const SeqBlock *__restrict__ bl
                                                  uint32_t *D, const uint8_t *__restrict__ lit, uint32_t *blk_pending,
                                                  uint32_t t_char, uint32_t n_sel_blocks, uint64_t n_elems, uint64_t skip_lo, uint32_t *status) {
     __shared__ uint32_t s_opos[257], s_ll[256], s_off[256], s_lpos[256];
+    __shared__ uint16_t s_chars[ASCII ? 256 : 2];          // the two characters of a packed byte (byte_chars costs twenty instructions a literal)
     __shared__ uint32_t s_abort;
     const uint32_t tid = threadIdx.x;
     if (tid == 0) s_abort = status[0];
+    if (ASCII) s_chars[tid] = static_cast<uint16_t>(byte_chars(tid, t_char));
     __syncthreads();
     if (s_abort) return;
     auto zero_range = [&](uint64_t lo, uint64_t hi) {      // D[lo, hi) = 0, by the whole workgroup (lo, hi uniform)
@@ -2981,7 +2987,7 @@ __global__ __launch_bounds__(256) void k_pj_fill(const SeqBlock *__restrict__ bl
         for (uint64_t e = a0 + 4ull * tid; e < a1; e += 1024) *reinterpret_cast<uint4 *>(D + e) = make_uint4(0, 0, 0, 0);
         for (uint64_t e = a1 + tid; e < hi; e += 256) D[e] = 0;
     };
-    auto lit_word = [&](uint8_t c) -> uint32_t { return kPjFinal | (ASCII ? byte_chars(c, t_char) : static_cast<uint32_t>(c)); };
+    auto lit_word = [&](uint8_t c) -> uint32_t { return kPjFinal | (ASCII ? static_cast<uint32_t>(s_chars[c]) : static_cast<uint32_t>(c)); };
     for (uint32_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
         const SeqBlock sb = blocks[b];
         const uint64_t obase = blk_base[sb.blk], fstart = blk_base[sb.frame_first_blk];
@@ -3181,7 +3187,7 @@ template <bool ASCII, uint32_t WIN>
 __global__ __launch_bounds__(256, WIN ? 5 : 6) void k_pj_sweep(uint32_t *D, uint8_t *out_bytes, uint32_t *tile_pending, unsigned long long *pcount,
                                                   uint64_t n_elems, uint32_t sweep, uint32_t max_dist, uint32_t *list_out,
                                                   uint64_t list_cap, unsigned long long *lstate, uint32_t first_list, uint32_t hops,
-                                                  const uint32_t *status) {
+                                                  uint32_t emit_now, uint32_t xcd_map, const uint32_t *status) {   // emit_now: 0 no, 1 every final element, 2 what this sweep made final
     using Elem = typename std::conditional<ASCII, uint16_t, uint8_t>::type;
     Elem *out = reinterpret_cast<Elem *>(out_bytes);
     constexpr uint32_t kSlots = WIN + 1;
@@ -3222,7 +3228,16 @@ __global__ __launch_bounds__(256, WIN ? 5 : 6) void k_pj_sweep(uint32_t *D, uint
     const uint64_t n_tiles = (n_elems + kPjTile - 1) / kPjTile;
     // WIN: a strip of consecutive tiles per workgroup; else tiles dealt round robin
     const uint64_t per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
-    const uint64_t t_first = WIN ? blockIdx.x * per_wg : blockIdx.x;
+    // Which tiles a workgroup takes follows the chip: workgroups b and b + 8 run on the same XCD -- one L2 -- and an element's
+    // source lies within a window (a few hundred tiles) in front of it, so the workgroups of ONE XCD take NEIGHBOURING strips
+    // (tiles): what they gather was read or written a moment ago by a neighbour on the same L2.  Dealt in launch order,
+    // neighbouring strips sit on eight different L2s and every gather goes to memory.  (xcd_map 0: launch order.)
+    uint32_t slot = blockIdx.x;                             // position of this workgroup in tile order
+    if (xcd_map && gridDim.x >= 16u) {
+        const uint32_t per_xcd = gridDim.x / 8u, body = per_xcd * 8u;   // (the last gridDim.x % 8 workgroups keep their places)
+        if (blockIdx.x < body) slot = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
+    }
+    const uint64_t t_first = WIN ? slot * per_wg : slot;
     const uint64_t t_last = WIN ? (t_first + per_wg < n_tiles ? t_first + per_wg : n_tiles) : n_tiles;
     const uint64_t t_step = WIN ? 1 : gridDim.x;
     uint32_t flip = 0;
@@ -3389,6 +3404,30 @@ __global__ __launch_bounds__(256, WIN ? 5 : 6) void k_pj_sweep(uint32_t *D, uint
                     *reinterpret_cast<uint4 *>(D + p[half]) = make_uint4(v[half][0], v[half][1], v[half][2], v[half][3]);
                 } else {
                     for (uint32_t k = 0; k < static_cast<uint32_t>(n_elems - p[half]); k++) D[p[half] + k] = v[half][k];
+                }
+            }
+            // ... and the elements that are final go to the output: in the first sweep all of them (the literals' words are
+            // final since k_pj_fill), later what this sweep made final.  A thread's four elements are consecutive and so are the
+            // threads: the wave writes 256 (512) contiguous bytes where everything is final -- no pass over D afterwards
+            // (k_pj_emit read all of it again: 6 GB for the qualities of 10 M reads).
+            if (emit_now) {
+                const uint32_t sel = emit_now == 1u ? 15u : (dirty >> (4 * half)) & 15u;
+                uint32_t fin = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++)
+                    if (v[half][k] >= kPjFinal && ((sel >> k) & 1u) && p[half] + k < n_elems) fin |= 1u << k;
+                if (fin == 15u) {
+                    if (ASCII) {                           // (the output of a tile need not be aligned: memcpy)
+                        const uint32_t x[2] = {(v[half][0] & 0xFFFFu) | (v[half][1] << 16), (v[half][2] & 0xFFFFu) | (v[half][3] << 16)};
+                        __builtin_memcpy(out + p[half], x, 8);
+                    } else {
+                        const uint32_t x = (v[half][0] & 0xFFu) | ((v[half][1] & 0xFFu) << 8) | ((v[half][2] & 0xFFu) << 16) | (v[half][3] << 24);
+                        __builtin_memcpy(out + p[half], &x, 4);
+                    }
+                } else if (fin) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++)
+                        if (fin & (1u << k)) out[p[half] + k] = static_cast<Elem>(v[half][k] & 0xFFFFu);
                 }
             }
             // (WIN) ... and into the slot, as the tiles behind this one will find them
@@ -4211,6 +4250,13 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
         const uint32_t max_dist = pj_max_dist();
         // look-ups per element and pass (k_pj_sweep); and whether the FIRST sweep already lists what it leaves pending
         uint32_t hops = a.strips ? kPjHops : kPjHopsDeep, first_list = a.shallow;
+        // the sweeps write what they make final to the output themselves (no k_pj_emit pass behind them)
+        bool fused_emit = true;
+        if (const char *e = hook_env("NAFGPU_PJ_EMIT")) fused_emit = e[0] != '1';     // 1: the separate pass (measurements)
+        // tiles follow the XCDs where most sources are final early (half the elements or more are literals: level-3 DNA 6.05 ->
+        // 5.81 ms); where chains are deep it loses (FASTQ-like level 3 63.3 -> 66.4 ms), level 1 is indifferent (profiles/r04_pj_xcd_probe.log)
+        uint32_t xcd_map = a.shallow ? 1u : 0u;
+        if (const char *e = hook_env("NAFGPU_PJ_XCD")) xcd_map = e[0] == '0' ? 0u : 1u;
         if (const char *e = hook_env("NAFGPU_PJ_HOPS")) hops = static_cast<uint32_t>(std::atoi(e)) > 0 ? static_cast<uint32_t>(std::atoi(e)) : 1u;
         if (const char *e = hook_env("NAFGPU_PJ_FIRST_LIST")) first_list = e[0] == '1' ? 1u : 0u;
         uint64_t tiles = (a.n_elems + kPjTile - 1) / kPjTile;
@@ -4250,16 +4296,17 @@ static void lz_execute(hipStream_t stream, const LzArgs &a) {
             if (a.strips && sweep <= kPjStripSweeps)
                 hipLaunchKernelGGL((k_pj_sweep<ASCII, kPjWin>), dim3(static_cast<uint32_t>(strips)), dim3(256), 0, stream, a.pj_dist, a.out,
                                    a.pj_tiles, pcount, a.n_elems, sweep, max_dist, can_list ? lists[sweep & 1u] : nullptr, a.pj_list_cap, lstate,
-                                   first_list, hops, a.status);
+                                   first_list, hops, fused_emit ? (sweep == 1 ? 1u : 2u) : 0u, xcd_map, a.status);
             else
                 hipLaunchKernelGGL((k_pj_sweep<ASCII, 0u>), dim3(static_cast<uint32_t>(tiles)), dim3(256), 0, stream, a.pj_dist, a.out,
                                    a.pj_tiles, pcount, a.n_elems, sweep, max_dist, can_list ? lists[sweep & 1u] : nullptr, a.pj_list_cap,
-                                   lstate, first_list, hops, a.status);
+                                   lstate, first_list, hops, fused_emit ? (sweep == 1 ? 1u : 2u) : 0u, xcd_map, a.status);
             if (can_list && sweep >= 2)
                 hipLaunchKernelGGL(k_pj_list<ASCII>, dim3(list_grid), dim3(256), 0, stream, a.pj_dist, a.out, pcount,
-                                   lists[(sweep & 1u) ^ 1u], lists[sweep & 1u], a.pj_list_cap, lstate, sweep, max_dist, finish ? 1u : 0u, hops, a.status);
+                                   lists[(sweep & 1u) ^ 1u], lists[sweep & 1u], a.pj_list_cap, lstate, sweep, max_dist, (finish || fused_emit) ? 1u : 0u, hops, a.status);
         }
         // (finish: the list passes wrote the output themselves; sweeps over all of D did not)
+        if (!fused_emit)
         hipLaunchKernelGGL(k_pj_emit<ASCII>, dim3(static_cast<uint32_t>(eg)), dim3(256), 0, stream, a.pj_dist, a.out, a.n_elems,
                            finish ? static_cast<const unsigned long long *>(lstate + 3) : static_cast<const unsigned long long *>(nullptr),
                            static_cast<unsigned long long>(kPjSweeps), a.status);

@@ -2937,7 +2937,9 @@ constexpr uint32_t kPjWait = kPjFinal - 1u;  // an element of the window in fron
 __device__ inline bool pj_pending(uint32_t v) { return v - 1u < kPjWait - 1u; }   // 1 <= v < kPjWait: a distance
 constexpr uint32_t kPjLocal = 4;             // jumps inside the tile (LDS) before a sweep looks into memory
 constexpr uint32_t kPjStripSweeps = 1;       // ... for the first this-many sweeps; what they leave is scattered: tile-wise from there
-constexpr uint32_t kPjWin = 1;               // tiles a strip-wise sweep keeps in LDS behind the current one (k_pj_sweep)
+constexpr uint32_t kPjWin = 1;               // tiles a strip-wise sweep keeps in LDS behind the current one (k_pj_sweep).  (Round 4: the held tiles as
+                                             // 16-bit words -- final 0xFF00 | byte, distances below 0xFE00, else "ask memory" -- and THREE of them in the
+                                             // same LDS: 29.1-29.3 against 28.3 ms on the FASTQ-like probe, profiles/r04_narrow_lds_ab.log: dropped.)
 constexpr uint32_t kPjHops = 2;              // look-ups per element and pass (a pending source hands over its distance: look again) ...
 constexpr uint32_t kPjHopsDeep = 4;          // ... where chains are deep (few literals: no strip-wise sweep).  Same box, hops 1 / 2 / 3 / 4
                                              // (profiles/r04_pj_hops_probe.log): FASTQ-like level 1 29.85 / 28.41 / 28.81 / 29.27 ms, level 3

@@ -60,6 +60,7 @@ int main(int argc, char **argv) {
         return 2;
     }
     if (argc > 3 && std::atoi(argv[3]) > 1) return repeat_mode(argv[1], std::atoi(argv[2]), std::atoi(argv[3]));
+    if (argc > 5 && std::atoi(argv[5])) nafgpu_test_hooks(1);        // (experiments: the library reads its NAFGPU_* switches)
     nafgpu_opts opts;
     nafgpu_opts_default(&opts);
     opts.device = argc > 2 ? std::atoi(argv[2]) : 0;

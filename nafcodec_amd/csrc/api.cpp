@@ -149,7 +149,7 @@ public:
             }
             const uint64_t n = std::min(end, held1) - pos;
             if (n == 0) break;
-            *f = job_->copy_to_host(buf_ + (pos - start), d_held + (pos - held0), n);
+            *f = job_->copy_to_pinned(buf_ + (pos - start), d_held + (pos - held0), n);
             if (!f->ok()) return nullptr;
             pos += n;
         }

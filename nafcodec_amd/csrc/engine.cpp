@@ -5,6 +5,9 @@
 #include <cstdlib>
 
 #include <atomic>
+#include <algorithm>
+#include <vector>
+#include <thread>
 #include <map>
 #include <mutex>
 #include <chrono>
@@ -231,6 +234,78 @@ StageTimes StageTimer::collect() {
 }
 
 // ------------------------------------------------------------------ SectionJob
+// Host -> device for the compressed bytes of a section.  One hipMemcpyAsync out of ordinary or mapped memory moves at PCIe rate in
+// one process and at a quarter of it in the next -- the runtime's copy engines again (see k_copy_out: 10 GB in 0.2 s or in 1.2 s,
+// tools/iter_regime_probe.py) -- so large uploads take the same road as the read-back: kStageThreads host threads copy their
+// chunks of the source into pinned buffers (two of 16 MiB each, so the memcpy of one overlaps the transfer of the other; the
+// page faults of a file mapping spread over the threads as well), and the GPU fetches every chunk itself (k_copy_out with
+// the pinned buffer as its source).  Returns when every byte is on the device.
+#ifndef NAFGPU_EMU
+namespace {
+constexpr size_t kStageChunk = size_t(16) << 20;
+constexpr unsigned kStageThreads = 8;
+constexpr size_t kStageMin = size_t(256) << 20;            // smaller uploads: one plain copy
+struct StageSlot {
+    uint8_t *buf[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr;
+    hipEvent_t done[2] = {nullptr, nullptr};
+};
+std::mutex g_stage_mu;                                     // one staged upload at a time per process (the buffers are shared)
+StageSlot g_stage[kStageThreads];
+bool g_stage_ready = false, g_stage_failed = false;
+bool stage_init() {
+    if (g_stage_ready) return true;
+    if (g_stage_failed) return false;
+    for (unsigned t = 0; t < kStageThreads; t++) {
+        StageSlot &sl = g_stage[t];
+        bool ok = hipStreamCreate(&sl.stream) == hipSuccess;
+        for (int k = 0; k < 2 && ok; k++)
+            ok = hipHostMalloc(reinterpret_cast<void **>(&sl.buf[k]), kStageChunk) == hipSuccess &&
+                 hipEventCreateWithFlags(&sl.done[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            g_stage_failed = true;                         // (what was allocated stays: a plain copy serves from here on)
+            return false;
+        }
+    }
+    g_stage_ready = true;
+    return true;
+}
+}  // namespace
+#endif
+
+bool upload_staged(uint8_t *d_dst, const uint8_t *src, size_t n, hipStream_t stream) {
+#ifndef NAFGPU_EMU
+    if (n >= kStageMin && !hook_env("NAFGPU_NO_STAGING")) {
+        std::lock_guard<std::mutex> guard(g_stage_mu);
+        if (stage_init() && hipStreamSynchronize(stream) == hipSuccess) {   // (what was enqueued in front -- the pad memsets -- is done)
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            const size_t n_chunks = (n + kStageChunk - 1) / kStageChunk;
+            std::atomic<bool> failed{false};
+            auto worker = [&](unsigned t) {
+                (void)hipSetDevice(dev);
+                StageSlot &sl = g_stage[t];
+                unsigned k = 0;
+                for (size_t c = t; c < n_chunks && !failed.load(); c += kStageThreads, k ^= 1u) {
+                    const size_t off = c * kStageChunk, len = std::min(kStageChunk, n - off);
+                    if (hipEventSynchronize(sl.done[k]) != hipSuccess) failed = true;   // (the kernel that last read this buffer)
+                    std::memcpy(sl.buf[k], src + off, len);
+                    launch_copy_out(sl.stream, d_dst + off, sl.buf[k], len);
+                    if (hipGetLastError() != hipSuccess || hipEventRecord(sl.done[k], sl.stream) != hipSuccess) failed = true;
+                }
+                if (hipStreamSynchronize(sl.stream) != hipSuccess) failed = true;
+            };
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < kStageThreads; t++) pool.emplace_back(worker, t);
+            worker(0);
+            for (std::thread &th : pool) th.join();
+            return !failed.load();
+        }
+    }
+#endif
+    return hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, stream) == hipSuccess;
+}
+
 Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expect_size, hipStream_t stream,
                             const SectionOptions &opt) {
     ready_ = false;
@@ -469,7 +544,7 @@ Failure SectionJob::load_tile(uint32_t t, hipStream_t stream) {
         if (ok) {
             (void)hipMemsetAsync(d_src_buf_.bytes(), 0, kSrcFrontPad, stream);
             (void)hipMemsetAsync(d_src_buf_.bytes() + kSrcFrontPad + src_n, 0, kSrcBackPad, stream);
-            if (src_n) ok = hip_ok(hipMemcpyAsync(d_src_buf_.bytes() + kSrcFrontPad, host_payload_ + plan_.src_lo, src_n, hipMemcpyHostToDevice, stream));
+            if (src_n) ok = upload_staged(d_src_buf_.bytes() + kSrcFrontPad, host_payload_ + plan_.src_lo, static_cast<size_t>(src_n), stream);
             d_src_ = d_src_buf_.bytes() + kSrcFrontPad - plan_.src_lo;     // kernels address the payload by its offsets
         }
         ok = ok && d_blk_size_.upload(plan_.blk_size.data(), n_blocks_ * sizeof(uint32_t), stream) &&
@@ -1480,6 +1555,17 @@ Failure ArchiveJob::copy_to_host(void *dst, const void *d_src, size_t n) {
     if (!n) return Failure();
     (void)hipSetDevice(device_);
     if (!hip_ok(hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, stream_)) || !hip_ok(hipStreamSynchronize(stream_)))
+        return Failure::make(NAFGPU_E_DEVICE, "device-to-host copy failed");
+    return Failure();
+}
+
+// ... into memory the caller got from hipHostMalloc (the record iterator's window): the GPU stores it there itself (k_copy_out)
+Failure ArchiveJob::copy_to_pinned(void *dst_pinned, const void *d_src, size_t n) {
+    if (!n) return Failure();
+    (void)hipSetDevice(device_);
+    if (n < (size_t(1) << 20) || hook_env("NAFGPU_D2H_MEMCPY")) return copy_to_host(dst_pinned, d_src, n);   // small: one call is one call
+    launch_copy_out(stream_, static_cast<uint8_t *>(dst_pinned), static_cast<const uint8_t *>(d_src), n);
+    if (!hip_ok(hipGetLastError()) || !hip_ok(hipStreamSynchronize(stream_)))
         return Failure::make(NAFGPU_E_DEVICE, "device-to-host copy failed");
     return Failure();
 }

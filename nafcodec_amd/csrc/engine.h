@@ -236,6 +236,8 @@ struct ArchiveOptions {
     bool tiled_output = false;                  // ... whose output is held one tile at a time (iterator path; not for decode_all_device)
 };
 
+bool upload_staged(uint8_t *d_dst, const uint8_t *src, size_t n, hipStream_t stream);   // engine.cpp: large host -> device copies
+
 // A whole archive on one GPU: sections -> record table -> ASCII bases.
 class ArchiveJob {
 public:
@@ -290,6 +292,7 @@ public:
     Failure format_text(bool with_ids, bool with_comments, bool with_quality, uint64_t n_rec, const uint8_t **d_text, uint64_t *n_text,
                         float *ms);
     Failure copy_to_host(void *dst, const void *d_src, size_t n);
+    Failure copy_to_pinned(void *dst_pinned, const void *d_src, size_t n);   // dst from hipHostMalloc: the GPU writes it (k_copy_out)
     Failure hash_device(const void *d_ptr, uint64_t n, uint64_t first_chunk, uint64_t *out);
 
 private:

@@ -56,7 +56,7 @@ static int repeat_mode(const char *path, int device, int repeat) {
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        std::fprintf(stderr, "usage: iter_bench ARCHIVE.naf [device [repeat [batch]]]\n");
+        std::fprintf(stderr, "usage: iter_bench ARCHIVE.naf [device [repeat [batch [hooks [tile_mib]]]]]\n");
         return 2;
     }
     if (argc > 3 && std::atoi(argv[3]) > 1) return repeat_mode(argv[1], std::atoi(argv[2]), std::atoi(argv[3]));
@@ -64,6 +64,7 @@ int main(int argc, char **argv) {
     nafgpu_opts opts;
     nafgpu_opts_default(&opts);
     opts.device = argc > 2 ? std::atoi(argv[2]) : 0;
+    if (argc > 6) opts.tile_mib = std::atoi(argv[6]);                // decode in tiles of this many MiB of output (nafgpu_opts.tile_mib)
     nafgpu_decoder *dec = nullptr;
     nafgpu_error err;
     const double t_open = now_s();

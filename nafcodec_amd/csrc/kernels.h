@@ -154,5 +154,6 @@ void launch_xxh64_frames(hipStream_t stream, const XxhSeg *segs, uint32_t n_segs
 // order-sensitive checksum of a device buffer (see hash64.h); *result must be zeroed first.
 // first_chunk: index of the buffer's first 4 KiB chunk in the whole object (shards add up)
 void launch_hash64(hipStream_t stream, const uint8_t *p, uint64_t n, uint64_t first_chunk, unsigned long long *result);
+void launch_copy_out(hipStream_t stream, uint8_t *dst_pinned, const uint8_t *d_src, uint64_t n);
 
 }  // namespace nafgpu

@@ -3970,6 +3970,21 @@ __global__ __launch_bounds__(64) void k_xxh64_frames(const XxhSeg *__restrict__ 
 // ======================================================================================
 // checksum (hash64.h)
 // ======================================================================================
+// Bytes out of HBM into PINNED HOST memory, stored by the GPU itself over PCIe: 16-byte stores aligned in the destination, the
+// source read at whatever alignment that leaves it (load16u), odd edges byte-wise.  Why not hipMemcpyAsync: the runtime's copy
+// engines move 55 GB/s in one process and 29-35 in the next (which engine a process is dealt, it seems: the same binary, the same
+// box, tools/iter_regime_probe.py), this kernel 54 GB/s in every one (profiles/r04_iter_regime_probe.log).
+__global__ __launch_bounds__(256) void k_copy_out(uint8_t *dst, const uint8_t *__restrict__ src, uint64_t n) {
+    const uint64_t head = (16u - (reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u;
+    const uint64_t h = head < n ? head : n;
+    const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x, nthr = static_cast<uint64_t>(gridDim.x) * 256;
+    if (tid < h) dst[tid] = src[tid];
+    const uint64_t n16 = (n - h) / 16;
+    for (uint64_t i = tid; i < n16; i += nthr) *reinterpret_cast<uint4 *>(dst + h + 16 * i) = load16u(src + h + 16 * i);
+    const uint64_t done = h + 16 * n16;
+    if (tid < n - done) dst[done + tid] = src[done + tid];
+}
+
 __global__ __launch_bounds__(256) void k_hash64(const uint8_t *__restrict__ p, uint64_t n, uint64_t first_chunk,
                                                 unsigned long long *result) {
     // sum over the 8-byte words of hash_word(word, position): any split of the words over threads gives
@@ -4413,6 +4428,15 @@ void launch_xxh64_frames(hipStream_t stream, const XxhSeg *segs, uint32_t n_segs
     if (!n_segs) return;
     hipLaunchKernelGGL(k_xxh64_frames, dim3(n_segs), dim3(64), 0, stream, segs, blk_base, out, ascii ? 1u : 0u, t_char, carry_in,
                        carry_out, status);
+}
+
+// Device -> pinned host memory by a kernel (k_copy_out): see ArchiveJob::copy_to_pinned.
+void launch_copy_out(hipStream_t stream, uint8_t *dst_pinned, const uint8_t *d_src, uint64_t n) {
+    if (!n) return;
+    uint64_t blocks = (n / 16 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_copy_out, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, dst_pinned, d_src, n);
 }
 
 void launch_hash64(hipStream_t stream, const uint8_t *p, uint64_t n, uint64_t first_chunk, unsigned long long *result) {

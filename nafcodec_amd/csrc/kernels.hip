@@ -946,6 +946,9 @@ __global__ __launch_bounds__(64) void k_huf_decode(const uint8_t *__restrict__ s
             // sum -- a borrow still means "one word on" (the sum is <= 32).  Per look-up: a shift, an address, the table
             // read, the store and a quarter of an advance -- 6 vector instructions where a look-up with its own advance
             // takes 13, and the chain from one table read to the next is two instructions long instead of ten.
+            // (Round 4, measured and dropped: the peek kept ROTATED so that the index is one AND-OR on a size-aligned table base and
+            //  taking an entry one v_alignbit_b32 with the entry as shift operand -- two vector instructions per look-up instead of
+            //  three, 16 of the round's ~207 gone: 10.40 against 10.47 ms.  The chain of LDS round trips is what a lane runs at.)
             auto group4 = [&](auto dword) {
                 uint32_t p = __builtin_amdgcn_alignbit(L.hi, L.lo, L.s), tot = 0;
 #pragma unroll

@@ -252,7 +252,7 @@ def iterator_leg(path, device, batch=0):
     on the C-ABI, what a Rust / C++ shim does -- opens the archive at `path` and calls nafgpu_next until the end (`batch` > 0:
     nafgpu_next_batch, that many records a call); every record's sequence / quality comes to the host through the decoder's
     pinned window.  Seconds from open to the last record; `records_per_s_after_first` leaves out the first call (which decodes
-    every section on the GPU)."""
+    every section on the GPU -- of a section of 4 GiB or more its first 2 GiB tile, the later ones as the records reach them)."""
     import subprocess
     tool = os.path.join(ROOT, "nafcodec_amd", "iter_bench")
     if not os.path.exists(tool):
@@ -267,8 +267,9 @@ def iterator_leg(path, device, batch=0):
             "iterate_s": round(j["iterate_s"], 4), "records_per_s": round(j["records"] / it), "Gbases_per_s": round(j["bases"] / it / 1e9, 3),
             "records_per_s_after_first": round(j["records"] / rest), "calls": j["calls"], "batch": batch,
             "end_to_end_Gbases_s": round(j["bases"] / max(j["total_s"], 1e-9) / 1e9, 3),
-            "note": "first next() to last through %s (the first call decodes every section on the GPU); end_to_end from nafgpu_open_path: "
-                    "host walk + H2D + decode + every record's bytes D2H through the 64 MiB pinned window"
+            "note": "first next() to last through %s (the first call decodes every section on the GPU, a section of 4 GiB or more tile by "
+                    "2 GiB tile as the records reach them); end_to_end from nafgpu_open_path: host walk + H2D + decode + every record's bytes "
+                    "D2H through the 64 MiB pinned window"
                     % ("nafgpu_next_batch, %d records a call" % batch if batch else "nafgpu_next")}
 
 

@@ -90,7 +90,9 @@ typedef struct {
     int32_t tile_mib;            /* decode the sequence / quality sections in tiles of about this many MiB of output, so that
                                     neither the compressed bytes nor the scratch memory -- nor, for nafgpu_next, the output --
                                     are resident whole (the reference streams any size through 4 KiB buffers, mod.rs:223);
-                                    0 = only when the archive would not fit in the device's free memory */
+                                    0 = when the archive would not fit in the device's free memory, and -- for nafgpu_next /
+                                    nafgpu_next_batch only -- for a section of 4 GiB or more, which the iterator takes in 2 GiB
+                                    tiles (the next tile's compressed bytes travel while this one is read back) */
 } nafgpu_opts;
 
 /* DecoderBuilder::new() (mod.rs:67-76) */

@@ -7,7 +7,9 @@
 #include <algorithm>
 #include <cerrno>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -82,41 +84,72 @@ private:
     int n_ = 0;
 };
 
+// The bytes of one section the iterator hands out, on the host: a window of pinned memory that moves forward over the
+// section (the reference's BufReader over its zstd stream, mod.rs:223).  While the caller works through one window the next
+// one is already on its way into a second buffer (`ahead`): the link is then busy all the time, where waiting for each window
+// in turn cost 0.14 ms of launch and wake-up per window on top of its 1.3 ms.
 class HostWindow {
 public:
     ~HostWindow() {
+        settle();
         if (buf_) PinnedPool::get().give(buf_, cap_);
+        if (nbuf_) PinnedPool::get().give(nbuf_, ncap_);
     }
     void bind(ArchiveJob *job, int section, uint64_t mult, uint64_t total, uint64_t window) {
+        settle();
         job_ = job;
         section_ = section;
         mult_ = mult;
         total_ = total;
         window_ = window;
         lo_ = hi_ = 0;
+        base_ = buf_;
     }
     // bytes [start, start+len) are on the host already (a record in front of a tile that failed is still handed out)
     bool holds(uint64_t start, uint64_t len) const { return start >= lo_ && start + len <= hi_ && hi_ > lo_; }
     // pointer to bytes [start, start+len) on the host; nullptr on failure
     const uint8_t *get(uint64_t start, uint64_t len, Failure *f) {
         if (len == 0) return reinterpret_cast<const uint8_t *>("");
-        if (start >= lo_ && start + len <= hi_) return buf_ + (start - lo_);
+        if (start >= lo_ && start + len <= hi_) return base_ + (start - lo_);
+        if (ahead_n_) {
+            // the window in flight begins where this one ends: a record that straddles the two has its first bytes copied into
+            // the room in front of it
+            const uint64_t a_lo = ahead_lo_, a_n = ahead_n_;
+            *f = job_->copy_to_pinned_end();
+            ahead_n_ = 0;
+            if (!f->ok()) return nullptr;
+            if (start >= lo_ && start <= hi_ && hi_ == a_lo && hi_ - start <= kHead && start + len <= a_lo + a_n) {
+                const uint64_t keep = hi_ - start;
+                uint8_t *nb = nbuf_ + kHead - keep;
+                if (keep) std::memcpy(nb, base_ + (start - lo_), keep);
+                std::swap(buf_, nbuf_);
+                std::swap(cap_, ncap_);
+                base_ = nb;
+                lo_ = start;
+                hi_ = a_lo + a_n;
+                send_ahead();
+                return base_;
+            }
+        }
         const uint64_t want = std::max(len, std::min(window_, total_ - start));
         const uint64_t keep = (start >= lo_ && start < hi_) ? hi_ - start : 0;   // already on the host (a record straddling the old window)
-        if (want > cap_) {
-            uint64_t cap = want;
-            void *p = PinnedPool::get().take(want, &cap);
-            if (!p && hipHostMalloc(&p, want) != hipSuccess) {
+        // (a section of several windows: room for the head of a straddling record in front, see above)
+        const uint64_t room = total_ > window_ ? std::max(want, window_ + kHead) : want;
+        if (room > cap_) {
+            uint64_t cap = room;
+            void *p = PinnedPool::get().take(room, &cap);
+            if (!p && hipHostMalloc(&p, room) != hipSuccess) {
                 *f = Failure::make(NAFGPU_E_DEVICE, "cannot allocate the pinned read-back window");
                 return nullptr;
             }
-            if (keep) std::memcpy(p, buf_ + (start - lo_), keep);
+            if (keep) std::memcpy(p, base_ + (start - lo_), keep);
             if (buf_) PinnedPool::get().give(buf_, cap_);
             buf_ = static_cast<uint8_t *>(p);
             cap_ = cap;
         } else if (keep) {
-            std::memmove(buf_, buf_ + (start - lo_), keep);
+            std::memmove(buf_, base_ + (start - lo_), keep);
         }
+        base_ = buf_;
         const SectionJob &sj = job_->job(section_);
         uint64_t pos = start + keep;                       // next byte to fetch
         const uint64_t end = start + want;
@@ -159,14 +192,49 @@ public:
             *f = Failure::io(NAFGPU_IO_UNEXPECTED_EOF, "section ends before the record does");
             return nullptr;
         }
-        return buf_;
+        send_ahead();
+        return base_;
+    }
+
+    // waits for the window in flight, if any (before the buffers, the job or the device bytes it reads go away)
+    void settle() {
+        if (ahead_n_ && job_) (void)job_->copy_to_pinned_end();
+        ahead_n_ = 0;
     }
 
 private:
+    static constexpr uint64_t kHead = uint64_t(8) << 20;   // room in front of a window in flight (records that straddle by more wait for their window)
+    // the window after this one, as far as it lies in the bytes held in HBM right now (a tile's end is crossed by get())
+    void send_ahead() {
+        if (hi_ >= total_ || hook_env("NAFGPU_NO_AHEAD")) return;      // (the hook: A/B runs, tools/iter_ahead_probe.py)
+        const SectionJob &sj = job_->job(section_);
+        uint64_t held0 = 0, held1 = total_;
+        const uint8_t *d_held = sj.out();
+        if (sj.tiled_output()) {
+            held0 = sj.tile_pos0() * mult_;
+            held1 = (sj.tile_pos0() + sj.tile_len()) * mult_;
+            d_held = sj.tile_data();
+        }
+        if (hi_ < held0 || hi_ >= held1) return;
+        const uint64_t n = std::min(window_, held1 - hi_);
+        if (n < std::min<uint64_t>(uint64_t(1) << 20, window_)) return;   // (the last bytes of a tile: the plain way)
+        if (kHead + n > ncap_) {
+            uint64_t cap = kHead + window_;
+            void *p = PinnedPool::get().take(cap, &cap);
+            if (!p && hipHostMalloc(&p, kHead + window_) != hipSuccess) return;
+            if (nbuf_) PinnedPool::get().give(nbuf_, ncap_);
+            nbuf_ = static_cast<uint8_t *>(p);
+            ncap_ = cap;
+        }
+        if (!job_->copy_to_pinned_begin(nbuf_ + kHead, d_held + (hi_ - held0), n)) return;
+        ahead_lo_ = hi_;
+        ahead_n_ = n;
+    }
     ArchiveJob *job_ = nullptr;
     int section_ = 0;
-    uint64_t mult_ = 1, total_ = 0, window_ = 0, lo_ = 0, hi_ = 0, cap_ = 0;
-    uint8_t *buf_ = nullptr;
+    uint64_t mult_ = 1, total_ = 0, window_ = 0, lo_ = 0, hi_ = 0, cap_ = 0, ncap_ = 0;
+    uint64_t ahead_lo_ = 0, ahead_n_ = 0;                  // bytes [ahead_lo_, + ahead_n_) of the section are on their way to nbuf_ + kHead
+    uint8_t *buf_ = nullptr, *nbuf_ = nullptr, *base_ = nullptr;   // base_: where byte lo_ is (inside buf_)
 };
 
 }  // namespace
@@ -181,10 +249,11 @@ struct nafgpu_decoder {
     size_t map_len = 0;
     const uint8_t *bytes = nullptr;
     size_t n_bytes = 0;
+    ArchiveJob job;
     ~nafgpu_decoder() {
+        job.drain();                     // (a tile's source bytes may still be travelling out of the mapping)
         if (map) (void)munmap(map, map_len);
     }
-    ArchiveJob job;
     bool device_ready = false, decoded = false;
     uint64_t tile_blocks = 0;            // > 0: the sequence / quality sections are decoded in tiles of this many zstd blocks
     bool tiled_output = false;           // ... and their output is held a tile at a time (record iterator)
@@ -205,14 +274,30 @@ struct nafgpu_decoder {
 
 namespace {
 
+constexpr uint64_t kIterTileFrom = uint64_t(4) << 30;    // the iterator holds a section's output a tile at a time from this size on ...
+constexpr uint64_t kIterTileBytes = uint64_t(2) << 30;   // ... in tiles of this many decoded bytes
+constexpr size_t kWalkBesideInit = size_t(64) << 20;     // archives from this size on are walked beside the start of the HIP runtime
+
 Failure ensure_uploaded(nafgpu_decoder *d, bool for_iterator);
 Failure after_decode(nafgpu_decoder *d);
 
 // Decoded output of this many bytes per tile (0: no tiling): nafgpu_opts.tile_mib (tests: NAFGPU_TILE_KIB), or -- when the
 // selected sections would not fit beside each other in the device's free memory -- a sixteenth of that memory.
-uint64_t tile_blocks_for(const nafgpu_decoder *d) {
+uint64_t tile_blocks_for(const nafgpu_decoder *d, bool for_iterator) {
     uint64_t tile_bytes = static_cast<uint64_t>(d->opts.tile_mib > 0 ? d->opts.tile_mib : 0) << 20;
     if (const char *e = hook_env("NAFGPU_TILE_KIB")) tile_bytes = std::strtoull(e, nullptr, 10) << 10;   // tests: tiles far below a MiB
+    if (!tile_bytes && for_iterator) {
+        // The record iterator reads every decoded byte back over the link, 20 ms a GiB, the decode of that GiB taking a third of a
+        // millisecond: a large section goes tile by tile -- the first records leave after one tile's upload and decode instead of
+        // the whole archive's, the compressed bytes of the next tile travel while this one is read back (engine.cpp:
+        // start_source_upload), and the device holds one tile of output, not tens of gigabytes (whose address ranges and chunks
+        // took 0.01 s in one process and 0.8 s in the next).  (NAFGPU_ITER_TILE_MIB: experiments; 0 = whole output)
+        uint64_t big = 0, tile = kIterTileBytes, from = kIterTileFrom;
+        for (int s : {kSequence, kQuality})
+            if (d->use[s]) big = std::max<uint64_t>(big, d->sec[s].original_size);
+        if (const char *e = hook_env("NAFGPU_ITER_TILE_MIB")) from = tile = std::strtoull(e, nullptr, 10) << 20;
+        if (tile && big >= from) tile_bytes = tile;
+    }
     if (!tile_bytes) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
@@ -232,12 +317,20 @@ uint64_t tile_blocks_for(const nafgpu_decoder *d) {
 Failure ensure_decoded(nafgpu_decoder *d, bool for_iterator) {
     if (!d->fatal.ok()) return d->fatal;
     if (d->decoded) return Failure();
+    d->seq_win.settle();                                   // (a window on its way reads what is about to be decoded again)
+    d->qual_win.settle();
+    const bool trace = hook_env("NAFGPU_DEBUG_TIMES") != nullptr;   // (experiments: what the first call is made of)
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     Failure f = ensure_uploaded(d, for_iterator);
     if (!f.ok()) return f;
+    const double t1 = now();
     f = d->job.decode();
     if (!f.ok()) return d->fatal = f;
+    const double t2 = now();
     f = after_decode(d);
     if (!f.ok()) return f;
+    if (trace) std::fprintf(stderr, "[nafgpu] first decode: init + walk + upload %.1f ms, decode %.1f, tables back %.1f\n", t1 - t0, t2 - t1, now() - t2);
     d->decoded = true;
     return Failure();
 }
@@ -247,17 +340,29 @@ Failure ensure_uploaded(nafgpu_decoder *d, bool for_iterator) {
     const uint64_t tile_blocks = d->device_ready ? d->tile_blocks : 0;
     if (d->device_ready && tile_blocks && d->tiled_output != for_iterator) d->device_ready = false;   // the other way of holding the output: prepare again
     if (!d->device_ready) {
-        Failure f = d->job.init(d->opts.device);
-        if (!f.ok()) return d->fatal = f;
-        ArchiveOptions ao;
+        d->seq_win.settle();
+        d->qual_win.settle();
         const bool want[kNumSections] = {d->opts.id != 0, d->opts.comment != 0, true, d->opts.mask != 0,
                                          d->opts.sequence != 0, d->opts.quality != 0};
+        Failure f;
+#ifndef NAFGPU_EMU
+        if (d->n_bytes >= kWalkBesideInit) {
+            // a process's first HIP call takes 0.15-0.2 s, the walk of a 10 GB archive out of a fresh file mapping as long (a page
+            // fault per block): side by side
+            std::future<Failure> started = std::async(std::launch::async, [d] { return d->job.init(d->opts.device); });
+            d->job.prewalk(d->bytes, d->n_bytes, d->sec, want);
+            f = started.get();
+        } else
+#endif
+            f = d->job.init(d->opts.device);
+        if (!f.ok()) return d->fatal = f;
+        ArchiveOptions ao;
         for (int s = 0; s < kNumSections; s++) ao.want[s] = want[s];
         ao.spec_mask = d->opts.spec_mask != 0;
         ao.shard_count = d->opts.shard_count > 1 ? static_cast<uint32_t>(d->opts.shard_count) : 1u;
         ao.shard_rank = d->opts.shard_rank > 0 ? static_cast<uint32_t>(d->opts.shard_rank) : 0u;
         ao.shard_protocol = d->opts.shard_protocol != 0 && ao.shard_count > 1;
-        d->tile_blocks = tile_blocks_for(d);
+        d->tile_blocks = tile_blocks_for(d, for_iterator);
         d->tiled_output = d->tile_blocks != 0 && for_iterator;
         ao.tile_blocks = d->tile_blocks;
         ao.tiled_output = d->tiled_output;
@@ -344,7 +449,8 @@ Failure after_decode(nafgpu_decoder *d) {
         f = d->job.copy_to_host(d->rec_ends.data(), d->job.d_rec_ends(), d->rec_ends.size() * sizeof(uint64_t));
         if (!f.ok()) return d->fatal = f;
     }
-    const uint64_t window = std::max<uint64_t>(d->opts.buffer_size, uint64_t(64) << 20);
+    uint64_t window = std::max<uint64_t>(d->opts.buffer_size, uint64_t(64) << 20);
+    if (const char *e = hook_env("NAFGPU_WINDOW_KIB")) window = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10)) << 10;   // (tests: many windows over a small section)
     d->seq_win.bind(&d->job, kSequence, d->header.sequence_type <= 1 ? 2 : 1, d->job.n_sequence_bytes(), window);
     d->qual_win.bind(&d->job, kQuality, 1, d->job.section_size(kQuality), window);
     // MaskReader yields units until their sum reaches the nucleotide count (reader.rs:200-202);

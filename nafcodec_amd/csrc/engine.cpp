@@ -273,15 +273,16 @@ bool stage_init() {
 }  // namespace
 #endif
 
-bool upload_staged(uint8_t *d_dst, const uint8_t *src, size_t n, hipStream_t stream) {
+bool upload_staged(uint8_t *d_dst, const uint8_t *src, size_t n, hipStream_t stream, size_t stage_min) {
 #ifndef NAFGPU_EMU
-    if (n >= kStageMin && !hook_env("NAFGPU_NO_STAGING")) {
+    if (n >= (stage_min ? stage_min : kStageMin) && !hook_env("NAFGPU_NO_STAGING")) {
         std::lock_guard<std::mutex> guard(g_stage_mu);
         if (stage_init() && hipStreamSynchronize(stream) == hipSuccess) {   // (what was enqueued in front -- the pad memsets -- is done)
             int dev = 0;
             (void)hipGetDevice(&dev);
             const size_t n_chunks = (n + kStageChunk - 1) / kStageChunk;
             std::atomic<bool> failed{false};
+            const bool sdma = hook_env("NAFGPU_STAGE_SDMA") != nullptr;   // (experiment: the copy engines fetch the chunks, not a kernel)
             auto worker = [&](unsigned t) {
                 (void)hipSetDevice(dev);
                 StageSlot &sl = g_stage[t];
@@ -290,7 +291,11 @@ bool upload_staged(uint8_t *d_dst, const uint8_t *src, size_t n, hipStream_t str
                     const size_t off = c * kStageChunk, len = std::min(kStageChunk, n - off);
                     if (hipEventSynchronize(sl.done[k]) != hipSuccess) failed = true;   // (the kernel that last read this buffer)
                     std::memcpy(sl.buf[k], src + off, len);
-                    launch_copy_out(sl.stream, d_dst + off, sl.buf[k], len);
+                    if (sdma) {
+                        if (hipMemcpyAsync(d_dst + off, sl.buf[k], len, hipMemcpyHostToDevice, sl.stream) != hipSuccess) failed = true;
+                    } else {
+                        launch_copy_out(sl.stream, d_dst + off, sl.buf[k], len);
+                    }
                     if (hipGetLastError() != hipSuccess || hipEventRecord(sl.done[k], sl.stream) != hipSuccess) failed = true;
                 }
                 if (hipStreamSynchronize(sl.stream) != hipSuccess) failed = true;
@@ -306,13 +311,70 @@ bool upload_staged(uint8_t *d_dst, const uint8_t *src, size_t n, hipStream_t str
     return hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, stream) == hipSuccess;
 }
 
+// tiles whose compressed bytes are fewer travel with load_tile itself (NAFGPU_SRC_PREFETCH_MIN: tests lower it)
+static size_t src_prefetch_min() {
+    if (const char *e = hook_env("NAFGPU_SRC_PREFETCH_MIN")) return static_cast<size_t>(std::strtoull(e, nullptr, 10));
+    return size_t(1) << 20;
+}
+
+void SectionJob::walk(const uint8_t *host_payload, size_t n) {
+    drain();
+    const double t0 = now_ms();
+    master_ = ZPlan();
+    walk_truncated_ = false;
+    walk_err_ = walk_zstd(host_payload, n, &master_, &walk_truncated_);
+    plan_ms_ = static_cast<float>(now_ms() - t0);
+    walked_payload_ = host_payload;
+    walked_n_ = n;
+}
+
+void SectionJob::drain() {
+    for (SrcSlot &sl : src_slot_) {
+        if (sl.pending.valid()) sl.pending.wait();
+        sl.pending = std::future<bool>();
+        sl.tile = 0xFFFFFFFFu;
+    }
+}
+
+// The compressed bytes of tile t on their way into slot t & 1, on a thread of their own (the staged upload keeps its caller
+// until the last byte is across).  Tile t - 2's bytes were there: its kernels are long done (decode_tile synchronises).
+bool SectionJob::start_source_upload(uint32_t t) {
+    SrcSlot &sl = src_slot_[t & 1];
+    if (sl.pending.valid()) sl.pending.wait();             // (an upload nobody came for)
+    sl.pending = std::future<bool>();
+    sl.tile = 0xFFFFFFFFu;
+    const Tile tile = tiles_[t];
+    const uint64_t lo = master_.blk_off[tile.b0], n = master_.blk_off[tile.b1] - lo;
+    if (!sl.buf.alloc(kSrcFrontPad + static_cast<size_t>(std::max(src_cap_, n)) + kSrcBackPad)) return false;
+    if (!prefetch_stream_ && !hip_ok(hipStreamCreateWithFlags(&prefetch_stream_, hipStreamNonBlocking))) return false;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    uint8_t *dst = sl.buf.bytes();
+    const uint8_t *src = host_payload_ + lo;
+    hipStream_t st = prefetch_stream_;
+#ifdef NAFGPU_EMU
+    const std::launch how = std::launch::deferred;         // (the CPU harness is one thread: the copy runs when it is asked for)
+#else
+    const std::launch how = std::launch::async;
+#endif
+    sl.tile = t;
+    if (hook_env("NAFGPU_DEBUG_TIMES")) std::fprintf(stderr, "[nafgpu] tile %u: %llu source bytes on their way\n", t, static_cast<unsigned long long>(n));
+    sl.pending = std::async(how, [dst, src, n, dev, st] {
+        (void)hipSetDevice(dev);
+        bool ok = hip_ok(hipMemsetAsync(dst, 0, kSrcFrontPad, st)) && hip_ok(hipMemsetAsync(dst + kSrcFrontPad + n, 0, kSrcBackPad, st));
+        ok = ok && (n == 0 || upload_staged(dst + kSrcFrontPad, src, static_cast<size_t>(n), st, size_t(32) << 20));
+        return ok && hip_ok(hipStreamSynchronize(st));
+    });
+    return true;
+}
+
 Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expect_size, hipStream_t stream,
                             const SectionOptions &opt) {
     ready_ = false;
+    drain();
     opt_ = opt;
     t_char_ = opt.t_char;
     host_payload_ = host_payload;
-    master_ = ZPlan();
     plan_ = ZPlan();
     tiles_.clear();
     loaded_tile_ = 0xFFFFFFFFu;
@@ -331,9 +393,13 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
         set_huf_split(fs && force == 0 ? 0u : lanes, force);
     }
     const double t0 = now_ms();
-    bool truncated = false;
-    std::string err = walk_zstd(host_payload, n, &master_, &truncated);
-    plan_ms_ = static_cast<float>(now_ms() - t0);
+    if (walked_payload_ != host_payload || walked_n_ != n) walk(host_payload, n);
+    walked_payload_ = nullptr;                             // (the result is used up: load_tile may move master_ away)
+    const bool truncated = walk_truncated_;
+    const std::string err = std::move(walk_err_);
+    walk_err_.clear();
+    const bool trace = hook_env("NAFGPU_DEBUG_TIMES") != nullptr;
+    if (trace) std::fprintf(stderr, "[nafgpu] prepare: walk of %zu bytes %.1f ms\n", n, plan_ms_);
     if (!err.empty())
         return Failure::io(truncated ? NAFGPU_IO_UNEXPECTED_EOF : NAFGPU_IO_INVALID_DATA, "zstd: " + err);
     expect_ = expect_size;
@@ -408,6 +474,8 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
         for (const Tile &t : tiles_) most = std::max<uint64_t>(most, t.b1 - t.b0);
         tile_cap_ = most * kBlockMax;
         ok = ok && d_out_.alloc_items(halo_cap_ + tile_cap_, mult, 64);
+        src_cap_ = 0;
+        for (const Tile &t : tiles_) src_cap_ = std::max<uint64_t>(src_cap_, master_.blk_off[t.b1] - master_.blk_off[t.b0]);
     } else {
         ok = ok && d_out_.alloc_items(out1_ - out0_, mult, 64);
     }
@@ -420,8 +488,10 @@ Failure SectionJob::prepare(const uint8_t *host_payload, size_t n, uint64_t expe
     carry_frame_ = 0xFFFFFFFFu;
     carry_same_frame_ = false;
     ready_ = true;
+    if (trace) std::fprintf(stderr, "[nafgpu] prepare: output buffer at %.1f ms\n", now_ms() - t0);
     if (tiles_.size() == 1) {
         Failure f = load_tile(0, stream);
+        if (trace) std::fprintf(stderr, "[nafgpu] prepare: tile loaded at %.1f ms\n", now_ms() - t0);
         if (!f.ok()) {
             ready_ = false;
             return f;
@@ -540,8 +610,17 @@ Failure SectionJob::load_tile(uint32_t t, hipStream_t stream) {
         d_src_ = d_src_buf_.bytes() + kSrcFrontPad - plan_.src_lo;         // kernels address the payload by its offsets
         ok = ok && d_blk_base_.alloc((n_blocks_ + 1) * sizeof(uint64_t)) && d_scan_tmp_.alloc(scan_tmp_bytes(n_blocks_));
     } else {
-        ok = d_src_buf_.alloc(kSrcFrontPad + static_cast<size_t>(src_n) + kSrcBackPad);
-        if (ok) {
+        if (tiled_output() && src_n >= src_prefetch_min()) {      // (start_source_upload: it may have travelled ahead)
+            SrcSlot &sl = src_slot_[t & 1];
+            ok = sl.tile == t || start_source_upload(t);
+            if (ok && sl.pending.valid()) ok = sl.pending.get();
+            if (ok) {
+                d_src_buf_.view(sl.buf.bytes(), sl.buf.size());
+                d_src_ = d_src_buf_.bytes() + kSrcFrontPad - plan_.src_lo;
+            } else {
+                sl.tile = 0xFFFFFFFFu;
+            }
+        } else if ((ok = d_src_buf_.alloc(kSrcFrontPad + static_cast<size_t>(src_n) + kSrcBackPad))) {
             (void)hipMemsetAsync(d_src_buf_.bytes(), 0, kSrcFrontPad, stream);
             (void)hipMemsetAsync(d_src_buf_.bytes() + kSrcFrontPad + src_n, 0, kSrcBackPad, stream);
             if (src_n) ok = upload_staged(d_src_buf_.bytes() + kSrcFrontPad, host_payload_ + plan_.src_lo, static_cast<size_t>(src_n), stream);
@@ -642,6 +721,9 @@ Failure SectionJob::decode_tile(uint32_t t, hipStream_t stream, StageTimer *time
     }
     tiles_done_ = t + 1;
     if (tile_pos0_ + tile_len_ > out1_) return Failure::io(NAFGPU_IO_INVALID_DATA, status_text(kStSizeMismatch));
+    if (tiled_output() && t + 1 < tiles_.size() &&
+        master_.blk_off[tiles_[t + 1].b1] - master_.blk_off[tiles_[t + 1].b0] >= src_prefetch_min())
+        (void)start_source_upload(t + 1);                                   // (a failure shows when the tile is loaded)
     if (tiles_done_ == tiles_.size()) out1_ = tile_pos0_ + tile_len_;                  // (less than announced: see prepare)
     return Failure();
 }
@@ -660,6 +742,8 @@ const uint8_t *SectionJob::tile_data() const {
 }
 
 SectionJob::~SectionJob() {
+    drain();
+    if (prefetch_stream_) (void)hipStreamDestroy(prefetch_stream_);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
     if (ev_early_fork_) (void)hipEventDestroy(ev_early_fork_);
@@ -1185,6 +1269,26 @@ Failure ArchiveJob::init(int device) {
     return Failure();
 }
 
+void ArchiveJob::prewalk(const uint8_t *bytes, size_t n, const SectionInfo sec[kNumSections], const bool want[kNumSections]) {
+    // (a section's walk is one thread following its block headers: the large sections side by side)
+    std::vector<std::thread> side;
+    for (int s = 0; s < kNumSections; s++) {
+        if (!(sec[s].present && want[s] && sec[s].offset <= n && sec[s].compressed_size <= n - sec[s].offset)) continue;
+        const uint8_t *payload = bytes + sec[s].offset;
+        const size_t len = static_cast<size_t>(sec[s].compressed_size);
+        SectionJob *j = &job_[s];
+        if (len >= (size_t(16) << 20) && s != kQuality)
+            side.emplace_back([j, payload, len] { j->walk(payload, len); });
+        else
+            j->walk(payload, len);
+    }
+    for (std::thread &t : side) t.join();
+}
+
+void ArchiveJob::drain() {
+    for (SectionJob &j : job_) j.drain();
+}
+
 Failure ArchiveJob::upload(const uint8_t *bytes, size_t n, const nafgpu_header &h, const SectionInfo sec[kNumSections],
                            const ArchiveOptions &opt) {
     (void)hipSetDevice(device_);
@@ -1223,6 +1327,7 @@ Failure ArchiveJob::upload(const uint8_t *bytes, size_t n, const nafgpu_header &
         if (fail_[s].ok()) compressed_ += job_[s].n_tiles() == 1 ? job_[s].source_bytes() : sec[s].compressed_size;
     }
     h2d_ms_ = std::max(0.0f, static_cast<float>(now_ms() - t0) - plan_ms_);
+    if (hook_env("NAFGPU_DEBUG_TIMES")) std::fprintf(stderr, "[nafgpu] upload: sections %.1f ms of which host walk %.1f\n", now_ms() - t0, plan_ms_);
     // ---- derived tables
     bool ok = d_totals_.alloc(8 * sizeof(ScanTotals)) && d_status_.alloc(64) && d_hash_.alloc(16);
     // The iterator never hands out more strings than records, and a section holds no more NULs than bytes:
@@ -1458,7 +1563,9 @@ Failure ArchiveJob::advance_tile(int s) {
     (void)hipSetDevice(device_);
     SectionJob &j = job_[s];
     if (!j.ready() || !j.tiled_output() || j.tiles_done() >= j.n_tiles()) return Failure::make(NAFGPU_E_INVALID_ARG, "no tile left");
+    const double t0 = now_ms();
     Failure f = j.decode_tile(j.tiles_done(), stream_, nullptr, aux_stream_);
+    if (hook_env("NAFGPU_DEBUG_TIMES")) std::fprintf(stderr, "[nafgpu] tile %u of section %d: %.1f ms\n", j.tiles_done(), s, now_ms() - t0);
     if (!f.ok()) {
         if (f.status != NAFGPU_E_DEVICE) fail_[s] = f;
         return f;
@@ -1567,6 +1674,19 @@ Failure ArchiveJob::copy_to_pinned(void *dst_pinned, const void *d_src, size_t n
     launch_copy_out(stream_, static_cast<uint8_t *>(dst_pinned), static_cast<const uint8_t *>(d_src), n);
     if (!hip_ok(hipGetLastError()) || !hip_ok(hipStreamSynchronize(stream_)))
         return Failure::make(NAFGPU_E_DEVICE, "device-to-host copy failed");
+    return Failure();
+}
+
+bool ArchiveJob::copy_to_pinned_begin(void *dst_pinned, const void *d_src, size_t n) {
+    if (!aux_stream_ || !n || hook_env("NAFGPU_D2H_MEMCPY")) return false;
+    (void)hipSetDevice(device_);
+    launch_copy_out(aux_stream_, static_cast<uint8_t *>(dst_pinned), static_cast<const uint8_t *>(d_src), n);
+    return hip_ok(hipGetLastError());
+}
+
+Failure ArchiveJob::copy_to_pinned_end() {
+    (void)hipSetDevice(device_);
+    if (aux_stream_ && !hip_ok(hipStreamSynchronize(aux_stream_))) return Failure::make(NAFGPU_E_DEVICE, "device-to-host copy failed");
     return Failure();
 }
 

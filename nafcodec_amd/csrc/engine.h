@@ -17,6 +17,7 @@
 
 #include <cstdint>
 #include <string>
+#include <future>
 #include <vector>
 
 #include "container.h"
@@ -114,6 +115,10 @@ public:
     // One tile (the usual case): its compressed bytes and task lists are uploaded here and stay resident --
     // run() then only enqueues kernels.  Several tiles: each is uploaded when it is decoded (decode_tile).
     Failure prepare(const uint8_t *host_payload, size_t n, uint64_t expect_size, hipStream_t stream, const SectionOptions &opt);
+    // The host walk alone, ahead of prepare() (which then finds it done): no HIP call, so it can run beside the start of the runtime.
+    void walk(const uint8_t *host_payload, size_t n);
+    // Waits for what a background thread may still be reading or writing (the source bytes of the next tile).
+    void drain();
     // Enqueues the decode kernels of the resident tile.  Results: out() holds size() bytes once the stream is done.
     // aux: a second stream (or null) on which the literal-buffer Huffman tasks run beside the direct ones
     void run(hipStream_t stream, StageTimer *timer, hipStream_t aux = nullptr);
@@ -168,6 +173,21 @@ private:
         uint32_t b0, b1;
     };
     Failure load_tile(uint32_t t, hipStream_t stream);
+    // Output held a tile at a time: the compressed bytes of tile t travel on a background thread into one of two buffers while
+    // the tile in front is being read back (the two directions of the link are independent).
+    struct SrcSlot {
+        DevBuf buf;
+        uint32_t tile = 0xFFFFFFFFu;     // whose bytes it holds (or will, once `pending` is done)
+        std::future<bool> pending;
+    };
+    bool start_source_upload(uint32_t t);
+    SrcSlot src_slot_[2];
+    uint64_t src_cap_ = 0;               // the most compressed bytes any tile reads
+    hipStream_t prefetch_stream_ = nullptr;
+    const uint8_t *walked_payload_ = nullptr;   // walk() ran for this payload: master_, walk_err_, walk_truncated_ are its result
+    size_t walked_n_ = 0;
+    std::string walk_err_;
+    bool walk_truncated_ = false;
     uint8_t *tile_out_base() const;                               // address of the loaded selection's local position 0
     void run_front(hipStream_t stream, StageTimer *timer, hipStream_t aux, bool *early);   // status reset, K1's literal-buffer classes beside K2
     void run_back(hipStream_t stream, StageTimer *timer, hipStream_t aux, bool early, uint32_t phase);   // scan, copies, K1, K4, checksums
@@ -236,14 +256,18 @@ struct ArchiveOptions {
     bool tiled_output = false;                  // ... whose output is held one tile at a time (iterator path; not for decode_all_device)
 };
 
-bool upload_staged(uint8_t *d_dst, const uint8_t *src, size_t n, hipStream_t stream);   // engine.cpp: large host -> device copies
+bool upload_staged(uint8_t *d_dst, const uint8_t *src, size_t n, hipStream_t stream, size_t stage_min = 0);   // engine.cpp: large host -> device copies
 
 // A whole archive on one GPU: sections -> record table -> ASCII bases.
 class ArchiveJob {
 public:
     ~ArchiveJob();
     Failure init(int device);
-    // bytes must stay valid until upload() returns
+    // the host walks of the wanted sections, ahead of upload() and without a HIP call (beside init() on another thread)
+    void prewalk(const uint8_t *bytes, size_t n, const SectionInfo sec[kNumSections], const bool want[kNumSections]);
+    // waits for background uploads (a tile's source bytes travelling ahead): before `bytes` goes away
+    void drain();
+    // bytes must stay valid until upload() returns -- with tiles (ArchiveOptions.tile_blocks) until the last tile is decoded
     Failure upload(const uint8_t *bytes, size_t n, const nafgpu_header &h, const SectionInfo sec[kNumSections],
                    const ArchiveOptions &opt);
     // (re)runs every kernel; synchronises; fills times
@@ -293,6 +317,9 @@ public:
                         float *ms);
     Failure copy_to_host(void *dst, const void *d_src, size_t n);
     Failure copy_to_pinned(void *dst_pinned, const void *d_src, size_t n);   // dst from hipHostMalloc: the GPU writes it (k_copy_out)
+    // the same copy enqueued on the second stream, not waited for (false: there is no such stream); ..._end() waits for all of them
+    bool copy_to_pinned_begin(void *dst_pinned, const void *d_src, size_t n);
+    Failure copy_to_pinned_end();
     Failure hash_device(const void *d_ptr, uint64_t n, uint64_t first_chunk, uint64_t *out);
 
 private:

@@ -162,6 +162,8 @@ hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st);
 hipError_t hipMemset(void *d, int v, size_t n);
 hipError_t hipMemGetInfo(size_t *free_bytes, size_t *total_bytes);
 hipError_t hipStreamCreate(hipStream_t *s);
+enum { hipStreamNonBlocking = 1 };
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return hipStreamCreate(s); }
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipDeviceSynchronize();

@@ -27,6 +27,8 @@ def check(lib, scale, tile_kib, monkeypatch, names=NAMES, fixtures=("NZ_AAEN0100
     want = {name: cases.run_oracle(blob, opts) for name, blob, opts in todo}
     enable_hooks(lib)
     monkeypatch.setenv("NAFGPU_TILE_KIB", str(tile_kib))
+    monkeypatch.setenv("NAFGPU_WINDOW_KIB", "64")         # several read-back windows per tile, each sent ahead of the one being handed out (api.cpp: HostWindow)
+    monkeypatch.setenv("NAFGPU_SRC_PREFETCH_MIN", "1024")  # tiles this small send their compressed bytes ahead too (engine.cpp: start_source_upload)
     for name, blob, opts in todo:
         # the record iterator: output held a tile at a time
         assert cases.run_product(blob, opts, lib) == want[name], (name, "iterator")
@@ -92,3 +94,39 @@ def test_tiled_synthetic_archive_checksums(monkeypatch):
         assert pos == arc.n_bases
     finally:
         lib.c.nafgpu_synth_free(ctypes.byref(arc))
+
+
+@pytest.mark.gpu
+def test_the_iterator_takes_a_large_section_tile_by_tile():
+    """No option and no hook: from 4 GiB of decoded sequence on, the record iterator holds the output a tile at a time and sends
+    the compressed bytes of the next tile ahead (api.cpp: tile_blocks_for, engine.cpp: start_source_upload).  The records of a
+    4.4-Gbase archive, laid end to end, must hash to what the writer says."""
+    import ctypes
+    import numpy as np
+    from nafcodec_amd import _ffi
+    from nafcodec_amd.decoder import Decoder
+    lib = _ffi.default()
+    n = 4_400_000_123
+    arc = lib.synth(n, seed=11)
+    path = "/dev/shm/nafgpu_iter_tiles_%d.naf" % os.getpid()
+    try:
+        with open(path, "wb") as f:
+            f.write((ctypes.c_char * arc.n).from_address(arc.bytes))
+        whole = np.empty(n, dtype=np.uint8)
+        pos = n_rec = 0
+        with Decoder(path) as d:
+            while True:
+                batch = d.read_batch(256)
+                if not batch:
+                    break
+                for r in batch:
+                    s = r.sequence.encode()
+                    whole[pos:pos + len(s)] = np.frombuffer(s, dtype=np.uint8)
+                    pos += len(s)
+                n_rec += len(batch)
+        assert (pos, n_rec) == (arc.n_bases, arc.n_records)
+        assert lib.c.nafgpu_hash64_host(whole.ctypes.data_as(ctypes.c_char_p), n) == arc.seq_hash
+    finally:
+        lib.c.nafgpu_synth_free(ctypes.byref(arc))
+        if os.path.exists(path):
+            os.unlink(path)

@@ -83,7 +83,10 @@ __device__ inline void flag_error(uint32_t *status, uint32_t code, uint32_t deta
 constexpr uint32_t kRingWords = 16;
 template <int TBL>
 struct HufGeom {
-    static constexpr bool kBig = TBL == kTblBaked;       // (128-byte units for the other formats: measured, no faster; 4 KB more LDS per wave)
+#ifndef NAFGPU_K1_UNIT64
+#define NAFGPU_K1_UNIT64 0
+#endif
+    static constexpr bool kBig = TBL == kTblBaked && !NAFGPU_K1_UNIT64;       // (128-byte units for the other formats: measured, no faster; 4 KB more LDS per wave)
     static constexpr uint32_t kUnit = kBig ? 128u : 64u;               // output bytes flushed per row at a time
     static constexpr uint32_t kUnitShift = kBig ? 7u : 6u;
     static constexpr uint32_t kPitch = kUnit + 64u + 8u;               // row pitch: unit + one round's worth + slack, 8-byte aligned, 2 (mod 32)-dword stride

@@ -13,9 +13,11 @@ with open(path, "wb") as f:
 lib.c.nafgpu_synth_free(ctypes.byref(arc))
 tool = os.path.join(R, "nafcodec_amd", "iter_bench")
 try:
-    for tile, win in (("2048", "64"), ("2048", "64"), ("2048", "32"), ("2048", "128"), ("0", "64"), ("0", "64"), ("2048", "64")):
-        env = dict(os.environ, NAFGPU_ITER_TILE_MIB=tile, NAFGPU_WINDOW_KIB=str(int(win) << 10))
+    for k in range(8):
+        env = dict(os.environ)
+        if k & 1:
+            env["NAFGPU_STAGE_SDMA"] = "1"
         p = subprocess.run([tool, path, "0", "1", "0", "1"], capture_output=True, text=True, env=env)
-        print("iterator tiles of", tile, "MiB, window", win, p.stdout.strip()[-330:], flush=True)
+        print("staged chunks fetched by", "the copy engines" if k & 1 else "a kernel        ", p.stdout.strip()[-330:], flush=True)
 finally:
     os.unlink(path)

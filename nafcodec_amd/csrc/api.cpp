@@ -349,9 +349,13 @@ Failure ensure_uploaded(nafgpu_decoder *d, bool for_iterator) {
         if (d->n_bytes >= kWalkBesideInit) {
             // a process's first HIP call takes 0.15-0.2 s, the walk of a 10 GB archive out of a fresh file mapping as long (a page
             // fault per block): side by side
-            std::future<Failure> started = std::async(std::launch::async, [d] { return d->job.init(d->opts.device); });
+            std::future<Failure> started;
+            try {
+                started = std::async(std::launch::async, [d] { return d->job.init(d->opts.device); });
+            } catch (...) {                                // no thread to be had: one after the other
+            }
             d->job.prewalk(d->bytes, d->n_bytes, d->sec, want);
-            f = started.get();
+            f = started.valid() ? started.get() : d->job.init(d->opts.device);
         } else
 #endif
             f = d->job.init(d->opts.device);

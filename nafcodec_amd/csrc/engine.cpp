@@ -301,8 +301,13 @@ bool upload_staged(uint8_t *d_dst, const uint8_t *src, size_t n, hipStream_t str
                 if (hipStreamSynchronize(sl.stream) != hipSuccess) failed = true;
             };
             std::vector<std::thread> pool;
-            for (unsigned t = 1; t < kStageThreads; t++) pool.emplace_back(worker, t);
+            unsigned started = 1;
+            try {
+                for (; started < kStageThreads; started++) pool.emplace_back(worker, started);
+            } catch (...) {                                // no more threads to be had: their chunks are done here
+            }
             worker(0);
+            for (unsigned t = started; t < kStageThreads; t++) worker(t);
             for (std::thread &th : pool) th.join();
             return !failed.load();
         }
@@ -359,12 +364,17 @@ bool SectionJob::start_source_upload(uint32_t t) {
 #endif
     sl.tile = t;
     if (hook_env("NAFGPU_DEBUG_TIMES")) std::fprintf(stderr, "[nafgpu] tile %u: %llu source bytes on their way\n", t, static_cast<unsigned long long>(n));
-    sl.pending = std::async(how, [dst, src, n, dev, st] {
+    auto send = [dst, src, n, dev, st] {
         (void)hipSetDevice(dev);
         bool ok = hip_ok(hipMemsetAsync(dst, 0, kSrcFrontPad, st)) && hip_ok(hipMemsetAsync(dst + kSrcFrontPad + n, 0, kSrcBackPad, st));
         ok = ok && (n == 0 || upload_staged(dst + kSrcFrontPad, src, static_cast<size_t>(n), st, size_t(32) << 20));
         return ok && hip_ok(hipStreamSynchronize(st));
-    });
+    };
+    try {
+        sl.pending = std::async(how, send);
+    } catch (...) {                                        // no thread to be had: the copy runs when the tile is loaded
+        sl.pending = std::async(std::launch::deferred, send);
+    }
     return true;
 }
 
@@ -793,7 +803,7 @@ void SectionJob::run_front(hipStream_t stream, StageTimer *timer, hipStream_t au
     // Streams bound for the literal buffer need nothing from K2 (their destinations are the plan's): they start on `aux`
     // now, beside k_seq_states -- a chain per block that keeps one wave per CU busy and leaves the rest of the chip idle.
     bool early = false;
-    if (n_seq_blocks_ && aux) {
+    if (n_seq_blocks_ && aux && !hook_env("NAFGPU_NO_EARLY_K1")) {   // (the hook: K2 with the chip to itself, for traces)
         bool any = false;
         for (const HufClass &c : classes_) any = any || c.to_lit;
         if (any) {
@@ -1277,10 +1287,15 @@ void ArchiveJob::prewalk(const uint8_t *bytes, size_t n, const SectionInfo sec[k
         const uint8_t *payload = bytes + sec[s].offset;
         const size_t len = static_cast<size_t>(sec[s].compressed_size);
         SectionJob *j = &job_[s];
-        if (len >= (size_t(16) << 20) && s != kQuality)
-            side.emplace_back([j, payload, len] { j->walk(payload, len); });
-        else
-            j->walk(payload, len);
+        bool aside = false;
+        if (len >= (size_t(16) << 20) && s != kQuality) {
+            try {
+                side.emplace_back([j, payload, len] { j->walk(payload, len); });
+                aside = true;
+            } catch (...) {                                // no thread to be had
+            }
+        }
+        if (!aside) j->walk(payload, len);
     }
     for (std::thread &t : side) t.join();
 }
@@ -1398,7 +1413,7 @@ Failure ArchiveJob::decode() {
     // iterator asks for the next ones, advance_tile).
     // K2 of every later single-tile section starts now, on its own stream: the sequence chains of a Quality section take
     // as long as the whole Sequence section in front of it, on one wave per CU.
-    if (k2_stream_) {
+    if (k2_stream_ && !hook_env("NAFGPU_NO_K2_AHEAD")) {   // (the hook: K2 of a section in its own place, for traces)
         bool first = true;
         for (int s = kMask + 1; s < kNumSections; s++) {
             if (!job_[s].ready() || job_[s].n_tiles() != 1) continue;

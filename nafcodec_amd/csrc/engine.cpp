@@ -1579,8 +1579,9 @@ Failure ArchiveJob::advance_tile(int s) {
     SectionJob &j = job_[s];
     if (!j.ready() || !j.tiled_output() || j.tiles_done() >= j.n_tiles()) return Failure::make(NAFGPU_E_INVALID_ARG, "no tile left");
     const double t0 = now_ms();
-    Failure f = j.decode_tile(j.tiles_done(), stream_, nullptr, aux_stream_);
-    if (hook_env("NAFGPU_DEBUG_TIMES")) std::fprintf(stderr, "[nafgpu] tile %u of section %d: %.1f ms\n", j.tiles_done(), s, now_ms() - t0);
+    const uint32_t t = j.tiles_done();
+    Failure f = j.decode_tile(t, stream_, nullptr, aux_stream_);
+    if (hook_env("NAFGPU_DEBUG_TIMES")) std::fprintf(stderr, "[nafgpu] tile %u of section %d: %.1f ms\n", t, s, now_ms() - t0);
     if (!f.ok()) {
         if (f.status != NAFGPU_E_DEVICE) fail_[s] = f;
         return f;

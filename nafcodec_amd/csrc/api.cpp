@@ -440,19 +440,22 @@ Failure errno_failure(const char *what, int e) {
 
 // the small sections and the record table come back to the host; windows over sequence / quality are bound
 Failure after_decode(nafgpu_decoder *d) {
-    Failure f;
-    auto fetch = [&](int s, std::vector<uint8_t> *dst) -> Failure {
-        if (!d->job.job(s).ready() || !d->job.section_failure(s).ok()) return Failure();
+    // ids, comments and the record table: one wait for the three of them (engine.cpp: copy_small_to_host)
+    ArchiveJob::SmallCopy copies[3];
+    int n_copies = 0;
+    auto fetch = [&](int s, std::vector<uint8_t> *dst) {
+        if (!d->job.job(s).ready() || !d->job.section_failure(s).ok()) return;
         dst->resize(static_cast<size_t>(d->job.section_size(s)));
-        return d->job.copy_to_host(dst->data(), d->job.d_section(s), dst->size());
+        copies[n_copies++] = {dst->data(), d->job.d_section(s), dst->size()};
     };
-    if (!(f = fetch(kIds, &d->ids)).ok()) return d->fatal = f;
-    if (!(f = fetch(kComments, &d->comments)).ok()) return d->fatal = f;
+    fetch(kIds, &d->ids);
+    fetch(kComments, &d->comments);
     if (d->job.job(kLengths).ready() && d->job.section_failure(kLengths).ok()) {
         d->rec_ends.resize(static_cast<size_t>(d->job.n_records()));
-        f = d->job.copy_to_host(d->rec_ends.data(), d->job.d_rec_ends(), d->rec_ends.size() * sizeof(uint64_t));
-        if (!f.ok()) return d->fatal = f;
+        copies[n_copies++] = {d->rec_ends.data(), d->job.d_rec_ends(), d->rec_ends.size() * sizeof(uint64_t)};
     }
+    Failure f = d->job.copy_small_to_host(copies, n_copies);
+    if (!f.ok()) return d->fatal = f;
     uint64_t window = std::max<uint64_t>(d->opts.buffer_size, uint64_t(64) << 20);
     if (const char *e = hook_env("NAFGPU_WINDOW_KIB")) window = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10)) << 10;   // (tests: many windows over a small section)
     d->seq_win.bind(&d->job, kSequence, d->header.sequence_type <= 1 ? 2 : 1, d->job.n_sequence_bytes(), window);

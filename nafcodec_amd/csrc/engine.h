@@ -29,13 +29,13 @@ namespace nafgpu {
 class DevBuf {
 public:
     DevBuf() = default;
-    ~DevBuf() { release(); }
+    ~DevBuf() { release(true); }
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     bool alloc(size_t bytes);                 // contents undefined
     bool alloc_items(uint64_t count, uint64_t item_bytes, uint64_t extra_bytes = 0);   // count * item_bytes + extra_bytes, overflow-checked
     bool upload(const void *host, size_t bytes, hipStream_t stream);   // alloc + async H2D
-    void release();
+    void release(bool dying = false);       // dying: the owner goes away (its streams are drained): a small buffer goes to the cache below
     void view(void *p, size_t bytes);         // a piece of another buffer: not owned, release() only forgets it
     template <class T>
     T *as() const { return static_cast<T *>(ptr_); }
@@ -47,6 +47,7 @@ private:
     void *ptr_ = nullptr;
     size_t size_ = 0, reserved_ = 0;          // reserved_ != 0: ptr_ is such a range
     bool view_ = false;
+    int cache_dev_ = -1;                      // >= 0: ptr_ is a size-class buffer of that device's cache (engine.cpp: SmallCache)
 #ifndef NAFGPU_EMU
     std::vector<hipMemGenericAllocationHandle_t> chunks_;
 #endif
@@ -127,6 +128,11 @@ public:
     void run_k2_ahead(hipStream_t st);
     // After synchronisation: device status -> Failure
     Failure check(hipStream_t stream);
+    // the same in two steps, so that the read-backs of several sections wait for the stream ONCE: check_begin enqueues them into
+    // `slot` (pinned host memory, kCheckSlotBytes of it), check_end reads the slot after the caller has synchronised the stream
+    static constexpr size_t kCheckSlotBytes = 96;
+    bool check_begin(hipStream_t stream, uint8_t *slot);
+    Failure check_end(const uint8_t *slot);
     // Tiles: uploads tile t (they are decoded in order), decodes it, synchronises, keeps what the next one needs
     // (repeat offsets, position, the LZ window).  Tile t's output then is tile_data() .. + tile_len() elements.
     uint32_t n_tiles() const { return static_cast<uint32_t>(tiles_.size()); }
@@ -267,6 +273,13 @@ public:
     void prewalk(const uint8_t *bytes, size_t n, const SectionInfo sec[kNumSections], const bool want[kNumSections]);
     // waits for background uploads (a tile's source bytes travelling ahead): before `bytes` goes away
     void drain();
+    // several small device arrays to the host with ONE wait for the stream (through a pinned block when they fit one)
+    struct SmallCopy {
+        void *dst;
+        const void *d_src;
+        size_t n;
+    };
+    Failure copy_small_to_host(const SmallCopy *copies, int count);
     // bytes must stay valid until upload() returns -- with tiles (ArchiveOptions.tile_blocks) until the last tile is decoded
     Failure upload(const uint8_t *bytes, size_t n, const nafgpu_header &h, const SectionInfo sec[kNumSections],
                    const ArchiveOptions &opt);

@@ -1405,7 +1405,11 @@ __global__ __launch_bounds__(64) void k_seq_states_lds(const uint8_t *__restrict
     uint4 fly[kSeqLdsLanes];                                             // the chunk in flight of every block (this thread's 16 bytes of it)
     auto load16 = [&](uint64_t at) -> uint4 {
         uint4 v = make_uint4(0, 0, 0, 0);
+#ifdef NAFGPU_EMU
+        if (static_cast<long long>(at) >= src_min) __builtin_memcpy(&v, src + at, 16);   // (the host compiler may take uint4 for aligned)
+#else
         if (static_cast<long long>(at) >= src_min) v = *reinterpret_cast<const uint4 *>(src + at);
+#endif
         return v;
     };
 #pragma unroll

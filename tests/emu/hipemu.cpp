@@ -184,6 +184,9 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
 hipError_t hipMalloc(void **p, size_t n) {
     void *q = nullptr;
     if (posix_memalign(&q, 256, n ? n : 1) != 0) return hipErrorOutOfMemory;
+    // device memory comes with whatever was there before (the product keeps small buffers from one decoder to the next):
+    // nothing may count on zeros
+    if (n <= (size_t(64) << 20)) std::memset(q, 0xA5, n);
     *p = q;
     return hipSuccess;
 }

@@ -297,6 +297,16 @@ lib.c.nafgpu_test_hooks(0)
 import io
 from nafcodec_amd.decoder import Decoder
 bad += ["text:" + n for n, blob in cases.text_cases(1)[part::parts] if Decoder(io.BytesIO(blob), _lib=lib).to_text() != cases.oracle_text(blob)]
+if part == 1:                                            # tiles of a dense-LZ section into the WHOLE output: the last tile's upper bound lies behind it
+    os.environ["NAFGPU_TILE_KIB"] = "300"
+    lib.c.nafgpu_test_hooks(1)
+    for n, blob, opts in [c for c in cases.build_cases(1) if c[0] == "dna_l3_big"]:
+        d = Decoder(io.BytesIO(blob), _lib=lib)
+        res = d.decode_all_device()
+        if d.copy_to_host(res.d_sequence, res.n_bases) != "".join(r[2] or "" for r in cases.run_oracle(blob, opts)[0]).encode():
+            bad.append("tiles, bulk:" + n)
+    del os.environ["NAFGPU_TILE_KIB"]
+    lib.c.nafgpu_test_hooks(0)
 print("BAD", bad)
 sys.exit(1 if bad else 0)
 """ % (ROOT, os.path.join(ROOT, "tests"), os.path.join(EMU_DIR, "libnafgpu_emu_asan.so"))

@@ -482,3 +482,31 @@ def test_encoder_output_decodes_on_the_gpu(lib):
             assert len(got) == len(recs)
             for a, b in zip(got, recs):
                 assert (a.id, a.comment, a.sequence, a.quality, a.length) == (b.id, b.comment, b.sequence, b.quality, len(b.sequence)), (st, level, b.id)
+
+
+@pytest.mark.gpu
+def test_decoders_in_several_threads_at_once(lib):
+    """Decoders are independent objects: four threads each open, read and close the reference's fixtures and a few generated
+    archives over and over (ctypes releases the GIL inside every call), sharing the library's process-wide pools -- streams,
+    pinned windows, small device buffers, the staging threads of large uploads.  Every run must give the oracle's records."""
+    import threading
+    todo = [(n, golden_bytes(n + ".naf"), {}) for n in ("NZ_AAEN01000029", "phix", "LuxC", "masked")]
+    todo += [c for c in cases.build_cases(1) if c[0] in ("dna_l3_big", "text_quality", "dna_multi_tree_compact", "fastq_flush_per_record")]
+    want = {name: cases.run_oracle(blob, opts) for name, blob, opts in todo}
+    bad = []
+
+    def work(k):
+        try:
+            for rep in range(6):
+                for name, blob, opts in todo[k % 2::2] if rep % 2 else todo:
+                    if cases.run_product(blob, opts, lib) != want[name]:
+                        bad.append((k, rep, name))
+        except Exception as e:                              # noqa: BLE001
+            bad.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not bad, bad[:5]

@@ -61,6 +61,7 @@ namespace {
 // K1's 610 k write fronts), which is what made K1 take 10.7-11.9 ms on the same archive.  Chunked backing gave 6.7 TB/s in
 // nine allocations out of nine, whatever the chunk size (2 MiB, 64 MiB, 1 GiB).
 constexpr size_t kVmmMinBytes = size_t(32) << 20, kVmmChunk = size_t(1) << 30;
+constexpr int kSmallDevices = 16;                          // devices the process-wide pools below know of
 
 bool vmm_usable(int dev, size_t *gran) {
     int ok = 0;
@@ -74,15 +75,84 @@ bool vmm_usable(int dev, size_t *gran) {
 }
 }  // namespace
 
+// Mapped ranges outlive the buffers they were.  Unmapping a range and mapping memory at the same addresses a moment later is
+// (a) slow -- the address ranges and chunks of a 50 GB decoder take 10 ms in one process and 0.3-0.8 s in the next -- and
+// (b) NOT SAFE on this stack: a decoder that went from tiles to the whole output (its 2 GiB tile buffer unmapped and freed,
+// buffers of 4.4 GB and 1.1 GB reserved and mapped in the same call, the smaller one at the addresses just freed) found
+// about every other 4 KiB page of its freshly uploaded source bytes holding something else -- zeros where the chunks were
+// new, old bytes where they were reused (NAFGPU_DEBUG_VERIFY_UPLOAD; plain hipMalloc: fine; unmapping chunk by chunk and
+// keeping the chunks for reuse: no better).  Translations of the old mapping seem to outlive it.  So a released range stays
+// as it is -- reserved, mapped, its chunks in place -- and waits here for the next buffer of its size (sizes are multiples of
+// kVmmTail, so that they meet their like again; a range up to an eighth larger than asked for is taken too).  When a creation
+// fails for want of memory the idle ranges are unmapped and their chunks released, but their ADDRESSES are never given back:
+// no later mapping can land where an old one was.
+namespace {
+constexpr size_t kVmmTail = size_t(64) << 20;
+struct IdleRange {
+    void *va;
+    size_t total, chunk;
+    std::vector<hipMemGenericAllocationHandle_t> chunks;
+};
+struct RangePool {
+    std::mutex mu;
+    std::vector<IdleRange> idle[kSmallDevices];
+};
+RangePool &range_pool() {
+    static RangePool *p = new RangePool;
+    return *p;
+}
+bool range_take(int dev, size_t total, size_t chunk, IdleRange *out) {
+    RangePool &rp = range_pool();
+    std::lock_guard<std::mutex> lock(rp.mu);
+    auto &v = rp.idle[dev];
+    size_t best = v.size();
+    for (size_t i = 0; i < v.size(); i++)
+        if (v[i].chunk == chunk && v[i].total >= total && v[i].total - total <= total / 8 && (best == v.size() || v[i].total < v[best].total)) best = i;
+    if (best == v.size()) return false;
+    *out = std::move(v[best]);
+    v.erase(v.begin() + static_cast<std::ptrdiff_t>(best));
+    return true;
+}
+void range_give(int dev, IdleRange &&r) {
+    RangePool &rp = range_pool();
+    std::lock_guard<std::mutex> lock(rp.mu);
+    rp.idle[dev].push_back(std::move(r));
+}
+void range_trim(int dev) {                                 // the memory of everything idle goes back to the driver (not the addresses)
+    RangePool &rp = range_pool();
+    std::lock_guard<std::mutex> lock(rp.mu);
+    for (IdleRange &r : rp.idle[dev]) {
+        size_t k = 0;
+        for (size_t off = 0; off < r.total; off += r.chunk, k++) {
+            (void)hipMemUnmap(static_cast<char *>(r.va) + off, std::min(r.chunk, r.total - off));
+            if (k < r.chunks.size()) (void)hipMemRelease(r.chunks[k]);
+        }
+    }
+    rp.idle[dev].clear();
+}
+}  // namespace
+
 bool DevBuf::alloc_mapped(size_t bytes) {
     int dev = 0;
     size_t gran = 0;
-    if (!hip_ok(hipGetDevice(&dev)) || !vmm_usable(dev, &gran)) return false;
-    const size_t total = (bytes + gran - 1) / gran * gran;
+    if (!hip_ok(hipGetDevice(&dev)) || dev < 0 || dev >= kSmallDevices || !vmm_usable(dev, &gran)) return false;
     size_t chunk = kVmmChunk;
     if (const char *ce = hook_env("NAFGPU_VMM_CHUNK_MIB")) {        // (experiments: tools/placement_probe.sh)
         const size_t want = static_cast<size_t>(std::strtoull(ce, nullptr, 10)) << 20;
         if (want >= gran && want % gran == 0) chunk = want;
+    }
+    const size_t tail_unit = kVmmTail % gran == 0 && chunk % kVmmTail == 0 ? kVmmTail : gran;
+    const size_t total = (bytes + tail_unit - 1) / tail_unit * tail_unit;
+    {
+        IdleRange r;
+        if (!hook_env("NAFGPU_VMM_NO_POOL") && range_take(dev, total, chunk, &r)) {
+            ptr_ = r.va;
+            size_ = bytes;
+            reserved_ = r.total;
+            chunk_bytes_ = r.chunk;
+            chunks_ = std::move(r.chunks);
+            return true;
+        }
     }
     void *va = nullptr;
     if (!hip_ok(hipMemAddressReserve(&va, total, gran, nullptr, 0)) || !va) return false;
@@ -95,7 +165,11 @@ bool DevBuf::alloc_mapped(size_t bytes) {
     for (size_t off = 0; off < total && ok; off += chunk) {
         const size_t n = total - off < chunk ? total - off : chunk;
         hipMemGenericAllocationHandle_t h;
-        if (!hip_ok(hipMemCreate(&h, n, &prop, 0))) { ok = false; break; }
+        if (!hip_ok(hipMemCreate(&h, n, &prop, 0))) {
+            (void)hipGetLastError();
+            range_trim(dev);                               // (what waits for a buffer of another size gives its memory back first)
+            if (!hip_ok(hipMemCreate(&h, n, &prop, 0))) { ok = false; break; }
+        }
         if (!hip_ok(hipMemMap(static_cast<char *>(va) + off, n, 0, h, 0))) {
             (void)hipMemRelease(h);
             ok = false;
@@ -111,7 +185,7 @@ bool DevBuf::alloc_mapped(size_t bytes) {
         ok = hip_ok(hipMemSetAccess(va, total, &acc, 1));
     }
     if (!ok) {                                   // e.g. out of device memory: undo, the caller reports the failure of hipMalloc
-        if (mapped) (void)hipMemUnmap(va, mapped);
+        for (size_t off = 0; off < mapped; off += chunk) (void)hipMemUnmap(static_cast<char *>(va) + off, std::min(chunk, mapped - off));
         for (auto h : chunks_) (void)hipMemRelease(h);
         chunks_.clear();
         (void)hipMemAddressFree(va, total);
@@ -121,6 +195,7 @@ bool DevBuf::alloc_mapped(size_t bytes) {
     ptr_ = va;
     size_ = bytes;
     reserved_ = total;
+    chunk_bytes_ = chunk;
     return true;
 }
 #endif
@@ -138,7 +213,7 @@ bool DevBuf::alloc_mapped(size_t bytes) {
 // rounded-up sizes would hide small overruns from the sanitizer.
 namespace {
 constexpr size_t kSmallMax = size_t(256) << 10, kSmallMin = 256, kSmallKeepBytes = size_t(64) << 20;
-constexpr int kSmallClasses = 11, kSmallDevices = 16;      // 256 B .. 256 KiB
+constexpr int kSmallClasses = 11;                          // 256 B .. 256 KiB
 struct SmallCache {
     std::mutex mu;
     std::vector<void *> idle[kSmallDevices][kSmallClasses];
@@ -187,7 +262,11 @@ bool DevBuf::alloc(size_t bytes) {
                 sc.bytes -= kSmallMin << c;
             }
         }
-        if (!p && !hip_ok(hipMalloc(&p, kSmallMin << c))) return false;
+        if (!p && !hip_ok(hipMalloc(&p, kSmallMin << c))) {
+            (void)hipGetLastError();
+            range_trim(dev);                               // (idle ranges give their memory back before anything fails for want of it)
+            if (!hip_ok(hipMalloc(&p, kSmallMin << c))) return false;
+        }
         ptr_ = p;
         size_ = kSmallMin << c;
         cache_dev_ = dev;
@@ -195,7 +274,17 @@ bool DevBuf::alloc(size_t bytes) {
     }
 #endif
     void *p = nullptr;
-    if (!hip_ok(hipMalloc(&p, bytes ? bytes : 16))) return false;
+    if (!hip_ok(hipMalloc(&p, bytes ? bytes : 16))) {
+#ifndef NAFGPU_EMU
+        (void)hipGetLastError();
+        int d = 0;
+        if (!hip_ok(hipGetDevice(&d)) || d < 0 || d >= kSmallDevices) return false;
+        range_trim(d);
+        if (!hip_ok(hipMalloc(&p, bytes ? bytes : 16))) return false;
+#else
+        return false;
+#endif
+    }
     ptr_ = p;
     size_ = bytes ? bytes : 16;
     return true;
@@ -234,10 +323,22 @@ void DevBuf::release(bool dying) {
 #endif
 #ifndef NAFGPU_EMU
     if (ptr_ && reserved_) {
-        (void)hipMemUnmap(ptr_, reserved_);
-        for (auto h : chunks_) (void)hipMemRelease(h);
+        // (range_pool above: why the range is kept as it is rather than unmapped)
+        int dev = 0;
+        if (hip_ok(hipGetDevice(&dev)) && dev >= 0 && dev < kSmallDevices && !hook_env("NAFGPU_VMM_NO_POOL")) {
+            if (!dying) (void)hipDeviceSynchronize();      // (a living owner: whatever it still has in flight is done before another takes the range)
+            IdleRange r{ptr_, reserved_, chunk_bytes_ ? chunk_bytes_ : reserved_, std::move(chunks_)};
+            range_give(dev, std::move(r));
+        } else {                                           // chunk by chunk, as they were mapped
+            const size_t step = chunk_bytes_ ? chunk_bytes_ : reserved_;
+            size_t k = 0;
+            for (size_t off = 0; off < reserved_; off += step, k++) {
+                (void)hipMemUnmap(static_cast<char *>(ptr_) + off, std::min(step, reserved_ - off));
+                if (k < chunks_.size()) (void)hipMemRelease(chunks_[k]);
+            }
+            (void)hipMemAddressFree(ptr_, reserved_);
+        }
         chunks_.clear();
-        (void)hipMemAddressFree(ptr_, reserved_);
         ptr_ = nullptr;
     }
 #endif
@@ -741,6 +842,50 @@ Failure SectionJob::load_tile(uint32_t t, hipStream_t stream) {
     if (!ok) return Failure::make(NAFGPU_E_DEVICE, "out of device memory while preparing a section");
     // the host vectors were consumed by asynchronous copies: keep them until the stream drains
     if (!hip_ok(hipStreamSynchronize(stream))) return Failure::make(NAFGPU_E_DEVICE, "upload of task lists failed");
+    if (hook_env("NAFGPU_DEBUG_VERIFY_UPLOAD") && src_n) {     // (chasing a bad upload: the source bytes read back and compared)
+        std::vector<uint8_t> back(static_cast<size_t>(src_n));
+        (void)hipMemcpy(back.data(), d_src_ + plan_.src_lo, back.size(), hipMemcpyDeviceToHost);
+        size_t bad = 0, first = 0, last = 0;
+        for (size_t i = 0; i < back.size(); i++)
+            if (back[i] != host_payload_[plan_.src_lo + i]) {
+                if (!bad) first = i;
+                last = i;
+                bad++;
+            }
+        std::fprintf(stderr, "[nafgpu] tile %u: %zu source bytes on the device, %zu differ (first at %zu, last at %zu)\n", t, back.size(), bad, first, last);
+        if (bad) {                                             // where in the payload do the wrong bytes come from?
+            const size_t probe = ((first + 4096) & ~size_t(15));
+            const void *hit = probe + 64 <= back.size() ? memmem(host_payload_, plan_.src_hi, back.data() + probe, 64) : nullptr;
+            std::fprintf(stderr, "[nafgpu]   the 64 bytes at %zu are the payload's bytes at %lld; d_src_buf_ %p size %zu, slots %p %p\n", probe,
+                         hit ? static_cast<long long>(static_cast<const uint8_t *>(hit) - host_payload_) : -1ll, static_cast<void *>(d_src_buf_.bytes()),
+                         d_src_buf_.size(), static_cast<void *>(src_slot_[0].buf.bytes()), static_cast<void *>(src_slot_[1].buf.bytes()));
+            {   // the first 64 KiB: runs of wrong bytes at 16-byte granularity, and where the first wrong 32 bytes come from
+                size_t r0 = 0, shown = 0;
+                bool w_in = false;
+                for (size_t i = 0; i < std::min<size_t>(back.size(), 1 << 16); i += 16) {
+                    const bool w = std::memcmp(back.data() + i, host_payload_ + plan_.src_lo + i, std::min<size_t>(16, back.size() - i)) != 0;
+                    if (w && !w_in) r0 = i;
+                    if (!w && w_in && shown++ < 10) std::fprintf(stderr, "[nafgpu]   wrong bytes %zu .. %zu\n", r0, i);
+                    w_in = w;
+                }
+                const size_t m = first & ~size_t(15);
+                const void *h2 = m + 32 <= back.size() ? memmem(host_payload_, plan_.src_hi, back.data() + m, 32) : nullptr;
+                std::fprintf(stderr, "[nafgpu]   the 32 device bytes at %zu are the payload's at %lld; first bytes there %02x %02x %02x %02x, expected %02x %02x %02x %02x\n", m,
+                             h2 ? static_cast<long long>(static_cast<const uint8_t *>(h2) - host_payload_) : -1ll, back[m], back[m + 1], back[m + 2], back[m + 3],
+                             host_payload_[plan_.src_lo + m], host_payload_[plan_.src_lo + m + 1], host_payload_[plan_.src_lo + m + 2], host_payload_[plan_.src_lo + m + 3]);
+            }
+            size_t run0 = first, runs = 0;                     // the runs of wrong bytes, 1 MiB granularity
+            bool in = false;
+            for (size_t i = 0; i < back.size(); i += size_t(1) << 20) {
+                const size_t e = std::min(back.size(), i + (size_t(1) << 20));
+                const bool w = std::memcmp(back.data() + i, host_payload_ + plan_.src_lo + i, e - i) != 0;
+                if (w && !in) run0 = i;
+                if (!w && in && runs++ < 12) std::fprintf(stderr, "[nafgpu]   wrong from MiB %zu to %zu\n", run0 >> 20, i >> 20);
+                in = w;
+            }
+            if (in) std::fprintf(stderr, "[nafgpu]   wrong from MiB %zu to the end\n", run0 >> 20);
+        }
+    }
     // only the counts are needed from here on
     std::vector<HufStream>().swap(plan_.streams);
     std::vector<HufTableRef>().swap(plan_.stream_ref);

@@ -50,6 +50,7 @@ private:
     int cache_dev_ = -1;                      // >= 0: ptr_ is a size-class buffer of that device's cache (engine.cpp: SmallCache)
 #ifndef NAFGPU_EMU
     std::vector<hipMemGenericAllocationHandle_t> chunks_;
+    size_t chunk_bytes_ = 0;                  // every chunk but the last maps this many bytes
 #endif
 };
 

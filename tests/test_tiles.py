@@ -130,3 +130,41 @@ def test_the_iterator_takes_a_large_section_tile_by_tile():
         lib.c.nafgpu_synth_free(ctypes.byref(arc))
         if os.path.exists(path):
             os.unlink(path)
+
+
+@pytest.mark.gpu
+def test_switching_between_the_iterator_and_the_whole_output_while_bytes_travel_ahead():
+    """One decoder over a 4.4-Gbase archive: a few records through the iterator (tiles, the next tile's compressed bytes and the
+    next window on their way), then the whole output at once (the device side is prepared again: what travels is waited for
+    first), then the iterator again from where it stood, then close with a tile still travelling."""
+    import ctypes
+    import numpy as np
+    from nafcodec_amd import _ffi
+    from nafcodec_amd.decoder import Decoder
+    lib = _ffi.default()
+    n = 4_400_000_123
+    arc = lib.synth(n, seed=12)
+    path = "/dev/shm/nafgpu_iter_switch_%d.naf" % os.getpid()
+    try:
+        with open(path, "wb") as f:
+            f.write((ctypes.c_char * arc.n).from_address(arc.bytes))
+        d = Decoder(path)
+        first = d.read_batch(40)
+        assert len(first) == 40
+        res = d.decode_all_device()
+        assert (res.n_bases, res.n_records) == (arc.n_bases, arc.n_records)
+        assert d.hash_device(res.d_sequence, res.n_bases) == arc.seq_hash
+        pos = sum(len(r.sequence) for r in first)
+        assert d.copy_to_host(res.d_sequence, pos) == "".join(r.sequence for r in first).encode()
+        more = d.read_batch(40)                            # the iterator goes on where it stood
+        assert len(more) > 0
+        m = sum(len(r.sequence) for r in more)
+        assert d.copy_to_host(res.d_sequence + pos, m) == "".join(r.sequence for r in more).encode()
+        d.close()
+        d = Decoder(path)                                  # ... and a decoder closed while the second tile's bytes are on their way
+        assert d.read().sequence == first[0].sequence
+        d.close()
+    finally:
+        lib.c.nafgpu_synth_free(ctypes.byref(arc))
+        if os.path.exists(path):
+            os.unlink(path)

@@ -271,6 +271,10 @@ int nafgpu_format_device(nafgpu_decoder *dec, nafgpu_text_result *out);
 int nafgpu_copy_to_host(nafgpu_decoder *dec, const void *d_ptr, uint64_t n, void *dst);
 /* hipDeviceSynchronize on `device` (-1 = current) */
 int nafgpu_device_synchronize(int device);
+/* The library keeps the device memory of closed decoders for the next one (mapped ranges of 32 MiB and more, up to 16 GiB
+ * of them idle per device; small buffers up to 64 MiB in all): this call gives all of it back to the driver -- before
+ * another allocator or another process needs the device (no counterpart in the reference; -1 = current device). */
+int nafgpu_trim_device_memory(int device);
 
 /* ---- L0 replacement on its own: one NAF section payload ------------------------------
  * Replaces zstd::stream::read::Decoder + include_magicbytes(false) (decoder/mod.rs:221-223)

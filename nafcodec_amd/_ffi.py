@@ -101,7 +101,7 @@ EXPORTS = [
     "nafgpu_encoder_opts_default", "nafgpu_encoder_opts_from_flags", "nafgpu_encoder_new", "nafgpu_encoder_push",
     "nafgpu_encoder_finish", "nafgpu_encoder_free", "nafgpu_test_hooks",
     "nafgpu_hash64_host_at", "nafgpu_shard_begin", "nafgpu_shard_place", "nafgpu_shard_halo", "nafgpu_shard_export_tail",
-    "nafgpu_shard_import_halo", "nafgpu_shard_finish", "nafgpu_next_batch",
+    "nafgpu_shard_import_halo", "nafgpu_shard_finish", "nafgpu_next_batch", "nafgpu_trim_device_memory",
 ]
 
 
@@ -134,6 +134,8 @@ class Library:
         L.nafgpu_decode_all_device.argtypes = [c_void_p, POINTER(DeviceResult)]
         L.nafgpu_upload.argtypes = [c_void_p]
         L.nafgpu_device_synchronize.argtypes = [c_int]
+        if hasattr(L, "nafgpu_trim_device_memory"):          # (absent from older builds loaded for A/B runs)
+            L.nafgpu_trim_device_memory.argtypes = [c_int]
         L.nafgpu_zstd_decompress.argtypes = [c_char_p, c_size_t, c_void_p, c_size_t, POINTER(c_size_t), c_int,
                                              POINTER(Error)]
         L.nafgpu_encoder_opts_default.argtypes = [c_uint8, POINTER(EncoderOpts)]

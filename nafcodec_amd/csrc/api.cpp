@@ -967,6 +967,13 @@ int nafgpu_device_synchronize(int device) {
     return hipDeviceSynchronize() == hipSuccess ? NAFGPU_OK : NAFGPU_E_DEVICE;
 }
 
+int nafgpu_trim_device_memory(int device) {
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) return NAFGPU_E_DEVICE;
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return NAFGPU_E_DEVICE;
+    trim_device_memory(device);
+    return NAFGPU_OK;
+}
+
 int nafgpu_hash64_device(const nafgpu_decoder *d, const void *d_ptr, uint64_t n, uint64_t *out) {
     return nafgpu_hash64_device_at(d, d_ptr, n, 0, out);
 }

@@ -113,21 +113,33 @@ bool range_take(int dev, size_t total, size_t chunk, IdleRange *out) {
     v.erase(v.begin() + static_cast<std::ptrdiff_t>(best));
     return true;
 }
+void range_drop(IdleRange &r) {                            // memory back to the driver, the addresses stay reserved
+    size_t k = 0;
+    for (size_t off = 0; off < r.total; off += r.chunk, k++) {
+        (void)hipMemUnmap(static_cast<char *>(r.va) + off, std::min(r.chunk, r.total - off));
+        if (k < r.chunks.size()) (void)hipMemRelease(r.chunks[k]);
+    }
+}
+// idle ranges kept per device at most (the oldest go first).  Not more: a process that holds -- or has just given back -- a hundred
+// gigabytes makes the NEXT process's first allocations take 0.5 s longer (bench.py's iterator legs run in children)
+constexpr size_t kVmmKeepBytes = size_t(16) << 30;
 void range_give(int dev, IdleRange &&r) {
     RangePool &rp = range_pool();
     std::lock_guard<std::mutex> lock(rp.mu);
-    rp.idle[dev].push_back(std::move(r));
+    auto &v = rp.idle[dev];
+    v.push_back(std::move(r));
+    size_t held = 0;
+    for (const IdleRange &e : v) held += e.total;
+    while (held > kVmmKeepBytes && v.size() > 1) {
+        held -= v.front().total;
+        range_drop(v.front());
+        v.erase(v.begin());
+    }
 }
 void range_trim(int dev) {                                 // the memory of everything idle goes back to the driver (not the addresses)
     RangePool &rp = range_pool();
     std::lock_guard<std::mutex> lock(rp.mu);
-    for (IdleRange &r : rp.idle[dev]) {
-        size_t k = 0;
-        for (size_t off = 0; off < r.total; off += r.chunk, k++) {
-            (void)hipMemUnmap(static_cast<char *>(r.va) + off, std::min(r.chunk, r.total - off));
-            if (k < r.chunks.size()) (void)hipMemRelease(r.chunks[k]);
-        }
-    }
+    for (IdleRange &r : rp.idle[dev]) range_drop(r);
     rp.idle[dev].clear();
 }
 }  // namespace
@@ -345,6 +357,29 @@ void DevBuf::release(bool dying) {
     if (ptr_) (void)hipFree(ptr_);
     ptr_ = nullptr;
     size_ = reserved_ = 0;
+}
+
+void trim_device_memory(int device) {
+#ifndef NAFGPU_EMU
+    if (device < 0 || device >= kSmallDevices) return;
+    (void)hipDeviceSynchronize();
+    range_trim(device);
+    std::vector<void *> gone;
+    {
+        SmallCache &sc = small_cache();
+        std::lock_guard<std::mutex> lock(sc.mu);
+        for (int c = 0; c < kSmallClasses; c++) {
+            for (void *p : sc.idle[device][c]) {
+                gone.push_back(p);
+                sc.bytes -= kSmallMin << c;
+            }
+            sc.idle[device][c].clear();
+        }
+    }
+    for (void *p : gone) (void)hipFree(p);
+#else
+    (void)device;
+#endif
 }
 
 // ------------------------------------------------------------------ StageTimer

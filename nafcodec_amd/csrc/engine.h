@@ -263,7 +263,8 @@ struct ArchiveOptions {
     bool tiled_output = false;                  // ... whose output is held one tile at a time (iterator path; not for decode_all_device)
 };
 
-bool upload_staged(uint8_t *d_dst, const uint8_t *src, size_t n, hipStream_t stream, size_t stage_min = 0);   // engine.cpp: large host -> device copies
+bool upload_staged(uint8_t *d_dst, const uint8_t *src, size_t n, hipStream_t stream, size_t stage_min = 0);
+void trim_device_memory(int device);             // engine.cpp: the idle mapped ranges and small buffers of `device` go back to the driver   // engine.cpp: large host -> device copies
 
 // A whole archive on one GPU: sections -> record table -> ASCII bases.
 class ArchiveJob {

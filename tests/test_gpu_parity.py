@@ -510,3 +510,36 @@ def test_decoders_in_several_threads_at_once(lib):
     for t in threads:
         t.join()
     assert not bad, bad[:5]
+
+
+@pytest.mark.gpu
+def test_kept_device_memory_is_given_back_on_request(lib):
+    """Closed decoders leave their large mapped ranges and small buffers to the next decoder of the process
+    (engine.cpp: range_pool, SmallCache); nafgpu_trim_device_memory gives them back to the driver, and a decoder after that
+    works as one before it."""
+    hip = ctypes.CDLL("libamdhip64.so")                     # (the runtime the library itself is linked to: hipMemGetInfo)
+
+    def free_bytes():
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
+    arc = lib.synth(600_000_011, seed=21)
+    try:
+        blob = ctypes.string_at(arc.bytes, arc.n)
+
+        def once():
+            from nafcodec_amd.decoder import Decoder
+            with Decoder(io.BytesIO(blob)) as d:
+                res = d.decode_all_device()
+                assert d.hash_device(res.d_sequence, res.n_bases) == arc.seq_hash
+
+        once()
+        free_kept = free_bytes()
+        assert lib.c.nafgpu_trim_device_memory(0) == 0
+        free_trimmed = free_bytes()
+        assert free_trimmed >= free_kept, (free_kept, free_trimmed)                   # (hipMemGetInfo does not count hipMemCreate chunks: the small buffers show)
+        once()                                                                        # ... and a decoder after the trim is as good as one before
+        once()
+    finally:
+        lib.c.nafgpu_synth_free(ctypes.byref(arc))

@@ -342,6 +342,7 @@ void DevBuf::release(bool dying) {
             IdleRange r{ptr_, reserved_, chunk_bytes_ ? chunk_bytes_ : reserved_, std::move(chunks_)};
             range_give(dev, std::move(r));
         } else {                                           // chunk by chunk, as they were mapped
+            if (hook_env("NAFGPU_VMM_SYNC_UNMAP")) (void)hipDeviceSynchronize();   // (experiment: is anything still in flight on the range?)
             const size_t step = chunk_bytes_ ? chunk_bytes_ : reserved_;
             size_t k = 0;
             for (size_t off = 0; off < reserved_; off += step, k++) {

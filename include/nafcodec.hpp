@@ -257,4 +257,7 @@ private:
     nafgpu_encoder_opts o_{};
 };
 
+// (no counterpart in the reference: the library keeps device memory of closed decoders for the next one -- nafgpu.h)
+inline void trim_device_memory(int device = -1) { (void)nafgpu_trim_device_memory(device); }
+
 }  // namespace nafcodec

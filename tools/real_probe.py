@@ -10,6 +10,7 @@ import zstd_ref, naf_writer as nw
 import nafcodec_amd
 from nafcodec_amd import _ffi
 from oracle import oracle
+if os.environ.get("NAFGPU_PROBE_HOOKS"): _ffi.default().c.nafgpu_test_hooks(1)   # (experiments: the NAFGPU_* switches are read)
 
 copies = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 blob = open(os.path.join(R, "tests", "golden", "NZ_AAEN01000029.naf"), "rb").read()
